@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the DiffUS hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays x
+512 steps.  One *step* = one pass of the hot path over one batch of poses:
+  forward frame (diffus_render_fwd) -> loss = sum(frame^2) per pose ->
+  zero the volume gradient -> backward (diffus_render_bwd: d/d volume,
+  d/d source, d/d directions) -> gather of the per-pose losses over ranks.
+Workload at N=1 = BASELINE config 3 (32 poses of the config-2 shape on one GPU;
+a single 256x512 frame is only 256 wavefronts, i.e. launch-latency-bound, and is
+reported separately as `single_pose`).  Multi-GPU: poses shard contiguously over
+ranks, 32 per GPU (weak scaling; N=8 is BASELINE config 4), the volume is
+replicated, the only collective is one all_gather of P losses (RCCL).
+
+Inputs are resident in HBM before the timed region.  Kernel durations for the
+roofline come from HIP events recorded on the launch stream (torch's current
+stream, which is the one handed to the C-ABI).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from diffus_amd import _lib  # noqa: E402
+from diffus_amd.phantom import phantom, pose_ring  # noqa: E402
+
+# algorithmic bytes per ray-step, no-reuse model (SURVEY §8d / DESIGN.md §Roofline)
+BYTES = {
+    "trilinear": {"fwd": 36, "bwd": 100, "bwd_pose_only": 36},
+    "nearest": {"fwd": 8, "bwd": 16, "bwd_pose_only": 8},
+}
+HBM_PEAK_GBS = 8000.0
+
+
+class HotPath:
+    """Pre-allocated buffers + direct C-ABI calls (what a captured training step does)."""
+
+    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True):
+        self.lib = _lib.load()
+        self.vol, self.src, self.dirs = vol, src, dirs
+        self.P, self.R = dirs.shape[0], dirs.shape[1]
+        self.S, self.start, self.alpha = S, start, alpha
+        self.sampler = {"nearest": 0, "trilinear": 1}[sampler]
+        dev = vol.device
+        N1 = S - start
+        self.frame = torch.empty((self.P, self.R, N1), dtype=torch.float32, device=dev)
+        self.gframe = torch.empty_like(self.frame)
+        self.gvol = torch.zeros_like(vol) if want_gvol else None
+        self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
+        self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
+        self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
+        nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, S, start), 256)
+        self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        d0, d1, d2 = vol.shape
+        self.common = (C.c_void_p(vol.data_ptr()), d0, d1, d2, C.c_void_p(src.data_ptr()), 0,
+                       C.c_void_p(dirs.data_ptr()), 0, self.P, self.R, S, start, float(alpha), self.sampler)
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd(self):
+        rc = self.lib.diffus_render_fwd(*self.common, C.c_void_p(self.frame.data_ptr()), None,
+                                        C.c_void_p(self.ws.data_ptr()), self.ws.numel(), self.stream())
+        _lib.check(rc, "diffus_render_fwd")
+
+    def bwd(self):
+        rc = self.lib.diffus_render_bwd(*self.common, C.c_void_p(self.gframe.data_ptr()),
+                                        C.c_void_p(self.gvol.data_ptr()) if self.gvol is not None else None,
+                                        C.c_void_p(self.gsrc.data_ptr()), C.c_void_p(self.gdirs.data_ptr()),
+                                        C.c_void_p(self.ws.data_ptr()), self.ws.numel(), self.stream())
+        _lib.check(rc, "diffus_render_bwd")
+
+    def loss_and_grad(self):
+        # L_p = sum(frame_p^2); dL/dframe = 2 frame
+        torch.mul(self.frame, 2.0, out=self.gframe)
+        torch.sum(self.frame * self.frame, dim=(1, 2), out=self.loss)
+
+    def step(self):
+        self.fwd()
+        self.loss_and_grad()
+        if self.gvol is not None:
+            self.gvol.zero_()
+        self.bwd()
+
+
+def time_events(fn, iters):
+    """Average device time of fn() in ms, HIP events on the current (launch) stream."""
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    for i in range(iters):
+        e0[i].record()
+        fn()
+        e1[i].record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
+    return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+
+
+def cpu_baseline(budget_rays=64, budget_steps=256):
+    """The reference's algorithm (N+1 dense torch.linalg.solve, oracle/dense.py) on
+    the host cores, on a bounded sample: config 1 = 64 rays x 256 steps, forward
+    only (the dense backward needs ~rays*steps^3 memory)."""
+    from oracle import dense
+    from oracle import oracle as orc
+    n = 256
+    vol = phantom(n)
+    src, dirs = pose_ring(n, 32, budget_rays)
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    dense.plot_beam_frame_dense(torch.from_numpy(vol), torch.from_numpy(src[0]), torch.from_numpy(dirs[0]),
+                                budget_steps, 1e-4, 0)
+    dt = time.perf_counter() - t0
+    out = {"value": budget_rays * budget_steps / dt, "unit": "ray-steps/s", "cores": torch.get_num_threads(),
+           "kind": "port",
+           "sample": f"reference algorithm (N+1 dense torch.linalg.solve, oracle/dense.py), forward only, "
+                     f"1 pose x {budget_rays} rays x {budget_steps} steps on the 256^3 phantom "
+                     f"(BASELINE config 1), {dt:.2f} s wall"}
+    # algorithm-matched extra: the O(N) scalar C oracle, one 256x512 pose, trilinear forward
+    src2, dirs2 = pose_ring(n, 32, 256)
+    orc.build()
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 2.0:
+        orc.plot_beam_frame(vol, src2[reps % 32], dirs2[reps % 32], 512, 1e-4, 0, sampler="trilinear")
+        reps += 1
+    dt2 = time.perf_counter() - t0
+    out["cpu_scan_value"] = reps * 256 * 512 / dt2
+    out["cpu_scan_note"] = "O(N) running-product C oracle (oracle/diffus_oracle.c), 1 thread, trilinear forward only"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--poses", type=int, default=32, help="poses per GPU")
+    ap.add_argument("--rays", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=512)
+    ap.add_argument("--n", type=int, default=256, help="volume edge")
+    ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
+    ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--alpha", type=float, default=1e-4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    ngpu = world
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    P_total = args.poses * ngpu
+    vol = torch.from_numpy(phantom(args.n)).to(dev)
+    src_all, dirs_all = pose_ring(args.n, P_total, args.rays)
+    lo = rank * args.poses
+    src = torch.from_numpy(src_all[lo:lo + args.poses]).to(dev).contiguous()
+    dirs = torch.from_numpy(dirs_all[lo:lo + args.poses]).to(dev).contiguous()
+    hp = HotPath(vol, src, dirs, args.samples, args.alpha, args.sampler, want_gvol=not args.no_gvol)
+    losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
+
+    def step():
+        hp.step()
+        if dist is not None:
+            dist.all_gather_into_tensor(losses_all, hp.loss)   # the one collective: P losses over xGMI
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ray_steps = P_total * args.rays * args.samples
+    value = ray_steps * args.steps / dt
+
+    # per-kernel device time (HIP events on the launch stream), rank-local
+    it = max(10, min(args.steps, 50))
+    fwd_ms = time_events(hp.fwd, it)
+    bwd_ms = time_events(hp.bwd, it)
+    local_rs = args.poses * args.rays * args.samples
+    b = BYTES[args.sampler]
+    bwd_bytes = b["bwd_pose_only"] if args.no_gvol else b["bwd"]
+    dom = "bwd" if bwd_ms[0] >= fwd_ms[0] else "fwd"
+    dom_ms = bwd_ms[0] if dom == "bwd" else fwd_ms[0]
+    dom_bytes = (bwd_bytes if dom == "bwd" else b["fwd"]) * local_rs
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+
+    # single-pose latency (BASELINE config 2): 1 pose, fwd + bwd
+    hp1 = HotPath(vol, src[:1].contiguous(), dirs[:1].contiguous(), args.samples, args.alpha, args.sampler,
+                  want_gvol=not args.no_gvol)
+    for _ in range(5):
+        hp1.step()
+    sp = time_events(hp1.step, 20)
+
+    if rank == 0:
+        out = {
+            "metric": "ray-steps/sec fwd+bwd",
+            "value": value,
+            "unit": "ray-steps/s",
+            "n_gpus": ngpu,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"BASELINE config {'3' if ngpu == 1 else '4-style'}: {args.poses} poses/GPU x {args.rays} rays x "
+                             f"{args.samples} steps through a {args.n}^3 analytic head phantom; {args.sampler} sampling; "
+                             f"forward + backward ({'d/dsource, d/ddirections' if args.no_gvol else 'd/dvolume, d/dsource, d/ddirections'}) "
+                             f"+ per-pose loss gather"),
+                "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
+                "volume": [args.n] * 3, "sampler": args.sampler, "start": 0, "alpha": args.alpha,
+                "parallelism": f"poses sharded x{ngpu}, volume replicated",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": f"render_{dom}_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_ray_step": dom_bytes / local_rs,
+                "launch_ms": dom_ms,
+                "fwd_ms": {"mean": fwd_ms[0], "median": fwd_ms[1], "min": fwd_ms[2]},
+                "bwd_ms": {"mean": bwd_ms[0], "median": bwd_ms[1], "min": bwd_ms[2]},
+            },
+            "single_pose": {"workload": "BASELINE config 2: 1 pose, fwd+bwd", "ms_per_step": sp[1],
+                            "value": args.rays * args.samples / (sp[1] * 1e-3)},
+        }
+        if ngpu == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is informative; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "ray-steps/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

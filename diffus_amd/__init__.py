@@ -1,0 +1,12 @@
+"""diffus_amd -- MI355X-native implementation of the DiffUS `plot_beam_frame` hot path.
+
+Drop-in for `from src.renderer import *` / `from src.cone import generate_cone_directions`
+of gduguey/DiffUS on that path.
+"""
+from ._lib import DiffusError, LIB_PATH  # noqa: F401
+from .cone import fan_directions_torch, generate_cone_directions  # noqa: F401
+from .renderer import (UltrasoundRenderer, compute_echo_traces, render_poses, resolve_start,  # noqa: F401
+                       trace_rays)
+
+__all__ = ["UltrasoundRenderer", "compute_echo_traces", "render_poses", "trace_rays", "resolve_start",
+           "generate_cone_directions", "fan_directions_torch", "DiffusError"]

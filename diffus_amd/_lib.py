@@ -1,0 +1,61 @@
+"""ctypes binding of libdiffus_hip.so (include/diffus_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails the product
+path raises.  (The CPU restatement lives in oracle/ and is test-only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffus_hip.so")
+
+EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
+           "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces")
+
+DIFFUS_F32, DIFFUS_F64 = 0, 1
+NEAREST, TRILINEAR = 0, 1
+MAX_SAMPLES = 1024
+
+_lib = None
+
+
+class DiffusError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DiffusError(
+            f"{LIB_PATH} not found: build it with `python -m diffus_amd.build` "
+            "(hipcc --offload-arch=gfx950).  diffus_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.diffus_abi_version.restype = i
+    lib.diffus_strerror.restype = C.c_char_p
+    lib.diffus_strerror.argtypes = [i]
+    lib.diffus_workspace_bytes.restype = sz
+    lib.diffus_workspace_bytes.argtypes = [i, i, i, i]
+    common = [vp, i, i, i, vp, i, vp, i, i, i, i, i, f, i]
+    lib.diffus_render_fwd.restype = i
+    lib.diffus_render_fwd.argtypes = common + [vp, vp, vp, sz, vp]
+    lib.diffus_render_bwd.restype = i
+    lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, vp, sz, vp]
+    lib.diffus_trace_rays.restype = i
+    lib.diffus_trace_rays.argtypes = [vp, i, i, i, vp, i, vp, i, i, i, i, i, vp, vp, vp, vp]
+    lib.diffus_echo_traces.restype = i
+    lib.diffus_echo_traces.argtypes = [vp, i, i, vp, vp]
+    if lib.diffus_abi_version() != 1:
+        raise DiffusError("libdiffus_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise DiffusError(f"{what} failed: {load().diffus_strerror(rc).decode()} ({rc})")

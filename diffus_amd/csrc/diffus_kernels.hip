@@ -1,0 +1,1085 @@
+// diffus_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for the DiffUS
+// plot_beam_frame hot path.  See include/diffus_hip.h for the boundary and
+// DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Execution model (CDNA4-first, not a port of the reference's ATen call chain):
+//   * one 64-lane wavefront marches one ray; lane l owns C = ceil(N1/64)
+//     CONSECUTIVE samples n = l*C .. l*C+C-1 of the cropped ray (N1 = S-start);
+//   * the reference's N+1 dense solves (src/renderer.py:367-457) collapse to a
+//     running product of 2x2 transfer matrices: each lane
+//     multiplies its C matrices, the wave does a 6-round Hillis-Steele scan of
+//     2x2 products with cross-lane shuffles, each lane then sweeps its chunk from
+//     its exclusive prefix.  No A matrix, no LU, no global scratch;
+//   * backward recomputes the forward in-kernel and runs the adjoint recursion
+//      as a reverse affine scan over the same lanes;
+//   * a pose's rays are kept on one XCD (blockIdx remap) so neighbouring rays,
+//     which touch the same voxels near the apex, share that XCD's L2.
+// This is gather/accumulate work: HBM/L2-bound, no MFMA anywhere.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "diffus_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+// ----------------------------------------------------------------------------
+// 2x2 matrices  [[a b],[c d]]
+struct Mat {
+    float a, b, c, d;
+};
+
+__device__ __forceinline__ Mat mat_identity() { return Mat{1.f, 0.f, 0.f, 1.f}; }
+
+__device__ __forceinline__ Mat mat_mul(const Mat &x, const Mat &y)
+{
+    Mat o;
+    o.a = __builtin_fmaf(x.a, y.a, x.b * y.c);
+    o.b = __builtin_fmaf(x.a, y.b, x.b * y.d);
+    o.c = __builtin_fmaf(x.c, y.a, x.d * y.c);
+    o.d = __builtin_fmaf(x.c, y.b, x.d * y.d);
+    return o;
+}
+
+// x * y^T
+__device__ __forceinline__ Mat mat_mul_bt(const Mat &x, const Mat &y)
+{
+    Mat o;
+    o.a = __builtin_fmaf(x.a, y.a, x.b * y.b);
+    o.b = __builtin_fmaf(x.a, y.c, x.b * y.d);
+    o.c = __builtin_fmaf(x.c, y.a, x.d * y.b);
+    o.d = __builtin_fmaf(x.c, y.c, x.d * y.d);
+    return o;
+}
+
+// x^T * y
+__device__ __forceinline__ Mat mat_mul_at(const Mat &x, const Mat &y)
+{
+    Mat o;
+    o.a = __builtin_fmaf(x.a, y.a, x.c * y.c);
+    o.b = __builtin_fmaf(x.a, y.b, x.c * y.d);
+    o.c = __builtin_fmaf(x.b, y.a, x.d * y.c);
+    o.d = __builtin_fmaf(x.b, y.b, x.d * y.d);
+    return o;
+}
+
+// Transfer matrix of one interface, M(r) = [[1-2r^2, r], [-r, 1]] (SURVEY A.3,
+// from the rows written at reference src/renderer.py:397-405 with :380-382).
+__device__ __forceinline__ Mat mat_of_r(float r) { return Mat{1.f - (2.f * r) * r, r, -r, 1.f}; }
+
+// P * M(r) without forming M
+__device__ __forceinline__ Mat mat_step(const Mat &p, float r)
+{
+    float a = 1.f - (2.f * r) * r;
+    Mat o;
+    o.a = __builtin_fmaf(p.a, a, -(p.b * r));
+    o.b = __builtin_fmaf(p.a, r, p.b);
+    o.c = __builtin_fmaf(p.c, a, -(p.d * r));
+    o.d = __builtin_fmaf(p.c, r, p.d);
+    return o;
+}
+
+__device__ __forceinline__ Mat mat_scale(const Mat &m, int e)
+{
+    return Mat{ldexpf(m.a, e), ldexpf(m.b, e), ldexpf(m.c, e), ldexpf(m.d, e)};
+}
+
+// Rescale by an exact power of two so that max|entry| is in [0.5,1).  Returns ex
+// with  m_out = m_in * 2^-ex  (0 when m is all zero / non finite).
+__device__ __forceinline__ int mat_renorm(Mat &m)
+{
+    float mx = fmaxf(fmaxf(fabsf(m.a), fabsf(m.b)), fmaxf(fabsf(m.c), fabsf(m.d)));
+    int ex = 0;
+    if (mx > 0.f && mx < __builtin_inff()) {
+        ex = __builtin_amdgcn_frexp_expf(mx);
+        m = mat_scale(m, -ex);
+    }
+    return ex;
+}
+
+__device__ __forceinline__ bool finitef(float x) { return fabsf(x) < __builtin_inff(); }
+__device__ __forceinline__ bool mat_finite(const Mat &m) { return finitef(m.a) && finitef(m.b) && finitef(m.c) && finitef(m.d); }
+
+__device__ __forceinline__ Mat mat_shfl_up(const Mat &m, int off)
+{
+    return Mat{__shfl_up(m.a, off, kWave), __shfl_up(m.b, off, kWave), __shfl_up(m.c, off, kWave),
+               __shfl_up(m.d, off, kWave)};
+}
+__device__ __forceinline__ Mat mat_shfl_down(const Mat &m, int off)
+{
+    return Mat{__shfl_down(m.a, off, kWave), __shfl_down(m.b, off, kWave), __shfl_down(m.c, off, kWave),
+               __shfl_down(m.d, off, kWave)};
+}
+
+// ----------------------------------------------------------------------------
+struct Pose {
+    // source and direction of this wave's ray, kept in both precisions; pmode
+    // says which roundings the reference would perform (diffus_oracle.c orc_point)
+    float sf[3], df[3];
+    double sd[3], dd[3];
+    int pmode; // 0: f32 src, f32 dir; 1: f64 src, f32 dir; 2: f64 dir (src any)
+};
+
+__device__ __forceinline__ void load_pose(Pose &ps, const void *src, int src_f64, const void *dirs, int dir_f64,
+                                          long pose, long ray_lin)
+{
+    for (int c = 0; c < 3; ++c) {
+        if (src_f64) {
+            ps.sd[c] = ((const double *)src)[pose * 3 + c];
+            ps.sf[c] = (float)ps.sd[c];
+        } else {
+            ps.sf[c] = ((const float *)src)[pose * 3 + c];
+            ps.sd[c] = (double)ps.sf[c];
+        }
+        if (dir_f64) {
+            ps.dd[c] = ((const double *)dirs)[ray_lin * 3 + c];
+            ps.df[c] = (float)ps.dd[c];
+        } else {
+            ps.df[c] = ((const float *)dirs)[ray_lin * 3 + c];
+            ps.dd[c] = (double)ps.df[c];
+        }
+    }
+    ps.pmode = dir_f64 ? 2 : (src_f64 ? 1 : 0);
+}
+
+// p_c = source_c + float(k) * dir_c with the reference's rounding sequence
+// (src/renderer.py:119-124, cast to f32 at :751).  No FMA contraction.
+__device__ __forceinline__ float ray_point(const Pose &ps, int c, int k)
+{
+    float stepf = (float)k;
+    if (ps.pmode == 0) {
+        return __fadd_rn(ps.sf[c], __fmul_rn(stepf, ps.df[c]));
+    } else if (ps.pmode == 1) {
+        float t = __fmul_rn(stepf, ps.df[c]);
+        return (float)__dadd_rn(ps.sd[c], (double)t);
+    } else {
+        return (float)__dadd_rn(ps.sd[c], __dmul_rn((double)stepf, ps.dd[c]));
+    }
+}
+
+// round-half-even -> clamp (src/renderer.py:754-756); NaN / beyond-int64 -> 0
+// like x86's float->int64 conversion followed by the clamp.
+__device__ __forceinline__ int nearest_index(float p, int dim)
+{
+    float r = rintf(p);
+    if (!(r > -9.2233720368547758e18f && r < 9.2233720368547758e18f)) return 0;
+    float hi = (float)(dim - 1);
+    r = fminf(fmaxf(r, 0.f), hi);
+    return (int)r;
+}
+
+struct Axis {
+    int i0, i1;
+    float t, m;
+};
+__device__ __forceinline__ Axis tri_axis(float p, int dim)
+{
+    Axis a;
+    float hi = (float)(dim - 1);
+    a.m = (p > 0.f && p < hi) ? 1.f : 0.f;
+    float pc = p;
+    if (!(pc > 0.f)) pc = 0.f;
+    if (pc > hi) pc = hi;
+    float f = floorf(pc);
+    a.i0 = (int)f;
+    a.t = pc - f;
+    a.i1 = min(a.i0 + 1, dim - 1);
+    return a;
+}
+
+struct __attribute__((packed, aligned(4))) F2 {
+    float x, y;
+};
+
+// the two dim-2 neighbours of one (i,j) row in ONE 8-byte load (they share a
+// cache line 31 times out of 32): halves the vector-memory instructions and
+// L1 tag lookups of the 8-corner gather.
+__device__ __forceinline__ void load_zpair(const float *__restrict__ row, const Axis &c, int d2, float &lo, float &hi)
+{
+    if (d2 >= 2) {
+        int b = min(c.i0, d2 - 2);
+        F2 v = *reinterpret_cast<const F2 *>(row + b);
+        lo = (c.i0 == b) ? v.x : v.y;
+        hi = v.y;
+    } else {
+        lo = hi = row[0];
+    }
+}
+
+struct TriSample {
+    float v;          // interpolated impedance
+    float g0, g1, g2; // d v / d p (border rule applied)
+};
+
+// Trilinear sample at p; lerp order dim 2, dim 1, dim 0, each a + t*(b-a) --
+// the exact sequence of oracle/diffus_oracle.c orc_sample_trilinear.
+template <bool GRAD>
+__device__ __forceinline__ TriSample tri_sample(const float *__restrict__ vol, int d0, int d1, int d2, float p0,
+                                                float p1, float p2)
+{
+    Axis a = tri_axis(p0, d0), b = tri_axis(p1, d1), c = tri_axis(p2, d2);
+    const long s0 = (long)d1 * d2;
+    const float *r00 = vol + a.i0 * s0 + (long)b.i0 * d2;
+    const float *r01 = vol + a.i0 * s0 + (long)b.i1 * d2;
+    const float *r10 = vol + a.i1 * s0 + (long)b.i0 * d2;
+    const float *r11 = vol + a.i1 * s0 + (long)b.i1 * d2;
+    float v000, v001, v010, v011, v100, v101, v110, v111;
+    load_zpair(r00, c, d2, v000, v001);
+    load_zpair(r01, c, d2, v010, v011);
+    load_zpair(r10, c, d2, v100, v101);
+    load_zpair(r11, c, d2, v110, v111);
+    float e00 = v001 - v000, e01 = v011 - v010, e10 = v101 - v100, e11 = v111 - v110;
+    float c00 = __fadd_rn(v000, __fmul_rn(c.t, e00)), c01 = __fadd_rn(v010, __fmul_rn(c.t, e01));
+    float c10 = __fadd_rn(v100, __fmul_rn(c.t, e10)), c11 = __fadd_rn(v110, __fmul_rn(c.t, e11));
+    float f0 = c01 - c00, f1 = c11 - c10;
+    float q0 = __fadd_rn(c00, __fmul_rn(b.t, f0)), q1 = __fadd_rn(c10, __fmul_rn(b.t, f1));
+    float g = q1 - q0;
+    TriSample s;
+    s.v = __fadd_rn(q0, __fmul_rn(a.t, g));
+    if (GRAD) {
+        float h0 = __fadd_rn(e00, __fmul_rn(b.t, e01 - e00));
+        float h1 = __fadd_rn(e10, __fmul_rn(b.t, e11 - e10));
+        s.g0 = g * a.m;
+        s.g1 = __fadd_rn(f0, __fmul_rn(a.t, f1 - f0)) * b.m;
+        s.g2 = __fadd_rn(h0, __fmul_rn(a.t, h1 - h0)) * c.m;
+    } else {
+        s.g0 = s.g1 = s.g2 = 0.f;
+    }
+    return s;
+}
+
+// scatter zb * (trilinear weights) into gvol
+__device__ __forceinline__ void tri_scatter(float *__restrict__ gvol, int d0, int d1, int d2, float p0, float p1,
+                                            float p2, float zb)
+{
+    Axis a = tri_axis(p0, d0), b = tri_axis(p1, d1), c = tri_axis(p2, d2);
+    const long s0 = (long)d1 * d2;
+    float wa1 = a.t, wa0 = 1.f - a.t, wb1 = b.t, wb0 = 1.f - b.t, wc1 = c.t, wc0 = 1.f - c.t;
+    float *r00 = gvol + a.i0 * s0 + (long)b.i0 * d2;
+    float *r01 = gvol + a.i0 * s0 + (long)b.i1 * d2;
+    float *r10 = gvol + a.i1 * s0 + (long)b.i0 * d2;
+    float *r11 = gvol + a.i1 * s0 + (long)b.i1 * d2;
+    float w00 = zb * wa0 * wb0, w01 = zb * wa0 * wb1, w10 = zb * wa1 * wb0, w11 = zb * wa1 * wb1;
+    atomicAdd(r00 + c.i0, w00 * wc0);
+    atomicAdd(r00 + c.i1, w00 * wc1);
+    atomicAdd(r01 + c.i0, w01 * wc0);
+    atomicAdd(r01 + c.i1, w01 * wc1);
+    atomicAdd(r10 + c.i0, w10 * wc0);
+    atomicAdd(r10 + c.i1, w10 * wc1);
+    atomicAdd(r11 + c.i0, w11 * wc0);
+    atomicAdd(r11 + c.i1, w11 * wc1);
+}
+
+// reflection coefficient (reference src/renderer.py:33): IEEE f32 sub, add, div
+__device__ __forceinline__ float reflect(float z1, float z2) { return __fdiv_rn(z2 - z1, z1 + z2); }
+
+// ----------------------------------------------------------------------------
+struct Args {
+    const float *vol;
+    int d0, d1, d2;
+    const void *src;
+    const void *dirs;
+    int src_f64, dir_f64;
+    int P, R, S, start, N1;
+    float neg_alpha;
+    // forward
+    float *frame;
+    long long *idx;
+    // backward
+    const float *gframe;
+    float *gvol;
+    float *gsrc_part; // (P,R,3) per-ray partials of d/d source
+    float *gdirs;
+    // start>0 coupling
+    float *med;  // (P) median of r[:,start] over rays
+    int *who;    // (P) ray that supplied it
+    float *gmed; // (P) accumulated d/d median
+};
+
+// Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b%8).  Remap so
+// that consecutive LOGICAL blocks (= consecutive rays of one pose) sit on one
+// XCD and share its L2.  Bijective for any grid size (guide T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
+{
+    unsigned xcd = b & 7u, q = nblk >> 3, rem = nblk & 7u;
+    unsigned base = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    return base + (b >> 3);
+}
+
+// Samples of this lane's chunk: impedance (and, for the trilinear backward, the
+// spatial gradient).  n >= N1 yields a harmless dummy.
+template <int C, int SAMPLER, bool GRAD>
+__device__ __forceinline__ void gather_chunk(const Args &A, const Pose &ps, int n0, float (&z)[C], float (&g0)[C],
+                                             float (&g1)[C], float (&g2)[C])
+{
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        z[j] = 1.f;
+        if (GRAD) g0[j] = g1[j] = g2[j] = 0.f;
+        if (n < A.N1) {
+            int k = A.start + n;
+            float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+            if (SAMPLER == DIFFUS_NEAREST) {
+                int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
+                z[j] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+            } else {
+                TriSample s = tri_sample<GRAD>(A.vol, A.d0, A.d1, A.d2, p0, p1, p2);
+                z[j] = s.v;
+                if (GRAD) {
+                    g0[j] = s.g0;
+                    g1[j] = s.g1;
+                    g2[j] = s.g2;
+                }
+            }
+        }
+    }
+}
+
+// r'_{n-1} for the lane's samples: r[j] couples sample n-1 and n (n = n0+j).
+// r = 0 (identity transfer matrix) for n = 0 and n >= N1; with start > 0 the
+// first kept coefficient is replaced by the per-pose median (reference :243-244).
+template <int C>
+__device__ __forceinline__ void reflect_chunk(const Args &A, int n0, const float (&z)[C], float zprev, float medv,
+                                              float (&r)[C])
+{
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
+        float v = reflect(zp, z[j]);
+        if (n == 1 && A.start > 0) v = medv;
+        r[j] = (n >= 1 && n < A.N1) ? v : 0.f;
+    }
+}
+
+// Echo series of one ray spread over a wave (replaces the N+1
+// dense solves of reference src/renderer.py:367-457).  r[j] is the reflection
+// coefficient entering sample n = lane*C + j (0 where there is none); e[j] gets
+// echo_n = (P_n)01/(P_n)11 with NaN -> 0 (reference :408).
+template <int C>
+__device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float (&e)[C])
+{
+    // local product of the chunk, then inclusive scan over lanes (lower lanes on the left)
+    Mat L = mat_identity();
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        L = mat_step(L, r[j]);
+        mat_renorm(L);
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Mat o = mat_shfl_up(L, off);
+        if (lane >= off) {
+            L = mat_mul(o, L);
+            mat_renorm(L);
+        }
+    }
+    Mat Pm = mat_shfl_up(L, 1);
+    if (lane == 0) Pm = mat_identity();
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        Pm = mat_step(Pm, r[j]);
+        mat_renorm(Pm);
+        float v = __fdiv_rn(Pm.b, Pm.d);
+        e[j] = (v == v) ? v : 0.f; // nan_to_num(nan=0)
+    }
+}
+
+// ----------------------------------------------------------------------------
+// FORWARD  (replaces reference src/renderer.py:201-275 with artifacts=False)
+template <int C, int SAMPLER>
+__global__ __launch_bounds__(kBlock) void render_fwd_kernel(Args A)
+{
+    const unsigned nblk = gridDim.x;
+    const long w = (long)xcd_remap(blockIdx.x, nblk) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w >= (long)A.P * A.R) return; // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const long pose = w / A.R;
+    const int n0 = lane * C;
+
+    Pose ps;
+    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+
+    float z[C], r[C], u0[C], u1[C], u2[C];
+    gather_chunk<C, SAMPLER, false>(A, ps, n0, z, u0, u1, u2);
+    float zprev = __shfl_up(z[C - 1], 1, kWave);
+    float medv = (A.start > 0) ? A.med[pose] : 0.f;
+    reflect_chunk<C>(A, n0, z, zprev, medv, r);
+
+    float e[C];
+    echo_chunk<C>(r, lane, e);
+    float *out = A.frame + w * A.N1;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        // attenuation, reference :256-259: f32(-alpha) * f32(n), expf, multiply
+        float att = expf(__fmul_rn(A.neg_alpha, (float)n));
+        if (n < A.N1) out[n] = __fmul_rn(e[j], att);
+    }
+
+    if (A.idx) {
+        const long plane = (long)A.P * A.R * A.N1;
+        long long *ix = A.idx + w * A.N1;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = n0 + j;
+            if (n < A.N1) {
+                int k = A.start + n;
+                ix[n] = nearest_index(ray_point(ps, 0, k), A.d0);
+                ix[plane + n] = nearest_index(ray_point(ps, 1, k), A.d1);
+                ix[2 * plane + n] = nearest_index(ray_point(ps, 2, k), A.d2);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// BACKWARD.  Notation (indices in cropped coordinates):
+//   T_n = M(r'_{n-1}),  P_n = P_{n-1} T_n,  echo_n = b_n/d_n,  (b_n,d_n) = 2nd column of P_n
+//   gbar_n = gframe_n * att_n;  Gbar_n = (gbar_n/d_n) [[0,1],[0,-echo_n]]
+//   U_{n-1} = (Gbar_n + U_n) T_n^T, U_N = 0;   Tbar_n = P_{n-1}^T (Gbar_n + U_n)
+//   rbar = -4 r Tbar_00 + Tbar_01 - Tbar_10
+// All P are carried rescaled by exact powers of two (P'_n = 2^{e_n} P_n); with
+// W_n = 2^{e_n-e_{n-1}} (Gbar'_n + U'_n):  Tbar_n = P'_{n-1}^T W_n,  U'_{n-1} = W_n T_n^T.
+// The chunk of one lane is an affine map U_in -> U_out; lanes are combined with a
+// reverse Hillis-Steele scan of affine maps (A, B, beta):  X -> A + X (B 2^beta)^T.
+template <int C, int SAMPLER, bool GPOSE>
+__global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
+{
+    const unsigned nblk = gridDim.x;
+    const long w = (long)xcd_remap(blockIdx.x, nblk) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w >= (long)A.P * A.R) return;
+    const int lane = threadIdx.x & 63;
+    const long pose = w / A.R;
+    const int n0 = lane * C;
+
+    Pose ps;
+    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+
+    float z[C], r[C], gp0[C], gp1[C], gp2[C];
+    gather_chunk<C, SAMPLER, GPOSE>(A, ps, n0, z, gp0, gp1, gp2);
+    const float zprev = __shfl_up(z[C - 1], 1, kWave);
+    const float medv = (A.start > 0) ? A.med[pose] : 0.f;
+    reflect_chunk<C>(A, n0, z, zprev, medv, r);
+
+    // ---- forward recompute with exponent tracking ----
+    Mat L = mat_identity();
+    int lam = 0; // L' = L * 2^lam
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        L = mat_step(L, r[j]);
+        lam -= mat_renorm(L);
+    }
+    const Mat Lloc = L;   // normalised local product T_first..T_last
+    const int lamloc = lam;
+    int iota = lam;       // inclusive prefix exponent
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Mat o = mat_shfl_up(L, off);
+        int oe = __shfl_up(iota, off, kWave);
+        if (lane >= off) {
+            L = mat_mul(o, L);
+            iota = oe + iota - mat_renorm(L);
+        }
+    }
+    Mat Pm = mat_shfl_up(L, 1);
+    int eps = __shfl_up(iota, 1, kWave); // exponent of the exclusive prefix
+    if (lane == 0) {
+        Pm = mat_identity();
+        eps = 0;
+    }
+
+    Mat Pin[C];  // P'_{n-1} as used by this lane
+    int ex[C];   // renorm exponent of step n
+    float gu[C]; // gbar_n / d'_n
+    float rho[C];
+    const float *gin = A.gframe + w * A.N1;
+    int esum = 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        Pin[j] = Pm;
+        Pm = mat_step(Pm, r[j]);
+        ex[j] = mat_renorm(Pm);
+        esum += ex[j];
+        float e = __fdiv_rn(Pm.b, Pm.d);
+        float gb = 0.f;
+        if (n < A.N1 && e == e) gb = gin[n] * expf(__fmul_rn(A.neg_alpha, (float)n));
+        float q = __fdiv_rn(gb, Pm.d);
+        gu[j] = (gb != 0.f) ? q : 0.f;
+        rho[j] = (e == e) ? e : 0.f;
+    }
+    // sanitise: past a NaN reflection coefficient every echo is a constant 0, so
+    // nothing flows back through those steps.
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        if (!finitef(r[j]) || !mat_finite(Pin[j]) || !finitef(gu[j]) || !finitef(rho[j])) gu[j] = 0.f;
+    }
+
+    // exponent of this lane's last P' and the hop to the next lane's exclusive prefix
+    const int elast = eps - esum;
+    int eps_next = __shfl_down(eps, 1, kWave);
+    const int delta = (lane == kWave - 1) ? 0 : (eps_next - elast);
+
+    // ---- lane-local affine map: A-part = sweep from U = 0 ----
+    auto sweep = [&](Mat U, float *rbar) {
+#pragma unroll
+        for (int j = C - 1; j >= 0; --j) {
+            Mat W;
+            W.a = U.a;
+            W.b = U.b + gu[j];
+            W.c = U.c;
+            W.d = U.d - gu[j] * rho[j];
+            W = mat_scale(W, -ex[j]);
+            if (rbar) {
+                Mat Tb = mat_mul_at(Pin[j], W);
+                float v = __builtin_fmaf(-4.f * r[j], Tb.a, Tb.b - Tb.c);
+                rbar[j] = v;
+            }
+            float rr = finitef(r[j]) ? r[j] : 0.f; // non-finite step: cut the chain (U is zero there anyway)
+            U = mat_mul_bt(W, mat_of_r(rr));
+        }
+        return U;
+    };
+    Mat Aacc = sweep(Mat{0.f, 0.f, 0.f, 0.f}, nullptr);
+    Mat Bn = Lloc;                       // normalised linear part
+    int beta = delta - esum - lamloc;    // B = Bn * 2^beta
+    // NaN-proof the linear part (a NaN chunk passes nothing)
+    if (!mat_finite(Bn)) Bn = Mat{0.f, 0.f, 0.f, 0.f};
+
+    // ---- reverse inclusive scan of affine maps: G_l = F_l o F_{l+1} o ... o F_63 ----
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Mat oA = mat_shfl_down(Aacc, off);
+        Mat oB = mat_shfl_down(Bn, off);
+        int ob = __shfl_down(beta, off, kWave);
+        if (lane + off < kWave) {
+            Mat t = mat_scale(mat_mul_bt(oA, Bn), beta);
+            Aacc.a += t.a; Aacc.b += t.b; Aacc.c += t.c; Aacc.d += t.d;
+            Bn = mat_mul(Bn, oB);
+            beta = beta + ob + mat_renorm(Bn); // B = Bn * 2^beta: a rescale of Bn by 2^-ex adds ex
+        }
+    }
+    Mat Uin = mat_shfl_down(Aacc, 1);
+    if (lane == kWave - 1) Uin = Mat{0.f, 0.f, 0.f, 0.f};
+    Uin = mat_scale(Uin, delta);
+
+    float rbar[C];
+    sweep(Uin, rbar);
+
+    // ---- rbar -> zbar (d r / d Z of reference :33) ----
+    float zbar[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) zbar[j] = 0.f;
+    float carry = 0.f, gmed_lane = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        bool live = (n >= 1 && n < A.N1);
+        float rb = live ? rbar[j] : 0.f;
+        if (!finitef(rb)) rb = 0.f; // drop non-finite
+        if (n == 1 && A.start > 0) {
+            gmed_lane = rb;
+            rb = 0.f;
+        }
+        float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
+        float s = zp + z[j];
+        float inv = __fdiv_rn(1.f, s);
+        float dz = 2.f * zp * inv * inv;    // d r / d Z_n
+        float dzp = -2.f * z[j] * inv * inv; // d r / d Z_{n-1}
+        float c1 = rb * dz, c0 = rb * dzp;
+        if (!finitef(c1)) c1 = 0.f;
+        if (!finitef(c0)) c0 = 0.f;
+        zbar[j] += c1;
+        if (j == 0)
+            carry = c0;
+        else
+            zbar[j == 0 ? 0 : j - 1] += c0;
+    }
+    float cin = __shfl_down(carry, 1, kWave);
+    if (lane != kWave - 1) zbar[C - 1] += cin;
+    if (gmed_lane != 0.f) atomicAdd(&A.gmed[pose], gmed_lane);
+
+    // ---- scatter to the volume, reduce the pose gradient ----
+    float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        float zb = zbar[j];
+        if (n < A.N1 && zb != 0.f) {
+            int k = A.start + n;
+            if (A.gvol) {
+                float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+                if (SAMPLER == DIFFUS_NEAREST) {
+                    int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
+                    atomicAdd(A.gvol + ((long)i0 * A.d1 + i1) * A.d2 + i2, zb);
+                } else {
+                    tri_scatter(A.gvol, A.d0, A.d1, A.d2, p0, p1, p2, zb);
+                }
+            }
+            if (GPOSE) {
+                float kf = (float)k;
+                float a0 = zb * gp0[j], a1 = zb * gp1[j], a2 = zb * gp2[j];
+                gs0 += a0; gs1 += a1; gs2 += a2;
+                gd0 = __builtin_fmaf(kf, a0, gd0);
+                gd1 = __builtin_fmaf(kf, a1, gd1);
+                gd2 = __builtin_fmaf(kf, a2, gd2);
+            }
+        }
+    }
+    if (GPOSE) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            gs0 += __shfl_xor(gs0, off, kWave);
+            gs1 += __shfl_xor(gs1, off, kWave);
+            gs2 += __shfl_xor(gs2, off, kWave);
+            gd0 += __shfl_xor(gd0, off, kWave);
+            gd1 += __shfl_xor(gd1, off, kWave);
+            gd2 += __shfl_xor(gd2, off, kWave);
+        }
+        if (lane == 0) {
+            if (A.gsrc_part) {
+                A.gsrc_part[w * 3 + 0] = gs0;
+                A.gsrc_part[w * 3 + 1] = gs1;
+                A.gsrc_part[w * 3 + 2] = gs2;
+            }
+            if (A.gdirs) {
+                A.gdirs[w * 3 + 0] = gd0;
+                A.gdirs[w * 3 + 1] = gd1;
+                A.gdirs[w * 3 + 2] = gd2;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// start > 0: median over rays of r[:, start] (reference :243), one block per pose.
+// Lower median like torch.median; NaN if any NaN.  Also zeroes gmed[p].
+template <int SAMPLER>
+__global__ __launch_bounds__(kBlock) void median_kernel(Args A)
+{
+    extern __shared__ float vals[];
+    __shared__ int s_nan;
+    const int pose = blockIdx.x;
+    if (threadIdx.x == 0) s_nan = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
+        Pose ps;
+        load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, (long)pose * A.R + i);
+        float zz[2];
+        for (int q = 0; q < 2; ++q) {
+            int k = A.start + q;
+            float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+            if (SAMPLER == DIFFUS_NEAREST) {
+                int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
+                zz[q] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+            } else {
+                zz[q] = tri_sample<false>(A.vol, A.d0, A.d1, A.d2, p0, p1, p2).v;
+            }
+        }
+        float v = reflect(zz[0], zz[1]);
+        vals[i] = v;
+        if (v != v) atomicOr(&s_nan, 1);
+    }
+    __syncthreads();
+    if (s_nan) {
+        if (threadIdx.x == 0) {
+            A.med[pose] = __builtin_nanf("");
+            A.who[pose] = -1;
+            A.gmed[pose] = 0.f;
+        }
+        return;
+    }
+    const int target = (A.R - 1) / 2;
+    for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
+        float v = vals[i];
+        int rank = 0;
+        for (int j = 0; j < A.R; ++j) {
+            float u = vals[j];
+            rank += (u < v) || (u == v && j < i);
+        }
+        if (rank == target) { // exactly one i satisfies this
+            A.med[pose] = v;
+            A.who[pose] = i;
+            A.gmed[pose] = 0.f;
+        }
+    }
+}
+
+// start > 0, backward: route gmed[p] to the ray that supplied the median
+// (torch.median's backward).  One thread per pose; runs after render_bwd_kernel.
+template <int SAMPLER>
+__global__ void median_bwd_kernel(Args A)
+{
+    const int pose = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pose >= A.P) return;
+    const int i = A.who[pose];
+    const float gm = A.gmed[pose];
+    if (i < 0 || gm == 0.f || !(fabsf(gm) < __builtin_inff())) return;
+    const long w = (long)pose * A.R + i;
+    Pose ps;
+    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    float zz[2], g0[2], g1[2], g2[2], pp[2][3];
+    for (int q = 0; q < 2; ++q) {
+        int k = A.start + q;
+        for (int c = 0; c < 3; ++c) pp[q][c] = ray_point(ps, c, k);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            int i0 = nearest_index(pp[q][0], A.d0), i1 = nearest_index(pp[q][1], A.d1),
+                i2 = nearest_index(pp[q][2], A.d2);
+            zz[q] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+            g0[q] = g1[q] = g2[q] = 0.f;
+        } else {
+            TriSample s = tri_sample<true>(A.vol, A.d0, A.d1, A.d2, pp[q][0], pp[q][1], pp[q][2]);
+            zz[q] = s.v; g0[q] = s.g0; g1[q] = s.g1; g2[q] = s.g2;
+        }
+    }
+    float s = zz[0] + zz[1];
+    float inv = __fdiv_rn(1.f, s);
+    float zb[2] = {gm * (-2.f * zz[1] * inv * inv), gm * (2.f * zz[0] * inv * inv)};
+    for (int q = 0; q < 2; ++q) {
+        if (!(fabsf(zb[q]) < __builtin_inff()) || zb[q] == 0.f) continue;
+        int k = A.start + q;
+        if (A.gvol) {
+            if (SAMPLER == DIFFUS_NEAREST) {
+                int i0 = nearest_index(pp[q][0], A.d0), i1 = nearest_index(pp[q][1], A.d1),
+                    i2 = nearest_index(pp[q][2], A.d2);
+                atomicAdd(A.gvol + ((long)i0 * A.d1 + i1) * A.d2 + i2, zb[q]);
+            } else {
+                tri_scatter(A.gvol, A.d0, A.d1, A.d2, pp[q][0], pp[q][1], pp[q][2], zb[q]);
+            }
+        }
+        if (SAMPLER == DIFFUS_TRILINEAR) {
+            float kf = (float)k;
+            if (A.gsrc_part) {
+                A.gsrc_part[w * 3 + 0] += zb[q] * g0[q];
+                A.gsrc_part[w * 3 + 1] += zb[q] * g1[q];
+                A.gsrc_part[w * 3 + 2] += zb[q] * g2[q];
+            }
+            if (A.gdirs) {
+                A.gdirs[w * 3 + 0] += kf * zb[q] * g0[q];
+                A.gdirs[w * 3 + 1] += kf * zb[q] * g1[q];
+                A.gdirs[w * 3 + 2] += kf * zb[q] * g2[q];
+            }
+        }
+    }
+}
+
+// gsrc[p,:] = sum over rays of gsrc_part[p,:,:], fixed order => deterministic.
+__global__ __launch_bounds__(kBlock) void reduce_gsrc_kernel(const float *__restrict__ part, float *__restrict__ gsrc,
+                                                             int R)
+{
+    __shared__ float sm[3][kBlock];
+    const int pose = blockIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < R; i += kBlock) {
+        const float *q = part + ((long)pose * R + i) * 3;
+        a0 += q[0]; a1 += q[1]; a2 += q[2];
+    }
+    sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+            sm[2][threadIdx.x] += sm[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) gsrc[pose * 3 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+// ----------------------------------------------------------------------------
+// Standalone stages (rows a3-a6 and a7-a9 of SURVEY §8a), exposed so that each
+// can be checked against the reference's golden vectors in isolation.
+
+// trace_ray + custom_nearest_sampler + compute_reflection_coeff
+// (reference src/renderer.py:90-180, :741-759, :27-33, :65-68): one thread per sample.
+template <int SAMPLER>
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(Args A, float *__restrict__ imp, float *__restrict__ refl,
+                                                            long long *__restrict__ idx)
+{
+    const long total = (long)A.P * A.R * A.S;
+    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long)gridDim.x * kBlock) {
+        const long w = t / A.S;
+        const int k = (int)(t - w * A.S);
+        Pose ps;
+        load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, w / A.R, w);
+        float zz[2];
+        const int nq = (refl && k + 1 < A.S) ? 2 : 1;
+        for (int q = 0; q < nq; ++q) {
+            float p0 = ray_point(ps, 0, k + q), p1 = ray_point(ps, 1, k + q), p2 = ray_point(ps, 2, k + q);
+            int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
+            if (q == 0 && idx) {
+                idx[t] = i0;
+                idx[total + t] = i1;
+                idx[2 * total + t] = i2;
+            }
+            if (SAMPLER == DIFFUS_NEAREST)
+                zz[q] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+            else
+                zz[q] = tri_sample<false>(A.vol, A.d0, A.d1, A.d2, p0, p1, p2).v;
+        }
+        if (imp) imp[t] = zz[0];
+        if (refl && k + 1 < A.S) refl[w * (A.S - 1) + k] = reflect(zz[0], zz[1]);
+    }
+}
+
+// compute_echo_traces (reference src/renderer.py:439-457): r (B,N) -> echo (B,N+1),
+// one wave per row.
+template <int C>
+__global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__restrict__ rin, float *__restrict__ echo,
+                                                             int B, int N)
+{
+    const long w = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int n0 = lane * C;
+    float r[C], e[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        r[j] = (n >= 1 && n <= N) ? rin[w * N + n - 1] : 0.f;
+    }
+    echo_chunk<C>(r, lane, e);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        if (n <= N) echo[w * (N + 1) + n] = e[j];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// host side
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+    float *med;
+    int *who;
+    float *gmed;
+    float *gsrc_part;
+    size_t bytes;
+};
+
+Workspace carve(void *base, int P, int R)
+{
+    Workspace ws;
+    char *p = (char *)base;
+    size_t o = 0;
+    ws.med = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
+    ws.who = (int *)(p + o);   o += align256(sizeof(int) * (size_t)P);
+    ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
+    ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
+    ws.bytes = o;
+    return ws;
+}
+
+int chunk_for(int N1)
+{
+    int c = (N1 + kWave - 1) / kWave;
+    if (c <= 2) return 2;
+    if (c <= 4) return 4;
+    if (c <= 8) return 8;
+    return 16;
+}
+
+int check_common(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+                 int dirs_dtype, int P, int R, int S, int start, int sampler)
+{
+    if (!vol || !src || !dirs) return DIFFUS_EINVAL;
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0 || P <= 0 || R <= 0 || S <= 0) return DIFFUS_EINVAL;
+    if ((src_dtype != DIFFUS_F32 && src_dtype != DIFFUS_F64) || (dirs_dtype != DIFFUS_F32 && dirs_dtype != DIFFUS_F64))
+        return DIFFUS_EINVAL;
+    if (sampler != DIFFUS_NEAREST && sampler != DIFFUS_TRILINEAR) return DIFFUS_EINVAL;
+    if (start < 0 || start > S - 1) return DIFFUS_EINVAL;
+    if (start > 0 && start > S - 2) return DIFFUS_EINVAL; // reference raises IndexError at :243
+    if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24)) return DIFFUS_EUNSUPPORTED; // float(dim-1) must be exact
+    if (S - start > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
+    if (start > 0 && (size_t)R * sizeof(float) > 64 * 1024) return DIFFUS_EUNSUPPORTED; // median LDS
+    return DIFFUS_OK;
+}
+
+Args make_args(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+               int dirs_dtype, int P, int R, int S, int start, float alpha, const Workspace &ws)
+{
+    Args A{};
+    A.vol = vol; A.d0 = d0; A.d1 = d1; A.d2 = d2;
+    A.src = src; A.dirs = dirs;
+    A.src_f64 = src_dtype == DIFFUS_F64; A.dir_f64 = dirs_dtype == DIFFUS_F64;
+    A.P = P; A.R = R; A.S = S; A.start = start; A.N1 = S - start;
+    A.neg_alpha = -alpha;
+    A.med = ws.med; A.who = ws.who; A.gmed = ws.gmed;
+    return A;
+}
+
+template <int SAMPLER>
+int launch_median(const Args &A, hipStream_t st)
+{
+    hipLaunchKernelGGL(median_kernel<SAMPLER>, dim3(A.P), dim3(kBlock), sizeof(float) * (size_t)A.R, st, A);
+    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+}
+
+template <int SAMPLER>
+int launch_fwd(const Args &A, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(A.N1)) {
+    case 2: hipLaunchKernelGGL((render_fwd_kernel<2, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 4: hipLaunchKernelGGL((render_fwd_kernel<4, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: hipLaunchKernelGGL((render_fwd_kernel<8, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: hipLaunchKernelGGL((render_fwd_kernel<16, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    }
+    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+}
+
+template <int SAMPLER, bool GPOSE>
+int launch_bwd(const Args &A, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(A.N1)) {
+    case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: hipLaunchKernelGGL((render_bwd_kernel<16, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    }
+    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+}
+
+} // namespace
+
+// ----------------------------------------------------------------------------
+extern "C" {
+
+int diffus_abi_version(void) { return DIFFUS_ABI_VERSION; }
+
+const char *diffus_strerror(int code)
+{
+    switch (code) {
+    case DIFFUS_OK: return "ok";
+    case DIFFUS_EINVAL: return "invalid argument";
+    case DIFFUS_EUNSUPPORTED: return "unsupported shape (S - start > 1024, volume too large, or too many rays for start > 0)";
+    case DIFFUS_ELAUNCH: return "HIP launch failure";
+    case DIFFUS_EWORKSPACE: return "workspace too small (see diffus_workspace_bytes)";
+    default: return "unknown diffus error";
+    }
+}
+
+size_t diffus_workspace_bytes(int P, int R, int S, int start)
+{
+    (void)S; (void)start;
+    if (P <= 0 || R <= 0) return 0;
+    return carve(nullptr, P, R).bytes;
+}
+
+int diffus_render_fwd(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+                      int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler, float *frame,
+                      int64_t *idx, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler);
+    if (rc) return rc;
+    if (!frame) return DIFFUS_EINVAL;
+    Workspace ws = carve(workspace, P, R);
+    if (start > 0 && (!workspace || workspace_bytes < ws.bytes)) return DIFFUS_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
+    A.frame = frame;
+    A.idx = (long long *)idx;
+    if (start > 0) {
+        rc = sampler == DIFFUS_NEAREST ? launch_median<DIFFUS_NEAREST>(A, st) : launch_median<DIFFUS_TRILINEAR>(A, st);
+        if (rc) return rc;
+    }
+    return sampler == DIFFUS_NEAREST ? launch_fwd<DIFFUS_NEAREST>(A, st) : launch_fwd<DIFFUS_TRILINEAR>(A, st);
+}
+
+int diffus_render_bwd(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+                      int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler, const float *gframe,
+                      float *gvol, float *gsrc, float *gdirs, void *workspace, size_t workspace_bytes,
+                      diffus_stream_t stream)
+{
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler);
+    if (rc) return rc;
+    if (!gframe) return DIFFUS_EINVAL;
+    if (!gvol && !gsrc && !gdirs) return DIFFUS_OK;
+    Workspace ws = carve(workspace, P, R);
+    if (!workspace || workspace_bytes < ws.bytes) return DIFFUS_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool pose = sampler == DIFFUS_TRILINEAR && (gsrc || gdirs);
+    if (sampler == DIFFUS_NEAREST) { // integer indices: no pose gradient (reference :754-758)
+        if (gsrc && hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)P * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
+        if (gdirs && hipMemsetAsync(gdirs, 0, sizeof(float) * (size_t)P * R * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
+        if (!gvol) return DIFFUS_OK;
+    }
+    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
+    A.gframe = gframe;
+    A.gvol = gvol;
+    A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
+    A.gdirs = pose ? gdirs : nullptr;
+    if (start > 0) { // recompute the median (and zero gmed)
+        rc = sampler == DIFFUS_NEAREST ? launch_median<DIFFUS_NEAREST>(A, st) : launch_median<DIFFUS_TRILINEAR>(A, st);
+        if (rc) return rc;
+    }
+    if (sampler == DIFFUS_NEAREST)
+        rc = launch_bwd<DIFFUS_NEAREST, false>(A, st);
+    else
+        rc = pose ? launch_bwd<DIFFUS_TRILINEAR, true>(A, st) : launch_bwd<DIFFUS_TRILINEAR, false>(A, st);
+    if (rc) return rc;
+    if (start > 0) {
+        const unsigned nb = (unsigned)((P + 63) / 64);
+        if (sampler == DIFFUS_NEAREST)
+            hipLaunchKernelGGL(median_bwd_kernel<DIFFUS_NEAREST>, dim3(nb), dim3(64), 0, st, A);
+        else
+            hipLaunchKernelGGL(median_bwd_kernel<DIFFUS_TRILINEAR>, dim3(nb), dim3(64), 0, st, A);
+        if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
+    }
+    if (pose && gsrc) {
+        hipLaunchKernelGGL(reduce_gsrc_kernel, dim3(P), dim3(kBlock), 0, st, ws.gsrc_part, gsrc, R);
+        if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
+    }
+    return DIFFUS_OK;
+}
+
+int diffus_trace_rays(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+                      int dirs_dtype, int P, int R, int S, int sampler, float *imp, float *refl, int64_t *idx,
+                      diffus_stream_t stream)
+{
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, sampler);
+    if (rc == DIFFUS_EUNSUPPORTED && S > DIFFUS_MAX_SAMPLES) rc = DIFFUS_OK; // no scan here: any S
+    if (rc) return rc;
+    if (!imp && !refl && !idx) return DIFFUS_OK;
+    Workspace ws = carve(nullptr, P, R);
+    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, 0.f, ws);
+    const long total = (long)P * R * S;
+    unsigned nblk = (unsigned)((total + kBlock - 1) / kBlock);
+    if (nblk > 256u * 16u) nblk = 256u * 16u;
+    hipStream_t st = (hipStream_t)stream;
+    if (sampler == DIFFUS_NEAREST)
+        hipLaunchKernelGGL(trace_rays_kernel<DIFFUS_NEAREST>, dim3(nblk), dim3(kBlock), 0, st, A, imp, refl,
+                           (long long *)idx);
+    else
+        hipLaunchKernelGGL(trace_rays_kernel<DIFFUS_TRILINEAR>, dim3(nblk), dim3(kBlock), 0, st, A, imp, refl,
+                           (long long *)idx);
+    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+}
+
+int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stream_t stream)
+{
+    if (!refl && N > 0) return DIFFUS_EINVAL;
+    if (!echo || B <= 0 || N < 0) return DIFFUS_EINVAL;
+    if (N + 1 > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nblk = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(N + 1)) {
+    case 2: hipLaunchKernelGGL(echo_traces_kernel<2>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    case 4: hipLaunchKernelGGL(echo_traces_kernel<4>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    case 8: hipLaunchKernelGGL(echo_traces_kernel<8>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    default: hipLaunchKernelGGL(echo_traces_kernel<16>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    }
+    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+}
+
+} // extern "C"

@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's renderer API over the HIP C-ABI.
+
+`UltrasoundRenderer` keeps the constructor and the `plot_beam_frame` signature,
+argument meaning, return tuple and error behaviour of the reference
+(src/renderer.py:18-25, :201-275), so `from diffus_amd import *` is a drop-in for
+`from src.renderer import *` on this path.  All arithmetic happens in
+libdiffus_hip.so (diffus_amd/csrc/diffus_kernels.hip); PyTorch only provides
+device memory, the current HIP stream and autograd plumbing.  There is no CPU
+fallback: without the built library every entry point raises DiffusError.
+
+Differences from the reference, all deliberate:
+  * no prints, no matplotlib figure per call (reference :122,179,245,252,:762-801);
+  * `artifacts=True` (NumPy/SciPy speckle chain, :264-273) is out of scope -> NotImplementedError;
+  * extra keyword-only arguments `sampler=` ("nearest" = reference semantics,
+    "trilinear" = differentiable in the pose) and `return_indices=`;
+  * gradients work: d frame / d volume for both samplers, d / d source and
+    d / d directions for trilinear (the reference raises);
+  * a float `start` is honoured as the fraction of num_samples the code intends
+    (:237-238); the reference crashes on it inside its visualisation (:774);
+  * `render_poses` batches P poses in one launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+log = logging.getLogger("diffus_amd")
+
+_SAMPLERS = {"nearest": _lib.NEAREST, "prop": _lib.NEAREST, "trilinear": _lib.TRILINEAR}
+_workspaces: dict = {}
+
+
+def _device_for(t: torch.Tensor) -> torch.device:
+    if t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise _lib.DiffusError("diffus_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _workspaces[dev] = ws
+    return ws
+
+
+def _pose_dtype(t: torch.Tensor) -> torch.dtype:
+    """torch promotion of `source + steps*directions` (reference :119-124):
+    float64 stays float64, everything else computes in float32."""
+    return torch.float64 if t.dtype == torch.float64 else torch.float32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def resolve_start(start, num_samples: int) -> int:
+    """reference src/renderer.py:237-240."""
+    if type(start) is float:
+        start = int(start * num_samples)
+    if type(start) is int:
+        start = max(0, start)
+    return int(start)
+
+
+class _Problem:
+    """Validated, device-resident arguments of one (batched) call."""
+
+    def __init__(self, volume, sources, directions, S, start, alpha, sampler):
+        if volume.dim() != 3:
+            raise ValueError(f"volume must be 3-D, got shape {tuple(volume.shape)}")
+        self.dev = _device_for(volume)
+        self.vol = volume.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+        sd, dd = _pose_dtype(sources), _pose_dtype(directions)
+        self.src = sources.detach().to(device=self.dev, dtype=sd).reshape(-1, 3).contiguous()
+        d = directions.detach().to(device=self.dev, dtype=dd)
+        if d.dim() == 1:
+            d = d.unsqueeze(0)
+        self.P = self.src.shape[0]
+        if d.dim() == 2:
+            d = d.unsqueeze(0).expand(self.P, -1, -1)
+        if d.dim() != 3 or d.shape[0] != self.P or d.shape[-1] != 3:
+            raise ValueError(f"directions must be (R,3) or (P,R,3); got {tuple(directions.shape)} for P={self.P}")
+        self.dirs = d.contiguous()
+        self.R = self.dirs.shape[1]
+        self.S, self.start, self.alpha = int(S), int(start), float(alpha)
+        self.N1 = self.S - self.start
+        self.sampler = _SAMPLERS[sampler]
+        self.src_dt = _lib.DIFFUS_F64 if sd == torch.float64 else _lib.DIFFUS_F32
+        self.dir_dt = _lib.DIFFUS_F64 if dd == torch.float64 else _lib.DIFFUS_F32
+
+    def common(self):
+        d0, d1, d2 = self.vol.shape
+        return (_ptr(self.vol), d0, d1, d2, _ptr(self.src), self.src_dt, _ptr(self.dirs), self.dir_dt,
+                self.P, self.R, self.S, self.start, self.alpha, self.sampler)
+
+    def workspace(self):
+        n = _lib.load().diffus_workspace_bytes(self.P, self.R, self.S, self.start)
+        return _workspace(self.dev, n)
+
+
+class _RenderFn(torch.autograd.Function):
+    """frame = render(volume, sources, directions); backward via diffus_render_bwd."""
+
+    @staticmethod
+    def forward(ctx, volume, sources, directions, S, start, alpha, sampler, want_idx):
+        lib = _lib.load()
+        pb = _Problem(volume, sources, directions, S, start, alpha, sampler)
+        with torch.cuda.device(pb.dev):
+            frame = torch.empty((pb.P, pb.R, pb.N1), dtype=torch.float32, device=pb.dev)
+            idx = torch.empty((3, pb.P, pb.R, pb.N1), dtype=torch.int64, device=pb.dev) if want_idx else None
+            ws = pb.workspace()
+            rc = lib.diffus_render_fwd(*pb.common(), _ptr(frame), _ptr(idx), _ptr(ws), ws.numel(), _stream(pb.dev))
+        _lib.check(rc, "diffus_render_fwd")
+        ctx.pb = pb
+        ctx.meta = (volume.device, volume.dtype, sources.device, sources.dtype, tuple(sources.shape),
+                    directions.device, directions.dtype, tuple(directions.shape))
+        if idx is None:
+            idx = torch.empty(0, dtype=torch.int64, device=pb.dev)
+        ctx.mark_non_differentiable(idx)
+        return frame, idx
+
+    @staticmethod
+    def backward(ctx, gframe, _gidx):
+        lib = _lib.load()
+        pb = ctx.pb
+        vdev, vdt, sdev, sdt, sshape, ddev, ddt, dshape = ctx.meta
+        need_v, need_s, need_d = ctx.needs_input_grad[:3]
+        with torch.cuda.device(pb.dev):
+            g = gframe.detach().to(device=pb.dev, dtype=torch.float32).contiguous()
+            gvol = torch.zeros_like(pb.vol) if need_v else None
+            gsrc = torch.empty((pb.P, 3), dtype=torch.float32, device=pb.dev) if need_s else None
+            gdirs = torch.empty((pb.P, pb.R, 3), dtype=torch.float32, device=pb.dev) if need_d else None
+            ws = pb.workspace()
+            rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(gsrc), _ptr(gdirs),
+                                       _ptr(ws), ws.numel(), _stream(pb.dev))
+        _lib.check(rc, "diffus_render_bwd")
+        out_v = gvol.to(device=vdev, dtype=vdt) if need_v else None
+        out_s = gsrc.reshape(sshape).to(device=sdev, dtype=sdt) if need_s else None
+        out_d = None
+        if need_d:
+            if len(dshape) == 3:
+                out_d = gdirs
+            elif len(dshape) == 2:      # one fan shared by all poses
+                out_d = gdirs.sum(0)
+            else:
+                out_d = gdirs.sum(0).reshape(dshape)
+            out_d = out_d.to(device=ddev, dtype=ddt)
+        return out_v, out_s, out_d, None, None, None, None, None
+
+
+def render_poses(volume, sources, directions, num_samples, attenuation_coeff, start=0, sampler="nearest",
+                 return_indices=False):
+    """Batched hot path: P poses in one launch.
+
+    volume (d0,d1,d2); sources (P,3) or (3,); directions (P,R,3) or (R,3) shared.
+    -> frame (P,R,num_samples-start) float32 [, idx (3,P,R,N1) int64].
+    Differentiable in volume (both samplers) and in sources/directions (trilinear).
+    """
+    if sampler not in _SAMPLERS:
+        raise ValueError(f"unknown sampler {sampler!r}")
+    start = resolve_start(start, num_samples)
+    if start > 0 and start >= num_samples - 1:
+        raise IndexError("index 0 is out of bounds for dimension 1 with size 0")  # reference :243
+    frame, idx = _RenderFn.apply(volume, sources, directions, num_samples, start, attenuation_coeff,
+                                 sampler, bool(return_indices))
+    return (frame, idx) if return_indices else frame
+
+
+def trace_rays(volume, sources, directions, num_samples, sampler="nearest", want=("imp", "refl", "idx")):
+    """Stage 1 alone (diffus_trace_rays): -> dict with imp (P,R,S), refl (P,R,S-1), idx (3,P,R,S)."""
+    lib = _lib.load()
+    pb = _Problem(volume, sources, directions, num_samples, 0, 0.0, sampler)
+    with torch.cuda.device(pb.dev):
+        imp = torch.empty((pb.P, pb.R, pb.S), dtype=torch.float32, device=pb.dev) if "imp" in want else None
+        refl = torch.empty((pb.P, pb.R, pb.S - 1), dtype=torch.float32, device=pb.dev) if "refl" in want else None
+        idx = torch.empty((3, pb.P, pb.R, pb.S), dtype=torch.int64, device=pb.dev) if "idx" in want else None
+        d0, d1, d2 = pb.vol.shape
+        rc = lib.diffus_trace_rays(_ptr(pb.vol), d0, d1, d2, _ptr(pb.src), pb.src_dt, _ptr(pb.dirs), pb.dir_dt,
+                                   pb.P, pb.R, pb.S, pb.sampler, _ptr(imp), _ptr(refl), _ptr(idx), _stream(pb.dev))
+    _lib.check(rc, "diffus_trace_rays")
+    return {"imp": imp, "refl": refl, "idx": idx}
+
+
+def compute_echo_traces(refLR: torch.Tensor, spacing: float = 1.0, c: float = 1.54e3):
+    """Mirror of reference src/renderer.py:439-457: (echo_signals (B,N+1), delays_us (N+1,))."""
+    lib = _lib.load()
+    if refLR.dim() != 2:
+        raise ValueError("not enough values to unpack (expected 2, got %d)" % refLR.dim())  # B, N = refLR.shape
+    dev = _device_for(refLR)
+    r = refLR.detach().to(device=dev, dtype=torch.float32).contiguous()
+    B, N = r.shape
+    with torch.cuda.device(dev):
+        echo = torch.empty((B, N + 1), dtype=torch.float32, device=dev)
+        rc = lib.diffus_echo_traces(_ptr(r) if N else None, B, N, _ptr(echo), _stream(dev))
+    _lib.check(rc, "diffus_echo_traces")
+    delays_us = 2 * spacing * torch.arange(N + 1, device=refLR.device) / c
+    return echo.to(device=refLR.device, dtype=refLR.dtype if refLR.is_floating_point() else torch.float32), delays_us
+
+
+class UltrasoundRenderer:
+    def __init__(self, num_samples: int, attenuation_coeff: float = 0.5):
+        """
+        num_samples: how many points to sample along each ray
+        attenuation_coeff: controls exponential decay of echoes with depth
+        (reference src/renderer.py:19-25)
+        """
+        self.num_samples = num_samples
+        self.attenuation_coeff = attenuation_coeff
+
+    @staticmethod
+    def compute_reflection_coeff(Z1: torch.Tensor, Z2: torch.Tensor) -> torch.Tensor:
+        """Amplitude reflection coefficient (Z2-Z1)/(Z1+Z2) (reference :27-33).
+        Host-side convenience on caller tensors; the hot path computes it in-kernel."""
+        return (Z2 - Z1) / (Z1 + Z2)
+
+    @staticmethod
+    def trace_ray(volume, source, directions, num_samples, start=0, *, sampler="nearest"):
+        """reference :90-180 -> (x, y, z, ray_values), each (n_rays, num_samples)."""
+        out = trace_rays(volume, source, directions, num_samples, sampler, want=("imp", "idx"))
+        dev = volume.device
+        idx = out["idx"][:, 0].to(dev)
+        return idx[0], idx[1], idx[2], out["imp"][0].to(dev)
+
+    def simulate_rays(self, volume, source, directions, num_samples: int = 0, MRI: bool = False, start=0, *,
+                      sampler="nearest"):
+        """reference :35-71 -> (x, y, z, R) with R (n_rays, num_samples-1), or Z1 when MRI."""
+        if num_samples == 0:
+            num_samples = self.num_samples
+        out = trace_rays(volume, source, directions, num_samples, sampler, want=("imp", "refl", "idx"))
+        dev = volume.device
+        if MRI:
+            return out["imp"][0, :, :-1].to(dev)
+        idx = out["idx"][:, 0].to(dev)
+        return idx[0], idx[1], idx[2], out["refl"][0].squeeze(0).to(dev)
+
+    def plot_beam_frame(self, volume: torch.Tensor, source: torch.Tensor, directions: torch.Tensor,
+                        angle: float = 45.0, plot: bool = True, artifacts: bool = False, ax=None, cmap=None,
+                        std_radial: float = 0.01, std_local: float = 0.15, max_sigma: float = 4.0,
+                        alpha: float = 5, start: float = 0, *, sampler: str = "nearest",
+                        return_indices: bool = True, **kwargs):
+        """Simulate the fan frame of one pose (reference src/renderer.py:201-275).
+
+        volume (d0,d1,d2) impedance; source (3,); directions (n_rays,3) unit vectors.
+        `angle`, `plot`, `ax`, `cmap` are accepted and, as in the reference, never read.
+        Returns (x, y, z, processed_output): three (n_rays, num_samples-start) int64
+        index planes (None when return_indices=False) and the float32 frame, on
+        volume.device.
+        """
+        if artifacts:
+            raise NotImplementedError("artifacts=True (speckle/lateral blur/sharpen, reference :264-273) is "
+                                      "outside the accelerated path; see DESIGN.md §Out of scope")
+        if torch.as_tensor(source).numel() != 3:
+            raise ValueError("source must have 3 components")
+        res = render_poses(volume, source, directions, self.num_samples, self.attenuation_coeff, start=start,
+                           sampler=sampler, return_indices=return_indices)
+        dev = volume.device
+        if return_indices:
+            frame, idx = res
+            idx = idx[:, 0].to(dev)
+            return idx[0], idx[1], idx[2], frame[0].to(dev)
+        return None, None, None, res[0].to(dev)

@@ -1,0 +1,141 @@
+/*
+ * diffus_hip.h -- C ABI of libdiffus_hip.so, the MI355X (gfx950) implementation
+ * of the DiffUS `UltrasoundRenderer.plot_beam_frame` hot path.
+ *
+ * The reference (gduguey/DiffUS) is pure Python and has no FFI of its own; the
+ * boundary it offers is the Python call surface used by its notebooks
+ * (reference src/renderer.py:19, :201-217, :275; src/cone.py:242).  This header
+ * is the C-ABI drop-in underneath that surface: each entry point names the
+ * reference function(s) it replaces.  A reference maintainer binds it with
+ * ctypes (INTEGRATION.md shows the stub); diffus_amd/renderer.py is such a
+ * binding, mirroring the reference class.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch tensor storage),
+ *     except where stated; tensors are dense row-major;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     all work is enqueued on it, nothing synchronises, nothing allocates, so
+ *     every call is legal inside hipGraph stream capture;
+ *   - return value: 0 on success, a negative DIFFUS_E* code otherwise; nothing
+ *     throws; diffus_strerror() explains a code;
+ *   - volume layout: (d0,d1,d2) float32, point coordinate c indexes dim c
+ *     (reference src/renderer.py:750-758), dim 2 contiguous;
+ *   - a *pose* is one probe position: `src` (3) + `dirs` (R,3); P poses are
+ *     batched as src (P,3), dirs (P,R,3);  S = num_samples; `start` is the
+ *     resolved integer crop (reference :237-240), 0 <= start <= S-1;
+ *     N1 = S - start samples per ray are produced.
+ */
+#ifndef DIFFUS_HIP_H
+#define DIFFUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIFFUS_ABI_VERSION 1
+
+/* error codes */
+#define DIFFUS_OK            0
+#define DIFFUS_EINVAL      (-1) /* bad argument (null pointer, non-positive size, bad enum) */
+#define DIFFUS_EUNSUPPORTED (-2) /* shape outside what the kernels cover (S - start > DIFFUS_MAX_SAMPLES) */
+#define DIFFUS_ELAUNCH     (-3) /* HIP reported a launch error (hipGetLastError) */
+#define DIFFUS_EWORKSPACE  (-4) /* workspace too small, see diffus_workspace_bytes */
+
+/* element type of `src` / `dirs`: the reference evaluates source + k*dir with
+ * torch's promotion rules, so f64 inputs change which roundings happen
+ * (reference src/renderer.py:119-124, :751; oracle/diffus_oracle.c orc_point) */
+#define DIFFUS_F32 0
+#define DIFFUS_F64 1
+
+/* sampler */
+#define DIFFUS_NEAREST   0 /* reference custom_nearest_sampler, src/renderer.py:741-759 */
+#define DIFFUS_TRILINEAR 1 /* grid_sample(bilinear, border, align_corners=True) semantics;
+                              the only mode with a pose gradient */
+
+/* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples,
+ * at most 16 -> N1 <= 1024 */
+#define DIFFUS_MAX_SAMPLES 1024
+
+typedef void *diffus_stream_t;
+
+int diffus_abi_version(void);
+const char *diffus_strerror(int code);
+
+/* Scratch the calls below need for a given problem (bytes; 256-B aligned device
+ * memory supplied by the caller, reusable across calls on one stream). */
+size_t diffus_workspace_bytes(int P, int R, int S, int start);
+
+/*
+ * Forward: replaces UltrasoundRenderer.plot_beam_frame with artifacts=False
+ * (reference src/renderer.py:201-275) and everything under it: trace_ray
+ * (:90-180), custom_nearest_sampler (:741-759), compute_reflection_coeff
+ * (:27-33), the start crop + median (:241-244), compute_echo_traces /
+ * propagate_full_rays_batched / prop_single_ray (:367-457, evaluated as an O(N)
+ * running product of 2x2 transfer matrices instead of N+1 dense solves) and the
+ * attenuation (:256-259) -- for P poses at once.
+ *
+ *   frame  out (P,R,N1) float32   processed_output of the reference
+ *   idx    out, nullable: (3,P,R,N1) int64 -- the x,y,z index planes the
+ *          reference returns, already cropped to [:, start:]
+ */
+int diffus_render_fwd(const float *vol, int d0, int d1, int d2,
+                      const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype,
+                      int P, int R, int S, int start, float alpha, int sampler,
+                      float *frame, int64_t *idx,
+                      void *workspace, size_t workspace_bytes,
+                      diffus_stream_t stream);
+
+/*
+ * Backward of diffus_render_fwd (what torch autograd would do through the
+ * reference's sub-functions, SURVEY.md §3.2 / App. A.4, without storing any
+ * dense system): given gframe = dL/dframe (P,R,N1) it recomputes the forward
+ * per ray and produces any of
+ *   gvol   nullable (d0,d1,d2) float32, ACCUMULATED with float atomics
+ *          (caller zeroes it; shared by all poses)
+ *   gsrc   nullable (P,3) float32, overwritten   (trilinear only, else zeros)
+ *   gdirs  nullable (P,R,3) float32, overwritten (trilinear only, else zeros)
+ * With start > 0 the median written into column 0 (reference :243-244) routes
+ * its gradient to the ray that supplied the median, like torch.median.
+ */
+int diffus_render_bwd(const float *vol, int d0, int d1, int d2,
+                      const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype,
+                      int P, int R, int S, int start, float alpha, int sampler,
+                      const float *gframe,
+                      float *gvol, float *gsrc, float *gdirs,
+                      void *workspace, size_t workspace_bytes,
+                      diffus_stream_t stream);
+
+/*
+ * Stage 1 alone: replaces UltrasoundRenderer.trace_ray / simulate_rays
+ * (reference src/renderer.py:90-180, :35-71) = custom_nearest_sampler
+ * (:741-759) + compute_reflection_coeff (:27-33).  Any of the outputs may be
+ * NULL.  No crop: all S samples.
+ *   imp   (P,R,S)   float32  sampled impedances (trace_ray's ray_values)
+ *   refl  (P,R,S-1) float32  reflection coefficients (simulate_rays' R)
+ *   idx   (3,P,R,S) int64    rounded, clamped voxel indices x,y,z
+ */
+int diffus_trace_rays(const float *vol, int d0, int d1, int d2,
+                      const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype,
+                      int P, int R, int S, int sampler,
+                      float *imp, float *refl, int64_t *idx,
+                      diffus_stream_t stream);
+
+/*
+ * Stage 2 alone: replaces compute_echo_traces' first return value (reference
+ * src/renderer.py:439-457, i.e. propagate_full_rays_batched :412-436 and
+ * prop_single_ray :367-410): refl (B,N) -> echo (B,N+1), echo[:,0] = 0.
+ * N + 1 <= DIFFUS_MAX_SAMPLES.
+ */
+int diffus_echo_traces(const float *refl, int B, int N, float *echo,
+                       diffus_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFUS_HIP_H */

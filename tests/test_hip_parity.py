@@ -1,0 +1,360 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via diffus_amd) against
+  (1) golden vectors produced by the reference itself (tests/golden, G1-G10),
+  (2) the CPU oracle on the same seeded inputs,
+  (3) torch autograd in float64 over oracle/autograd_ref.py for gradients,
+  (4) size-independent properties at BASELINE.json's full sizes.
+Tolerances: index planes exact; nearest-mode frame vs reference fp32
+<= 1e-4 max-norm-relative per frame; vs fp64 truth <= 1e-5; gradients <= 1e-3
+max-norm-relative (float atomics reorder sums).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, maxnorm_rel
+from diffus_amd.phantom import phantom, pose_ring
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def da():
+    import diffus_amd
+    from diffus_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    assert torch.cuda.is_available()
+    return diffus_amd
+
+
+@pytest.fixture(scope="module")
+def vols():
+    return {n: phantom(n) for n in (32, 64)}
+
+
+@pytest.fixture(scope="module")
+def vol256():
+    return phantom(256)
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ----------------------------------------------------------------------------- stage 2: echo series
+def test_echo_traces_golden(da, oracle):
+    g1 = load_golden("g1_three_layer")
+    e, delays = da.compute_echo_traces(cuda(g1["r"]))
+    np.testing.assert_allclose(e.cpu().numpy(), g1["echo"], atol=3e-7)
+    assert delays.shape == (3,)
+    g2 = load_golden("g2_modeling_choices_phantom")
+    e, _ = da.compute_echo_traces(cuda(g2["r"]))
+    assert maxnorm_rel(e.cpu().numpy(), g2["echo"]) < 1e-5
+    g3 = load_golden("g3_nan")
+    e, _ = da.compute_echo_traces(cuda(g3["r"]))
+    np.testing.assert_array_equal(e.cpu().numpy(), g3["echo"])
+    g4 = load_golden("g4_random_series")
+    e = da.compute_echo_traces(cuda(g4["r"]))[0].cpu().numpy()
+    orc = oracle.echo_scan(g4["r"])
+    for i in range(8):
+        assert maxnorm_rel(e[i], g4["echo32"][i]) < 1e-4, i      # the reference in fp32
+        assert maxnorm_rel(e[i], g4["echo64"][i]) < 1e-5, i      # the reference in fp64
+        assert maxnorm_rel(e[i], orc[i]) < 1e-5, i
+
+
+@pytest.mark.parametrize("N", [0, 1, 2, 63, 64, 127, 128, 255, 300, 511, 1023])
+def test_echo_traces_sizes(da, oracle, N):
+    rng = np.random.default_rng(N)
+    r = rng.uniform(-0.6, 0.6, size=(5, N)).astype(np.float32)
+    if N > 10:
+        r[1, N // 2] = 0.99995  # nearly singular interface
+        r[2, 3] = np.nan
+        r[3, :] = 0
+    e = da.compute_echo_traces(cuda(r))[0].cpu().numpy()
+    ref = oracle.echo_scan(r.astype(np.float64), np.float64)
+    assert e.shape == (5, N + 1)
+    assert np.all(e[:, 0] == 0)
+    for i in range(5):
+        assert maxnorm_rel(e[i], ref[i]) < 2e-5, (N, i)
+    if N > 10:
+        assert np.all(e[2, 4:] == 0)
+
+
+def test_echo_adversarial_growth(da, oracle):
+    # alternating air/tissue: |P| doubles every two steps (2^500 over the ray) -- renormalisation path
+    z = np.where(np.arange(1024) % 2 == 0, 400.0, 1.6e6).astype(np.float32)[None, :]
+    r = oracle.reflection(z)
+    e = da.compute_echo_traces(cuda(r))[0].cpu().numpy()
+    ref = oracle.echo_scan(r.astype(np.float64), np.float64)
+    assert np.all(np.isfinite(e))
+    assert maxnorm_rel(e, ref) < 1e-4
+
+
+# ----------------------------------------------------------------------------- stage 1: sampling
+@pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
+def test_trace_rays_vs_oracle(da, oracle, vols, sampler):
+    g = load_golden("g5_small_frames")
+    for t in [str(x) for x in g["tags"]]:
+        n, S = int(g[f"{t}_n"]), int(g[f"{t}_S"])
+        src, dirs = g[f"{t}_source"], g[f"{t}_directions"]
+        out = da.trace_rays(cuda(vols[n]), torch.from_numpy(src), torch.from_numpy(dirs), S, sampler)
+        ix, iy, iz, imp_n = oracle.sample_nearest(vols[n], src, dirs, S)
+        idx = out["idx"][:, 0].cpu().numpy()
+        np.testing.assert_array_equal(idx[0], ix, err_msg=t)
+        np.testing.assert_array_equal(idx[1], iy, err_msg=t)
+        np.testing.assert_array_equal(idx[2], iz, err_msg=t)
+        imp = imp_n if sampler == "nearest" else oracle.sample_trilinear(vols[n], src, dirs, S)
+        np.testing.assert_array_equal(out["imp"][0].cpu().numpy(), imp, err_msg=t)     # same fp32 op sequence
+        np.testing.assert_array_equal(out["refl"][0].cpu().numpy(), oracle.reflection(imp), err_msg=t)
+
+
+def test_trilinear_vs_grid_sample_golden(da):
+    g = load_golden("g9_trilinear")
+    n, S, alpha = int(g["n"]), int(g["S"]), float(g["alpha"])
+    vol = cuda(phantom(n))
+    out = da.trace_rays(vol, torch.from_numpy(g["source"]), torch.from_numpy(g["directions"]), S, "trilinear")
+    assert maxnorm_rel(out["imp"][0].cpu().numpy(), g["imp"]) < 1e-6
+    R = da.UltrasoundRenderer(S, alpha)
+    _, _, _, f = R.plot_beam_frame(vol, torch.from_numpy(g["source"]), torch.from_numpy(g["directions"]),
+                                   sampler="trilinear")
+    assert maxnorm_rel(f.cpu().numpy(), g["frame"]) < 1e-4
+
+
+# ----------------------------------------------------------------------------- whole frames vs the reference
+def test_plot_beam_frame_golden_small(da, oracle, vols):
+    g = load_golden("g5_small_frames")
+    for t in [str(x) for x in g["tags"]]:
+        n, S, alpha, start = int(g[f"{t}_n"]), int(g[f"{t}_S"]), float(g[f"{t}_alpha"]), int(g[f"{t}_start"])
+        R = da.UltrasoundRenderer(S, alpha)
+        vol = cuda(vols[n])
+        x, y, z, f = R.plot_beam_frame(vol, torch.from_numpy(g[f"{t}_source"]), torch.from_numpy(g[f"{t}_directions"]),
+                                       plot=False, start=start)
+        assert x.dtype == torch.int64 and f.dtype == torch.float32 and f.device == vol.device
+        np.testing.assert_array_equal(x.cpu().numpy(), g[f"{t}_x"], err_msg=t)
+        np.testing.assert_array_equal(y.cpu().numpy(), g[f"{t}_y"], err_msg=t)
+        np.testing.assert_array_equal(z.cpu().numpy(), g[f"{t}_z"], err_msg=t)
+        f = f.cpu().numpy()
+        assert f.shape == g[f"{t}_frame"].shape
+        assert maxnorm_rel(f, g[f"{t}_frame"]) < 1e-4, t
+        _, _, _, fo = oracle.plot_beam_frame(vols[n], g[f"{t}_source"], g[f"{t}_directions"], S, alpha, start)
+        assert maxnorm_rel(f, fo) < 2e-5, t
+        assert np.all(f[:, 0] == 0)
+
+
+def test_cpu_tensors_are_accepted_like_the_reference(da, vols):
+    g = load_golden("g5_small_frames")
+    t = "a"
+    R = da.UltrasoundRenderer(int(g[f"{t}_S"]), float(g[f"{t}_alpha"]))
+    x, y, z, f = R.plot_beam_frame(torch.from_numpy(vols[64]), torch.from_numpy(g[f"{t}_source"]),
+                                   torch.from_numpy(g[f"{t}_directions"]))
+    assert f.device.type == "cpu" and x.device.type == "cpu"
+    assert maxnorm_rel(f.numpy(), g[f"{t}_frame"]) < 1e-4
+
+
+def test_config1_golden(da, vol256):
+    g = load_golden("g6_config1")
+    R = da.UltrasoundRenderer(256, 1e-4)
+    x, y, z, f = R.plot_beam_frame(cuda(vol256), torch.from_numpy(g["source"]), torch.from_numpy(g["directions"]))
+    np.testing.assert_array_equal(x.cpu().numpy(), g["x"])
+    np.testing.assert_array_equal(y.cpu().numpy(), g["y"])
+    np.testing.assert_array_equal(z.cpu().numpy(), g["z"])
+    assert maxnorm_rel(f.cpu().numpy(), g["frame"]) < 1e-4
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "g10_config2_fwd.npz")),
+                    reason="G10 not generated")
+def test_config2_golden(da, vol256):
+    g = load_golden("g10_config2_fwd")
+    R = da.UltrasoundRenderer(512, 1e-4)
+    _, _, _, f = R.plot_beam_frame(cuda(vol256), torch.from_numpy(g["source"]), torch.from_numpy(g["directions"]),
+                                   return_indices=False)
+    assert maxnorm_rel(f.cpu().numpy(), g["frame"]) < 1e-4
+
+
+# ----------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("S,start,R", [(2, 0, 2), (3, 1, 3), (48, 46, 5), (65, 0, 1), (130, 1, 7), (257, 0, 3),
+                                       (513, 0, 2), (1024, 0, 3), (1030, 6, 2)])
+@pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
+def test_shapes_and_edges_vs_oracle(da, oracle, vols, S, start, R, sampler):
+    src, dirs = pose_ring(64, 3, R)
+    vol = vols[64]
+    f = da.render_poses(cuda(vol), torch.from_numpy(src), torch.from_numpy(dirs), S, 2e-3, start=start,
+                        sampler=sampler).cpu().numpy()
+    assert f.shape == (3, R, S - start)
+    for p in range(3):
+        _, _, _, fo = oracle.plot_beam_frame(vol, src[p], dirs[p], S, 2e-3, start, sampler=sampler)
+        assert maxnorm_rel(f[p], fo) < 3e-5, (p, S, start)
+
+
+def test_too_many_samples_fails_loudly(da, vols):
+    src, dirs = pose_ring(64, 1, 4)
+    with pytest.raises(da.DiffusError, match="unsupported"):
+        da.render_poses(cuda(vols[64]), torch.from_numpy(src), torch.from_numpy(dirs), 1025, 1e-3)
+    with pytest.raises(IndexError):
+        da.render_poses(cuda(vols[64]), torch.from_numpy(src), torch.from_numpy(dirs), 48, 1e-3, start=47)
+    with pytest.raises(NotImplementedError):
+        da.UltrasoundRenderer(48).plot_beam_frame(cuda(vols[64]), torch.from_numpy(src[0]), torch.from_numpy(dirs[0]),
+                                                  artifacts=True)
+
+
+def test_zero_impedance_and_degenerate_volume(da, oracle):
+    vol = phantom(32).copy()
+    vol[10:14, :, :] = 0.0        # Z1+Z2 = 0 -> NaN r -> echoes zero from there on (reference :408)
+    src = np.array([2.0, 16.0, 16.0], np.float32)
+    dirs = np.array([[1.0, 0.0, 0.0], [0.9, 0.1, 0.0]], np.float32)
+    for sampler in ("nearest", "trilinear"):
+        f = da.render_poses(cuda(vol), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
+                            sampler=sampler).cpu().numpy()[0]
+        _, _, _, fo = oracle.plot_beam_frame(vol, src, dirs, 30, 1e-3, 0, sampler=sampler)
+        assert np.all(np.isfinite(f))
+        np.testing.assert_allclose(f, fo, atol=1e-6)
+        assert np.all(f[0, 12:] == 0)
+    flat = phantom(32)[:, :, :1].copy()   # d2 == 1: the paired dim-2 load must not be used
+    f = da.render_poses(cuda(flat), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
+                        sampler="trilinear").cpu().numpy()[0]
+    _, _, _, fo = oracle.plot_beam_frame(flat, src, dirs, 30, 1e-3, 0, sampler="trilinear")
+    assert maxnorm_rel(f, fo) < 2e-5
+
+
+# ----------------------------------------------------------------------------- gradients
+def _autograd_case(vol_np, src, dirs, S, alpha, start, sampler, gseed=0):
+    from oracle import autograd_ref as ar
+    vol = torch.from_numpy(vol_np).double().requires_grad_(True)
+    s = torch.from_numpy(src).double().requires_grad_(True)
+    d = torch.from_numpy(dirs).double().requires_grad_(True)
+    f = ar.render(vol, s, d, S, alpha, start, sampler)
+    g = torch.Generator().manual_seed(gseed)
+    up = torch.randn(f.shape, generator=g, dtype=torch.float64)
+    (f * up).sum().backward()
+    return f.detach().numpy(), up.float(), vol.grad.numpy(), (s.grad.numpy() if s.grad is not None else None), \
+        (d.grad.numpy() if d.grad is not None else None)
+
+
+@pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
+@pytest.mark.parametrize("S,start", [(48, 0), (48, 7), (150, 0), (300, 12), (700, 0)])
+def test_backward_vs_float64_autograd(da, vols, sampler, S, start):
+    n = 64
+    src, dirs = pose_ring(n, 4, 6)
+    src, dirs = src[1], dirs[1].copy()
+    dirs[:, 2] = 0.21                                   # out of plane: all three lerps carry gradient
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    alpha = 3e-3
+    f_ref, up, gv_ref, gs_ref, gd_ref = _autograd_case(vols[n], src, dirs, S, alpha, start, sampler)
+    vol = cuda(vols[n]).requires_grad_(True)
+    s = torch.from_numpy(src).cuda().requires_grad_(True)
+    d = torch.from_numpy(dirs).cuda().requires_grad_(True)
+    f = da.render_poses(vol, s, d, S, alpha, start=start, sampler=sampler)[0]
+    assert maxnorm_rel(f.detach().cpu().numpy(), f_ref) < 2e-5
+    (f * up.cuda()).sum().backward()
+    assert maxnorm_rel(vol.grad.cpu().numpy(), gv_ref) < 1e-3
+    if sampler == "trilinear":
+        assert maxnorm_rel(s.grad.cpu().numpy(), gs_ref) < 1e-3
+        assert maxnorm_rel(d.grad.cpu().numpy(), gd_ref) < 1e-3
+    else:
+        assert torch.all(s.grad == 0) and torch.all(d.grad == 0)   # integer indices: no pose gradient
+
+
+def test_backward_golden_volume_grad(da):
+    g = load_golden("g7_volume_grad")
+    n, S, alpha = int(g["n"]), int(g["S"]), float(g["alpha"])
+    vol = cuda(phantom(n)).requires_grad_(True)
+    f = da.render_poses(vol, torch.from_numpy(g["source"]), torch.from_numpy(g["directions"]), S, alpha)[0]
+    assert maxnorm_rel(f.detach().cpu().numpy(), g["frame"]) < 1e-4
+    (f ** 2).sum().backward()
+    gv = vol.grad.flatten().cpu().numpy()
+    ref = np.zeros_like(gv)
+    ref[g["grad_index"]] = g["grad_value"]
+    assert maxnorm_rel(gv, ref) < 1e-3          # the reference's own autograd (fp32 LU backward)
+
+
+def test_backward_batched_shared_fan_and_f64_pose(da, vols):
+    n, S, alpha = 64, 100, 1e-3
+    src, dirs = pose_ring(n, 5, 8)
+    fan = dirs[0].copy()
+    vol = cuda(vols[n]).requires_grad_(True)
+    s = torch.from_numpy(src).double().cuda().requires_grad_(True)     # f64 sources, shared f32 fan
+    d = torch.from_numpy(fan).cuda().requires_grad_(True)
+    f = da.render_poses(vol, s, d, S, alpha, start=3, sampler="trilinear")
+    assert f.shape == (5, 8, 97)
+    (f ** 2).sum().backward()
+    assert s.grad.dtype == torch.float64 and s.grad.shape == (5, 3) and d.grad.shape == (8, 3)
+    gv = torch.zeros_like(vol)
+    gd = torch.zeros_like(d)
+    for p in range(5):
+        v2 = cuda(vols[n]).requires_grad_(True)
+        s2 = torch.from_numpy(src[p]).double().cuda().requires_grad_(True)
+        d2 = torch.from_numpy(fan).cuda().requires_grad_(True)
+        f2 = da.render_poses(v2, s2, d2, S, alpha, start=3, sampler="trilinear")
+        torch.testing.assert_close(f2[0], f[p], rtol=0, atol=0)
+        (f2 ** 2).sum().backward()
+        gv += v2.grad
+        gd += d2.grad
+        assert maxnorm_rel(s2.grad.cpu().numpy(), s.grad[p].cpu().numpy()) < 1e-5
+    assert maxnorm_rel(vol.grad.cpu().numpy(), gv.cpu().numpy()) < 1e-4
+    assert maxnorm_rel(d.grad.cpu().numpy(), gd.cpu().numpy()) < 1e-4
+
+
+def test_pose_gradient_finite_difference(da, vols):
+    # independent of any autograd: central differences on the HIP forward itself, smooth volume
+    n = 64
+    u = np.arange(n, dtype=np.float64) / (n - 1)
+    vol = (1.6e6 + 2e5 * np.sin(5 * u)[:, None, None] * np.cos(4 * u)[None, :, None] * np.sin(3 * u + 1)[None, None, :])
+    vol = cuda(vol.astype(np.float32))
+    src0 = torch.tensor([20.3, 22.7, 30.4], dtype=torch.float64)
+    d0 = torch.tensor([[0.6, 0.7, 0.3872983], [0.8, 0.5, 0.3316625]], dtype=torch.float64)
+    S, alpha = 40, 1e-2
+    w = torch.linspace(0.5, 1.5, 2 * S, dtype=torch.float64).reshape(2, S).cuda()
+
+    def loss(s, d):
+        return (da.render_poses(vol, s, d, S, alpha, sampler="trilinear")[0].double() * w).sum()
+
+    s = src0.clone().cuda().requires_grad_(True)
+    d = d0.clone().cuda().requires_grad_(True)
+    loss(s, d).backward()
+    h = 1e-2
+    for c in range(3):
+        e = torch.zeros(3, dtype=torch.float64); e[c] = h
+        fd = (loss((src0 + e).cuda(), d0.cuda()) - loss((src0 - e).cuda(), d0.cuda())).item() / (2 * h)
+        assert abs(fd - s.grad[c].item()) < 2e-2 * max(1e-12, s.grad.abs().max().item()), (c, fd, s.grad)
+
+
+# ----------------------------------------------------------------------------- full-size (BASELINE configs 2/3)
+def test_full_size_batch_vs_oracle_and_properties(da, oracle, vol256):
+    P, R, S, alpha = 32, 256, 512, 1e-4
+    src, dirs = pose_ring(256, P, R)
+    vol = cuda(vol256)
+    s, d = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+    for sampler in ("nearest", "trilinear"):
+        f = da.render_poses(vol, s, d, S, alpha, sampler=sampler)
+        assert f.shape == (P, R, S)
+        fc = f.cpu().numpy()
+        assert np.all(np.isfinite(fc)) and np.all(fc[:, :, 0] == 0)
+        for p in (0, 7, 19, 31):                       # the O(N) C oracle does a 256x512 frame in milliseconds
+            _, _, _, fo = oracle.plot_beam_frame(vol256, src[p], dirs[p], S, alpha, 0, sampler=sampler)
+            assert maxnorm_rel(fc[p], fo) < 2e-5, (sampler, p)
+        # determinism and batch-independence of the forward
+        f2 = da.render_poses(vol, s[5:6], d[5:6], S, alpha, sampler=sampler)
+        assert torch.equal(f2[0], f[5])
+        assert torch.equal(da.render_poses(vol, s, d, S, alpha, sampler=sampler), f)
+
+
+def test_full_size_backward_properties(da, vol256):
+    P, R, S, alpha = 32, 256, 512, 1e-4
+    src, dirs = pose_ring(256, P, R)
+    vol = cuda(vol256).requires_grad_(True)
+    s = torch.from_numpy(src).cuda().requires_grad_(True)
+    d = torch.from_numpy(dirs).cuda().requires_grad_(True)
+    f = da.render_poses(vol, s, d, S, alpha, sampler="trilinear")
+    g1 = torch.autograd.grad(f, (vol, s, d), grad_outputs=2 * f.detach(), retain_graph=True)
+    g2 = torch.autograd.grad(f, (vol, s, d), grad_outputs=6 * f.detach(), retain_graph=True)
+    for a, b in zip(g1, g2):                            # backward is linear in the upstream gradient
+        assert torch.all(torch.isfinite(a))
+        assert maxnorm_rel((3 * a).cpu().numpy(), b.cpu().numpy()) < 1e-4
+    # volume gradient only touches voxels on the fans (two dim-2 slabs around each apex plane)
+    nzz = torch.nonzero(g1[0].abs().sum((0, 1))).flatten().cpu().numpy()
+    zs = src[:, 2]
+    assert nzz.min() >= np.floor(zs.min()) and nzz.max() <= np.ceil(zs.max()) + 1
+    # zero upstream gradient -> zero gradients
+    g0 = torch.autograd.grad(f, (vol, s, d), grad_outputs=torch.zeros_like(f))
+    assert all(torch.all(x == 0) for x in g0)
