@@ -119,7 +119,10 @@ def cpu_baseline(budget_rays=64, budget_steps=256):
     n = 256
     vol = phantom(n)
     src, dirs = pose_ring(n, 32, budget_rays)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU a 16-core share of the host; more threads than that (or than the
+    # affinity mask) only oversubscribes the many small LAPACK calls
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     dense.plot_beam_frame_dense(torch.from_numpy(vol), torch.from_numpy(src[0]), torch.from_numpy(dirs[0]),
                                 budget_steps, 1e-4, 0)

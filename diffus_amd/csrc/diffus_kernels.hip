@@ -291,6 +291,7 @@ struct Args {
     // backward
     const float *gframe;
     float *gvol;
+    float *zbar;      // (P,R,N1) d L / d imp per sample, consumed by scatter_patch_kernel
     float *gsrc_part; // (P,R,3) per-ray partials of d/d source
     float *gdirs;
     // start>0 coupling
@@ -604,25 +605,23 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
     if (lane != kWave - 1) zbar[C - 1] += cin;
     if (gmed_lane != 0.f) atomicAdd(&A.gmed[pose], gmed_lane);
 
-    // ---- scatter to the volume, reduce the pose gradient ----
-    float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
+    // ---- hand d L / d imp to the scatter kernel, reduce the pose gradient ----
+    // The volume scatter is a separate launch (scatter_patch_kernel): its thread <-> sample
+    // mapping is chosen for LDS privatisation, not for the scan.
+    if (A.zbar) {
+        float *zo = A.zbar + w * A.N1;
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
-        float zb = zbar[j];
-        if (n < A.N1 && zb != 0.f) {
-            int k = A.start + n;
-            if (A.gvol) {
-                float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
-                if (SAMPLER == DIFFUS_NEAREST) {
-                    int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
-                    atomicAdd(A.gvol + ((long)i0 * A.d1 + i1) * A.d2 + i2, zb);
-                } else {
-                    tri_scatter(A.gvol, A.d0, A.d1, A.d2, p0, p1, p2, zb);
-                }
-            }
-            if (GPOSE) {
-                float kf = (float)k;
+        for (int j = 0; j < C; ++j)
+            if (n0 + j < A.N1) zo[n0 + j] = zbar[j];
+    }
+    float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
+    if (GPOSE) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = n0 + j;
+            float zb = zbar[j];
+            if (n < A.N1 && zb != 0.f) {
+                float kf = (float)(A.start + n);
                 float a0 = zb * gp0[j], a1 = zb * gp1[j], a2 = zb * gp2[j];
                 gs0 += a0; gs1 += a1; gs2 += a2;
                 gd0 = __builtin_fmaf(kf, a0, gd0);
@@ -652,6 +651,161 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
                 A.gdirs[w * 3 + 1] = gd1;
                 A.gdirs[w * 3 + 2] = gd2;
             }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// VOLUME SCATTER.  gvol += sum over samples of zbar * (interpolation weights).
+// Naive per-sample global float atomics run ~10x below even the scattered-atomic
+// rate because every fan hammers the few hundred voxels around its apex
+// (measured: 17.5 ms for 33 M atomics).  Instead a block takes a PATCH of
+// kPatchRays adjacent rays x kPatchSteps consecutive steps of one pose, whose
+// footprint is a small box of voxels; it accumulates the patch into an LDS tile
+// covering that box (ds_add_f32) and flushes each touched voxel ONCE.  Patches
+// whose box does not fit the tile fall back to direct global atomics.
+constexpr int kPatchRays = 16;
+constexpr int kPatchSteps = 64;
+constexpr int kTileCap = 12 * 1024; // floats (48 KiB): 3 blocks per CU
+constexpr int kSamplesPerThread = kPatchRays * kPatchSteps / kBlock; // 4
+
+struct Cell {
+    int i0[3], i1[3];
+    float t[3];
+};
+
+template <int SAMPLER>
+__device__ __forceinline__ Cell cell_of(const Args &A, const Pose &ps, int k)
+{
+    Cell c;
+    const int dims[3] = {A.d0, A.d1, A.d2};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float p = ray_point(ps, a, k);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            c.i0[a] = c.i1[a] = nearest_index(p, dims[a]);
+            c.t[a] = 0.f;
+        } else {
+            Axis ax = tri_axis(p, dims[a]);
+            c.i0[a] = ax.i0;
+            c.i1[a] = ax.i1;
+            c.t[a] = ax.t;
+        }
+    }
+    return c;
+}
+
+template <int SAMPLER, typename F>
+__device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
+{
+    if (SAMPLER == DIFFUS_NEAREST) {
+        f(c.i0[0], c.i0[1], c.i0[2], zb);
+    } else {
+        float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1, wc1 = c.t[2], wc0 = 1.f - wc1;
+        float w00 = zb * wa0 * wb0, w01 = zb * wa0 * wb1, w10 = zb * wa1 * wb0, w11 = zb * wa1 * wb1;
+        f(c.i0[0], c.i0[1], c.i0[2], w00 * wc0);
+        f(c.i0[0], c.i0[1], c.i1[2], w00 * wc1);
+        f(c.i0[0], c.i1[1], c.i0[2], w01 * wc0);
+        f(c.i0[0], c.i1[1], c.i1[2], w01 * wc1);
+        f(c.i1[0], c.i0[1], c.i0[2], w10 * wc0);
+        f(c.i1[0], c.i0[1], c.i1[2], w10 * wc1);
+        f(c.i1[0], c.i1[1], c.i0[2], w11 * wc0);
+        f(c.i1[0], c.i1[1], c.i1[2], w11 * wc1);
+    }
+}
+
+template <int SAMPLER>
+__global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_groups, int step_groups)
+{
+    __shared__ float tile[kTileCap];
+    __shared__ int s_lo[3], s_hi[3];
+
+    // patch -> (pose, ray group, step group); the XCD remap keeps a pose on one XCD
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int sg = L % step_groups;
+    const int rg = (L / step_groups) % ray_groups;
+    const int pose = L / (step_groups * ray_groups);
+    const int tid = threadIdx.x;
+    // thread -> ray (tid / 16) and 4 consecutive steps ((tid % 16) * 4 ..)
+    const int ray = rg * kPatchRays + tid / (kPatchSteps / kSamplesPerThread);
+    const int nbase = sg * kPatchSteps + (tid % (kPatchSteps / kSamplesPerThread)) * kSamplesPerThread;
+    const bool ray_ok = ray < A.R;
+    const long w = (long)pose * A.R + (ray_ok ? ray : 0);
+
+    if (tid < 3) {
+        s_lo[tid] = 0x7fffffff;
+        s_hi[tid] = -1;
+    }
+    Pose ps;
+    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    Cell cells[kSamplesPerThread];
+    float zb[kSamplesPerThread];
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+        int n = nbase + q;
+        zb[q] = 0.f;
+        if (ray_ok && n < A.N1) zb[q] = A.zbar[w * A.N1 + n];
+        if (!finitef(zb[q])) zb[q] = 0.f;
+        cells[q] = cell_of<SAMPLER>(A, ps, A.start + n);
+        if (zb[q] != 0.f) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = min(lo[a], cells[q].i0[a]);
+                hi[a] = max(hi[a], cells[q].i1[a]);
+            }
+        }
+    }
+    // block bounding box: wave reduce, then one LDS atomic per wave
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo[a] = min(lo[a], __shfl_xor(lo[a], off, kWave));
+            hi[a] = max(hi[a], __shfl_xor(hi[a], off, kWave));
+        }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&s_lo[a], lo[a]);
+            atomicMax(&s_hi[a], hi[a]);
+        }
+    }
+    __syncthreads();
+    const int l0 = s_lo[0], l1 = s_lo[1], l2 = s_lo[2];
+    if (s_hi[0] < 0) return; // nothing to add in this patch (block-uniform)
+    const int b0 = s_hi[0] - l0 + 1, b1 = s_hi[1] - l1 + 1, b2 = s_hi[2] - l2 + 1;
+    const long vol_tile = (long)b0 * b1 * b2;
+    const long s0 = (long)A.d1 * A.d2;
+
+    if (vol_tile > kTileCap) { // block-uniform fallback: direct atomics
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+            if (zb[q] != 0.f)
+                for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
+                    if (v != 0.f) atomicAdd(A.gvol + i * s0 + (long)j * A.d2 + k, v);
+                });
+        return;
+    }
+    const int nt = (int)vol_tile;
+    for (int e = tid; e < nt; e += kBlock) tile[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q)
+        if (zb[q] != 0.f)
+            for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
+                atomicAdd(&tile[((i - l0) * b1 + (j - l1)) * b2 + (k - l2)], v);
+            });
+    __syncthreads();
+    const int b12 = b1 * b2;
+    for (int e = tid; e < nt; e += kBlock) {
+        float v = tile[e];
+        if (v != 0.f) {
+            int i = e / b12, rem = e - i * b12;
+            int j = rem / b2, k = rem - j * b2;
+            atomicAdd(A.gvol + (l0 + i) * s0 + (long)(l1 + j) * A.d2 + (l2 + k), v);
         }
     }
 }
@@ -861,10 +1015,11 @@ struct Workspace {
     int *who;
     float *gmed;
     float *gsrc_part;
+    float *zbar;
     size_t bytes;
 };
 
-Workspace carve(void *base, int P, int R)
+Workspace carve(void *base, int P, int R, int N1)
 {
     Workspace ws;
     char *p = (char *)base;
@@ -873,6 +1028,7 @@ Workspace carve(void *base, int P, int R)
     ws.who = (int *)(p + o);   o += align256(sizeof(int) * (size_t)P);
     ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
     ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
+    ws.zbar = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * (N1 > 0 ? N1 : 0));
     ws.bytes = o;
     return ws;
 }
@@ -971,9 +1127,8 @@ const char *diffus_strerror(int code)
 
 size_t diffus_workspace_bytes(int P, int R, int S, int start)
 {
-    (void)S; (void)start;
-    if (P <= 0 || R <= 0) return 0;
-    return carve(nullptr, P, R).bytes;
+    if (P <= 0 || R <= 0 || S <= 0 || start < 0 || start >= S) return 0;
+    return carve(nullptr, P, R, S - start).bytes;
 }
 
 int diffus_render_fwd(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
@@ -983,7 +1138,7 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, const void *src,
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler);
     if (rc) return rc;
     if (!frame) return DIFFUS_EINVAL;
-    Workspace ws = carve(workspace, P, R);
+    Workspace ws = carve(workspace, P, R, S - start);
     if (start > 0 && (!workspace || workspace_bytes < ws.bytes)) return DIFFUS_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
@@ -1005,7 +1160,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, const void *src,
     if (rc) return rc;
     if (!gframe) return DIFFUS_EINVAL;
     if (!gvol && !gsrc && !gdirs) return DIFFUS_OK;
-    Workspace ws = carve(workspace, P, R);
+    Workspace ws = carve(workspace, P, R, S - start);
     if (!workspace || workspace_bytes < ws.bytes) return DIFFUS_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool pose = sampler == DIFFUS_TRILINEAR && (gsrc || gdirs);
@@ -1017,6 +1172,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, const void *src,
     Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.gframe = gframe;
     A.gvol = gvol;
+    A.zbar = gvol ? ws.zbar : nullptr;
     A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
     A.gdirs = pose ? gdirs : nullptr;
     if (start > 0) { // recompute the median (and zero gmed)
@@ -1028,6 +1184,15 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, const void *src,
     else
         rc = pose ? launch_bwd<DIFFUS_TRILINEAR, true>(A, st) : launch_bwd<DIFFUS_TRILINEAR, false>(A, st);
     if (rc) return rc;
+    if (gvol) {
+        const int rgs = (R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
+        const unsigned nb = (unsigned)((long)P * rgs * sgs);
+        if (sampler == DIFFUS_NEAREST)
+            hipLaunchKernelGGL(scatter_patch_kernel<DIFFUS_NEAREST>, dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
+        else
+            hipLaunchKernelGGL(scatter_patch_kernel<DIFFUS_TRILINEAR>, dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
+        if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
+    }
     if (start > 0) {
         const unsigned nb = (unsigned)((P + 63) / 64);
         if (sampler == DIFFUS_NEAREST)
@@ -1051,7 +1216,7 @@ int diffus_trace_rays(const float *vol, int d0, int d1, int d2, const void *src,
     if (rc == DIFFUS_EUNSUPPORTED && S > DIFFUS_MAX_SAMPLES) rc = DIFFUS_OK; // no scan here: any S
     if (rc) return rc;
     if (!imp && !refl && !idx) return DIFFUS_OK;
-    Workspace ws = carve(nullptr, P, R);
+    Workspace ws = carve(nullptr, P, R, S);
     Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, 0.f, ws);
     const long total = (long)P * R * S;
     unsigned nblk = (unsigned)((total + kBlock - 1) / kBlock);
