@@ -49,9 +49,10 @@ HBM_PEAK_GBS = 8000.0
 class HotPath:
     """Pre-allocated buffers + direct C-ABI calls (what a captured training step does)."""
 
-    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True):
+    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="bricked"):
         self.lib = _lib.load()
         self.vol, self.src, self.dirs = vol, src, dirs
+        self.layout = {"canonical": 0, "bricked": 1}[layout]
         self.P, self.R = dirs.shape[0], dirs.shape[1]
         self.S, self.start, self.alpha = S, start, alpha
         self.sampler = {"nearest": 0, "trilinear": 1}[sampler]
@@ -59,14 +60,25 @@ class HotPath:
         N1 = S - start
         self.frame = torch.empty((self.P, self.R, N1), dtype=torch.float32, device=dev)
         self.gframe = torch.empty_like(self.frame)
-        self.gvol = torch.zeros_like(vol) if want_gvol else None
+        d0, d1, d2 = vol.shape
+        self.gvol = torch.empty_like(vol) if want_gvol else None       # canonical gradient, what the caller gets
+        if self.layout == 1:
+            # HBM-resident bricked copy of the (constant) volume, made once outside the timed region;
+            # the bricked gradient scratch is zeroed, filled and converted back EVERY step.
+            nb = self.lib.diffus_bricked_floats(d0, d1, d2)
+            self.vol_k = torch.empty(nb, dtype=torch.float32, device=dev)
+            _lib.check(self.lib.diffus_brick_volume(C.c_void_p(vol.data_ptr()), d0, d1, d2,
+                                                    C.c_void_p(self.vol_k.data_ptr()), self.stream()), "brick")
+            self.gvol_k = torch.empty(nb, dtype=torch.float32, device=dev) if want_gvol else None
+        else:
+            self.vol_k, self.gvol_k = vol, self.gvol
         self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
         self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
         nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, S, start), 256)
         self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        d0, d1, d2 = vol.shape
-        self.common = (C.c_void_p(vol.data_ptr()), d0, d1, d2, C.c_void_p(src.data_ptr()), 0,
+        self.dims = (d0, d1, d2)
+        self.common = (C.c_void_p(self.vol_k.data_ptr()), d0, d1, d2, self.layout, C.c_void_p(src.data_ptr()), 0,
                        C.c_void_p(dirs.data_ptr()), 0, self.P, self.R, S, start, float(alpha), self.sampler)
 
     def stream(self):
@@ -79,7 +91,7 @@ class HotPath:
 
     def bwd(self):
         rc = self.lib.diffus_render_bwd(*self.common, C.c_void_p(self.gframe.data_ptr()),
-                                        C.c_void_p(self.gvol.data_ptr()) if self.gvol is not None else None,
+                                        C.c_void_p(self.gvol_k.data_ptr()) if self.gvol_k is not None else None,
                                         C.c_void_p(self.gsrc.data_ptr()), C.c_void_p(self.gdirs.data_ptr()),
                                         C.c_void_p(self.ws.data_ptr()), self.ws.numel(), self.stream())
         _lib.check(rc, "diffus_render_bwd")
@@ -89,12 +101,23 @@ class HotPath:
         torch.mul(self.frame, 2.0, out=self.gframe)
         torch.sum(self.frame * self.frame, dim=(1, 2), out=self.loss)
 
+    def zero_grad(self):
+        if self.gvol_k is not None:
+            self.gvol_k.zero_()
+
+    def finish_grad(self):
+        """bricked gradient -> the caller's canonical (d0,d1,d2) tensor."""
+        if self.layout == 1 and self.gvol is not None:
+            rc = self.lib.diffus_unbrick_volume(C.c_void_p(self.gvol_k.data_ptr()), *self.dims,
+                                                C.c_void_p(self.gvol.data_ptr()), 0, self.stream())
+            _lib.check(rc, "diffus_unbrick_volume")
+
     def step(self):
         self.fwd()
         self.loss_and_grad()
-        if self.gvol is not None:
-            self.gvol.zero_()
+        self.zero_grad()
         self.bwd()
+        self.finish_grad()
 
 
 def time_events(fn, iters):
@@ -157,6 +180,7 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="volume edge")
     ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
     ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
+    ap.add_argument("--layout", default="bricked", choices=["bricked", "canonical"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alpha", type=float, default=1e-4)
     args = ap.parse_args()
@@ -183,7 +207,8 @@ def main():
     lo = rank * args.poses
     src = torch.from_numpy(src_all[lo:lo + args.poses]).to(dev).contiguous()
     dirs = torch.from_numpy(dirs_all[lo:lo + args.poses]).to(dev).contiguous()
-    hp = HotPath(vol, src, dirs, args.samples, args.alpha, args.sampler, want_gvol=not args.no_gvol)
+    hp = HotPath(vol, src, dirs, args.samples, args.alpha, args.sampler, want_gvol=not args.no_gvol,
+                 layout=args.layout)
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
 
     def step():
@@ -225,7 +250,7 @@ def main():
 
     # single-pose latency (BASELINE config 2): 1 pose, fwd + bwd
     hp1 = HotPath(vol, src[:1].contiguous(), dirs[:1].contiguous(), args.samples, args.alpha, args.sampler,
-                  want_gvol=not args.no_gvol)
+                  want_gvol=not args.no_gvol, layout=args.layout)
     for _ in range(5):
         hp1.step()
     sp = time_events(hp1.step, 20)
@@ -251,6 +276,7 @@ def main():
                              f"+ per-pose loss gather"),
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": 0, "alpha": args.alpha,
+                "layout": args.layout,
                 "parallelism": f"poses sharded x{ngpu}, volume replicated",
             },
             "roofline": {

@@ -5,8 +5,9 @@ of gduguey/DiffUS on that path.
 """
 from ._lib import DiffusError, LIB_PATH  # noqa: F401
 from .cone import fan_directions_torch, generate_cone_directions  # noqa: F401
-from .renderer import (UltrasoundRenderer, compute_echo_traces, render_poses, resolve_start,  # noqa: F401
-                       trace_rays)
+from .renderer import (BrickedVolume, UltrasoundRenderer, brick_volume, compute_echo_traces,  # noqa: F401
+                       render_poses, resolve_start, trace_rays, unbrick_volume)
 
 __all__ = ["UltrasoundRenderer", "compute_echo_traces", "render_poses", "trace_rays", "resolve_start",
-           "generate_cone_directions", "fan_directions_torch", "DiffusError"]
+           "generate_cone_directions", "fan_directions_torch", "DiffusError", "BrickedVolume", "brick_volume",
+           "unbrick_volume"]

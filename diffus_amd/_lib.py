@@ -9,13 +9,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiffus_hip.so")
+LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so")
 
 EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
+           "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
+CANONICAL, BRICKED = 0, 1
 MAX_SAMPLES = 1024
 
 _lib = None
@@ -41,13 +43,19 @@ def load():
     lib.diffus_strerror.argtypes = [i]
     lib.diffus_workspace_bytes.restype = sz
     lib.diffus_workspace_bytes.argtypes = [i, i, i, i]
-    common = [vp, i, i, i, vp, i, vp, i, i, i, i, i, f, i]
+    common = [vp, i, i, i, i, vp, i, vp, i, i, i, i, i, f, i]
     lib.diffus_render_fwd.restype = i
     lib.diffus_render_fwd.argtypes = common + [vp, vp, vp, sz, vp]
     lib.diffus_render_bwd.restype = i
     lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, vp, sz, vp]
     lib.diffus_trace_rays.restype = i
-    lib.diffus_trace_rays.argtypes = [vp, i, i, i, vp, i, vp, i, i, i, i, i, vp, vp, vp, vp]
+    lib.diffus_trace_rays.argtypes = [vp, i, i, i, i, vp, i, vp, i, i, i, i, i, vp, vp, vp, vp]
+    lib.diffus_bricked_floats.restype = sz
+    lib.diffus_bricked_floats.argtypes = [i, i, i]
+    lib.diffus_brick_volume.restype = i
+    lib.diffus_brick_volume.argtypes = [vp, i, i, i, vp, vp]
+    lib.diffus_unbrick_volume.restype = i
+    lib.diffus_unbrick_volume.argtypes = [vp, i, i, i, vp, i, vp]
     lib.diffus_echo_traces.restype = i
     lib.diffus_echo_traces.argtypes = [vp, i, i, vp, vp]
     if lib.diffus_abi_version() != 1:

@@ -12,11 +12,19 @@
 //     its exclusive prefix.  No A matrix, no LU, no global scratch;
 //   * backward recomputes the forward in-kernel and runs the adjoint recursion
 //      as a reverse affine scan over the same lanes;
+//   * memory is touched in an INTERLEAVED lane mapping (consecutive lanes =
+//     consecutive steps) and the scan runs in a CHUNKED one; a per-wave LDS
+//     buffer transposes between them;
+//   * the volume (and its gradient) can live in a BRICKED layout: 4x4x2-voxel
+//     bricks = one 128-B line, so a fan sheet uses whole lines instead of 8 B of
+//     each; the gradient scatter is privatised in LDS tiles per patch of rays;
 //   * a pose's rays are kept on one XCD (blockIdx remap) so neighbouring rays,
 //     which touch the same voxels near the apex, share that XCD's L2.
 // This is gather/accumulate work: HBM/L2-bound, no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "diffus_hip.h"
 
@@ -171,6 +179,33 @@ __device__ __forceinline__ int nearest_index(float p, int dim)
     return (int)r;
 }
 
+// ----------------------------------------------------------------------------
+// Volume layouts.
+//   CANONICAL: the caller's (d0,d1,d2) row-major tensor, dim 2 contiguous.
+//   BRICKED:   4x4x2-voxel bricks of 32 floats = one 128-B cache line, bricks in
+//              row-major order over (ceil(d0/4), ceil(d1/4), ceil(d2/2)).  Every
+//              demo fan lies in a plane of constant dim-2 (reference src/cone.py:258):
+//              in the canonical layout each sample then uses 8 bytes of every
+//              128-B line it touches; in a brick the same sheet uses the whole line,
+//              and neighbouring steps/rays land in the same line.
+constexpr int kBrickFloats = 32;
+
+struct Geom {
+    int d0, d1, d2;
+    int nb1, nb2; // bricks along dim 1 / dim 2
+};
+
+template <int LAYOUT>
+__device__ __forceinline__ long vox_off(const Geom &G, int x, int y, int z)
+{
+    if (LAYOUT == DIFFUS_CANONICAL) {
+        return ((long)x * G.d1 + y) * G.d2 + z;
+    } else {
+        long brick = ((long)(x >> 2) * G.nb1 + (y >> 2)) * G.nb2 + (z >> 1);
+        return brick * kBrickFloats + (((x & 3) << 3) | ((y & 3) << 1) | (z & 1));
+    }
+}
+
 struct Axis {
     int i0, i1;
     float t, m;
@@ -181,7 +216,7 @@ __device__ __forceinline__ Axis tri_axis(float p, int dim)
     float hi = (float)(dim - 1);
     a.m = (p > 0.f && p < hi) ? 1.f : 0.f;
     float pc = p;
-    if (!(pc > 0.f)) pc = 0.f;
+    if (!(pc > 0.f)) pc = 0.f; // also catches NaN
     if (pc > hi) pc = hi;
     float f = floorf(pc);
     a.i0 = (int)f;
@@ -194,18 +229,32 @@ struct __attribute__((packed, aligned(4))) F2 {
     float x, y;
 };
 
-// the two dim-2 neighbours of one (i,j) row in ONE 8-byte load (they share a
-// cache line 31 times out of 32): halves the vector-memory instructions and
+// The two dim-2 neighbours of one (x,y) column.  Where they are adjacent in
+// memory they come in ONE 8-byte load: half the vector-memory instructions and
 // L1 tag lookups of the 8-corner gather.
-__device__ __forceinline__ void load_zpair(const float *__restrict__ row, const Axis &c, int d2, float &lo, float &hi)
+template <int LAYOUT>
+__device__ __forceinline__ void load_zpair(const float *__restrict__ vol, const Geom &G, int x, int y, const Axis &c,
+                                           float &lo, float &hi)
 {
-    if (d2 >= 2) {
-        int b = min(c.i0, d2 - 2);
-        F2 v = *reinterpret_cast<const F2 *>(row + b);
-        lo = (c.i0 == b) ? v.x : v.y;
-        hi = v.y;
+    if (LAYOUT == DIFFUS_CANONICAL) {
+        const float *row = vol + ((long)x * G.d1 + y) * G.d2;
+        if (G.d2 >= 2) {
+            int b = min(c.i0, G.d2 - 2);
+            F2 v = *reinterpret_cast<const F2 *>(row + b);
+            lo = (c.i0 == b) ? v.x : v.y;
+            hi = v.y;
+        } else {
+            lo = hi = row[0];
+        }
     } else {
-        lo = hi = row[0];
+        if (!(c.i0 & 1) && c.i1 == c.i0 + 1) { // same brick, 8-byte aligned pair
+            float2 v = *reinterpret_cast<const float2 *>(vol + vox_off<LAYOUT>(G, x, y, c.i0));
+            lo = v.x;
+            hi = v.y;
+        } else {
+            lo = vol[vox_off<LAYOUT>(G, x, y, c.i0)];
+            hi = vol[vox_off<LAYOUT>(G, x, y, c.i1)];
+        }
     }
 }
 
@@ -216,21 +265,16 @@ struct TriSample {
 
 // Trilinear sample at p; lerp order dim 2, dim 1, dim 0, each a + t*(b-a) --
 // the exact sequence of oracle/diffus_oracle.c orc_sample_trilinear.
-template <bool GRAD>
-__device__ __forceinline__ TriSample tri_sample(const float *__restrict__ vol, int d0, int d1, int d2, float p0,
-                                                float p1, float p2)
+template <int LAYOUT, bool GRAD>
+__device__ __forceinline__ TriSample tri_sample(const float *__restrict__ vol, const Geom &G, float p0, float p1,
+                                                float p2)
 {
-    Axis a = tri_axis(p0, d0), b = tri_axis(p1, d1), c = tri_axis(p2, d2);
-    const long s0 = (long)d1 * d2;
-    const float *r00 = vol + a.i0 * s0 + (long)b.i0 * d2;
-    const float *r01 = vol + a.i0 * s0 + (long)b.i1 * d2;
-    const float *r10 = vol + a.i1 * s0 + (long)b.i0 * d2;
-    const float *r11 = vol + a.i1 * s0 + (long)b.i1 * d2;
+    Axis a = tri_axis(p0, G.d0), b = tri_axis(p1, G.d1), c = tri_axis(p2, G.d2);
     float v000, v001, v010, v011, v100, v101, v110, v111;
-    load_zpair(r00, c, d2, v000, v001);
-    load_zpair(r01, c, d2, v010, v011);
-    load_zpair(r10, c, d2, v100, v101);
-    load_zpair(r11, c, d2, v110, v111);
+    load_zpair<LAYOUT>(vol, G, a.i0, b.i0, c, v000, v001);
+    load_zpair<LAYOUT>(vol, G, a.i0, b.i1, c, v010, v011);
+    load_zpair<LAYOUT>(vol, G, a.i1, b.i0, c, v100, v101);
+    load_zpair<LAYOUT>(vol, G, a.i1, b.i1, c, v110, v111);
     float e00 = v001 - v000, e01 = v011 - v010, e10 = v101 - v100, e11 = v111 - v110;
     float c00 = __fadd_rn(v000, __fmul_rn(c.t, e00)), c01 = __fadd_rn(v010, __fmul_rn(c.t, e01));
     float c10 = __fadd_rn(v100, __fmul_rn(c.t, e10)), c11 = __fadd_rn(v110, __fmul_rn(c.t, e11));
@@ -251,35 +295,13 @@ __device__ __forceinline__ TriSample tri_sample(const float *__restrict__ vol, i
     return s;
 }
 
-// scatter zb * (trilinear weights) into gvol
-__device__ __forceinline__ void tri_scatter(float *__restrict__ gvol, int d0, int d1, int d2, float p0, float p1,
-                                            float p2, float zb)
-{
-    Axis a = tri_axis(p0, d0), b = tri_axis(p1, d1), c = tri_axis(p2, d2);
-    const long s0 = (long)d1 * d2;
-    float wa1 = a.t, wa0 = 1.f - a.t, wb1 = b.t, wb0 = 1.f - b.t, wc1 = c.t, wc0 = 1.f - c.t;
-    float *r00 = gvol + a.i0 * s0 + (long)b.i0 * d2;
-    float *r01 = gvol + a.i0 * s0 + (long)b.i1 * d2;
-    float *r10 = gvol + a.i1 * s0 + (long)b.i0 * d2;
-    float *r11 = gvol + a.i1 * s0 + (long)b.i1 * d2;
-    float w00 = zb * wa0 * wb0, w01 = zb * wa0 * wb1, w10 = zb * wa1 * wb0, w11 = zb * wa1 * wb1;
-    atomicAdd(r00 + c.i0, w00 * wc0);
-    atomicAdd(r00 + c.i1, w00 * wc1);
-    atomicAdd(r01 + c.i0, w01 * wc0);
-    atomicAdd(r01 + c.i1, w01 * wc1);
-    atomicAdd(r10 + c.i0, w10 * wc0);
-    atomicAdd(r10 + c.i1, w10 * wc1);
-    atomicAdd(r11 + c.i0, w11 * wc0);
-    atomicAdd(r11 + c.i1, w11 * wc1);
-}
-
 // reflection coefficient (reference src/renderer.py:33): IEEE f32 sub, add, div
 __device__ __forceinline__ float reflect(float z1, float z2) { return __fdiv_rn(z2 - z1, z1 + z2); }
 
 // ----------------------------------------------------------------------------
 struct Args {
     const float *vol;
-    int d0, d1, d2;
+    Geom G;
     const void *src;
     const void *dirs;
     int src_f64, dir_f64;
@@ -290,7 +312,7 @@ struct Args {
     long long *idx;
     // backward
     const float *gframe;
-    float *gvol;
+    float *gvol;      // same layout as vol
     float *zbar;      // (P,R,N1) d L / d imp per sample, consumed by scatter_patch_kernel
     float *gsrc_part; // (P,R,3) per-ray partials of d/d source
     float *gdirs;
@@ -310,25 +332,79 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     return base + (b >> 3);
 }
 
-// Samples of this lane's chunk: impedance (and, for the trilinear backward, the
-// spatial gradient).  n >= N1 yields a harmless dummy.
-template <int C, int SAMPLER, bool GRAD>
-__device__ __forceinline__ void gather_chunk(const Args &A, const Pose &ps, int n0, float (&z)[C], float (&g0)[C],
-                                             float (&g1)[C], float (&g2)[C])
+// ----------------------------------------------------------------------------
+// Two lane <-> sample mappings of one ray's N1 samples over a wave:
+//   INTERLEAVED  sample n = j*64 + lane   -- consecutive lanes = consecutive steps:
+//                used for everything that touches memory (gathers land in the
+//                same bricks / lines, frame & gradient rows are read and written
+//                as 256-B runs);
+//   CHUNKED      sample n = lane*C + j    -- a lane owns C consecutive samples:
+//                used for the scan (15 serial 2x2 products + 6 shuffle rounds
+//                instead of 8 x 6 shuffle rounds).
+// A per-wave LDS buffer of 64*C floats converts between the two.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int C>
+__device__ __forceinline__ void to_chunked(float *wb, int lane, const float (&in)[C], float (&out)[C])
+{
+#pragma unroll
+    for (int j = 0; j < C; ++j) wb[j * kWave + lane] = in[j];
+    wave_lds_sync();
+    if (C >= 4) {
+        const float4 *q = reinterpret_cast<const float4 *>(wb + lane * C);
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) {
+            float4 v = q[j];
+            out[4 * j] = v.x; out[4 * j + 1] = v.y; out[4 * j + 2] = v.z; out[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) out[j] = wb[lane * C + j];
+    }
+    wave_lds_sync();
+}
+
+template <int C>
+__device__ __forceinline__ void to_interleaved(float *wb, int lane, const float (&in)[C], float (&out)[C])
+{
+    if (C >= 4) {
+        float4 *q = reinterpret_cast<float4 *>(wb + lane * C);
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) q[j] = make_float4(in[4 * j], in[4 * j + 1], in[4 * j + 2], in[4 * j + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) wb[lane * C + j] = in[j];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < C; ++j) out[j] = wb[j * kWave + lane];
+    wave_lds_sync();
+}
+
+// Impedance (and for the trilinear backward its spatial gradient) at the wave's
+// samples, INTERLEAVED mapping.  n >= N1 yields a harmless dummy.
+template <int C, int SAMPLER, int LAYOUT, bool GRAD>
+__device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps, int lane, float (&z)[C],
+                                                   float (&g0)[C], float (&g1)[C], float (&g2)[C])
 {
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
+        int n = j * kWave + lane;
         z[j] = 1.f;
         if (GRAD) g0[j] = g1[j] = g2[j] = 0.f;
         if (n < A.N1) {
             int k = A.start + n;
             float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
             if (SAMPLER == DIFFUS_NEAREST) {
-                int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
-                z[j] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+                int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+                z[j] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
             } else {
-                TriSample s = tri_sample<GRAD>(A.vol, A.d0, A.d1, A.d2, p0, p1, p2);
+                TriSample s = tri_sample<LAYOUT, GRAD>(A.vol, A.G, p0, p1, p2);
                 z[j] = s.v;
                 if (GRAD) {
                     g0[j] = s.g0;
@@ -340,9 +416,10 @@ __device__ __forceinline__ void gather_chunk(const Args &A, const Pose &ps, int 
     }
 }
 
-// r'_{n-1} for the lane's samples: r[j] couples sample n-1 and n (n = n0+j).
-// r = 0 (identity transfer matrix) for n = 0 and n >= N1; with start > 0 the
-// first kept coefficient is replaced by the per-pose median (reference :243-244).
+// r'_{n-1} for the lane's samples (CHUNKED): r[j] couples sample n-1 and n
+// (n = lane*C+j).  r = 0 (identity transfer matrix) for n = 0 and n >= N1; with
+// start > 0 the first kept coefficient is replaced by the per-pose median
+// (reference :243-244).
 template <int C>
 __device__ __forceinline__ void reflect_chunk(const Args &A, int n0, const float (&z)[C], float zprev, float medv,
                                               float (&r)[C])
@@ -392,34 +469,40 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
 
 // ----------------------------------------------------------------------------
 // FORWARD  (replaces reference src/renderer.py:201-275 with artifacts=False)
-template <int C, int SAMPLER>
-__global__ __launch_bounds__(kBlock) void render_fwd_kernel(Args A)
+template <int C, int SAMPLER, int LAYOUT, int WPB>
+__global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
 {
-    const unsigned nblk = gridDim.x;
-    const long w = (long)xcd_remap(blockIdx.x, nblk) * kWavesPerBlock + (threadIdx.x >> 6);
-    if (w >= (long)A.P * A.R) return; // wave-uniform
+    __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
+    const int wib = threadIdx.x >> 6;
+    const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
+    if (w >= (long)A.P * A.R) return; // wave-uniform; no block-level barrier below
     const int lane = threadIdx.x & 63;
     const long pose = w / A.R;
     const int n0 = lane * C;
+    float *wb = lds[wib];
 
     Pose ps;
     load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
-    float z[C], r[C], u0[C], u1[C], u2[C];
-    gather_chunk<C, SAMPLER, false>(A, ps, n0, z, u0, u1, u2);
+    float zi[C], z[C], r[C], e[C], u0[C], u1[C], u2[C];
+    gather_interleaved<C, SAMPLER, LAYOUT, false>(A, ps, lane, zi, u0, u1, u2);
+    to_chunked<C>(wb, lane, zi, z);
     float zprev = __shfl_up(z[C - 1], 1, kWave);
     float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, n0, z, zprev, medv, r);
-
-    float e[C];
     echo_chunk<C>(r, lane, e);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        // attenuation, reference :256-259: f32(-alpha) * f32(n), expf, multiply
+        float att = expf(__fmul_rn(A.neg_alpha, (float)(n0 + j)));
+        e[j] = __fmul_rn(e[j], att);
+    }
+    to_interleaved<C>(wb, lane, e, zi);
     float *out = A.frame + w * A.N1;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
-        // attenuation, reference :256-259: f32(-alpha) * f32(n), expf, multiply
-        float att = expf(__fmul_rn(A.neg_alpha, (float)n));
-        if (n < A.N1) out[n] = __fmul_rn(e[j], att);
+        int n = j * kWave + lane;
+        if (n < A.N1) out[n] = zi[j];
     }
 
     if (A.idx) {
@@ -427,12 +510,12 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(Args A)
         long long *ix = A.idx + w * A.N1;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            int n = n0 + j;
+            int n = j * kWave + lane;
             if (n < A.N1) {
                 int k = A.start + n;
-                ix[n] = nearest_index(ray_point(ps, 0, k), A.d0);
-                ix[plane + n] = nearest_index(ray_point(ps, 1, k), A.d1);
-                ix[2 * plane + n] = nearest_index(ray_point(ps, 2, k), A.d2);
+                ix[n] = nearest_index(ray_point(ps, 0, k), A.G.d0);
+                ix[plane + n] = nearest_index(ray_point(ps, 1, k), A.G.d1);
+                ix[2 * plane + n] = nearest_index(ray_point(ps, 2, k), A.G.d2);
             }
         }
     }
@@ -448,21 +531,35 @@ __global__ __launch_bounds__(kBlock) void render_fwd_kernel(Args A)
 // W_n = 2^{e_n-e_{n-1}} (Gbar'_n + U'_n):  Tbar_n = P'_{n-1}^T W_n,  U'_{n-1} = W_n T_n^T.
 // The chunk of one lane is an affine map U_in -> U_out; lanes are combined with a
 // reverse Hillis-Steele scan of affine maps (A, B, beta):  X -> A + X (B 2^beta)^T.
-template <int C, int SAMPLER, bool GPOSE>
-__global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
+template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB>
+__global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
 {
-    const unsigned nblk = gridDim.x;
-    const long w = (long)xcd_remap(blockIdx.x, nblk) * kWavesPerBlock + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
+    constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 48 more registers
+    const int wib = threadIdx.x >> 6;
+    const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
     if (w >= (long)A.P * A.R) return;
     const int lane = threadIdx.x & 63;
     const long pose = w / A.R;
     const int n0 = lane * C;
+    float *wb = lds[wib];
 
     Pose ps;
     load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
-    float z[C], r[C], gp0[C], gp1[C], gp2[C];
-    gather_chunk<C, SAMPLER, GPOSE>(A, ps, n0, z, gp0, gp1, gp2);
+    float zi[C], gi0[C], gi1[C], gi2[C], z[C], r[C], gb[C];
+    gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD>(A, ps, lane, zi, gi0, gi1, gi2);
+    to_chunked<C>(wb, lane, zi, z);
+    {
+        // upstream gradient row, read as 256-B runs, attenuation folded in
+        const float *gin = A.gframe + w * A.N1;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = j * kWave + lane;
+            zi[j] = (n < A.N1) ? gin[n] * expf(__fmul_rn(A.neg_alpha, (float)n)) : 0.f;
+        }
+        to_chunked<C>(wb, lane, zi, gb);
+    }
     const float zprev = __shfl_up(z[C - 1], 1, kWave);
     const float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, n0, z, zprev, medv, r);
@@ -498,26 +595,19 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
     int ex[C];   // renorm exponent of step n
     float gu[C]; // gbar_n / d'_n
     float rho[C];
-    const float *gin = A.gframe + w * A.N1;
     int esum = 0;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
         Pin[j] = Pm;
         Pm = mat_step(Pm, r[j]);
         ex[j] = mat_renorm(Pm);
         esum += ex[j];
         float e = __fdiv_rn(Pm.b, Pm.d);
-        float gb = 0.f;
-        if (n < A.N1 && e == e) gb = gin[n] * expf(__fmul_rn(A.neg_alpha, (float)n));
-        float q = __fdiv_rn(gb, Pm.d);
-        gu[j] = (gb != 0.f) ? q : 0.f;
+        float g = (e == e) ? gb[j] : 0.f; // echoes zeroed by nan_to_num are constants
+        float q = __fdiv_rn(g, Pm.d);
+        gu[j] = (g != 0.f) ? q : 0.f;
         rho[j] = (e == e) ? e : 0.f;
-    }
-    // sanitise: past a NaN reflection coefficient every echo is a constant 0, so
-    // nothing flows back through those steps.
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
+        // past a non-finite reflection coefficient every echo is the constant 0
         if (!finitef(r[j]) || !mat_finite(Pin[j]) || !finitef(gu[j]) || !finitef(rho[j])) gu[j] = 0.f;
     }
 
@@ -538,8 +628,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
             W = mat_scale(W, -ex[j]);
             if (rbar) {
                 Mat Tb = mat_mul_at(Pin[j], W);
-                float v = __builtin_fmaf(-4.f * r[j], Tb.a, Tb.b - Tb.c);
-                rbar[j] = v;
+                rbar[j] = __builtin_fmaf(-4.f * r[j], Tb.a, Tb.b - Tb.c);
             }
             float rr = finitef(r[j]) ? r[j] : 0.f; // non-finite step: cut the chain (U is zero there anyway)
             U = mat_mul_bt(W, mat_of_r(rr));
@@ -547,10 +636,9 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
         return U;
     };
     Mat Aacc = sweep(Mat{0.f, 0.f, 0.f, 0.f}, nullptr);
-    Mat Bn = Lloc;                       // normalised linear part
-    int beta = delta - esum - lamloc;    // B = Bn * 2^beta
-    // NaN-proof the linear part (a NaN chunk passes nothing)
-    if (!mat_finite(Bn)) Bn = Mat{0.f, 0.f, 0.f, 0.f};
+    Mat Bn = Lloc;                    // normalised linear part
+    int beta = delta - esum - lamloc; // B = Bn * 2^beta
+    if (!mat_finite(Bn)) Bn = Mat{0.f, 0.f, 0.f, 0.f}; // a non-finite chunk passes nothing
 
     // ---- reverse inclusive scan of affine maps: G_l = F_l o F_{l+1} o ... o F_63 ----
 #pragma unroll
@@ -590,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
         float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
         float s = zp + z[j];
         float inv = __fdiv_rn(1.f, s);
-        float dz = 2.f * zp * inv * inv;    // d r / d Z_n
+        float dz = 2.f * zp * inv * inv;     // d r / d Z_n
         float dzp = -2.f * z[j] * inv * inv; // d r / d Z_{n-1}
         float c1 = rb * dz, c0 = rb * dzp;
         if (!finitef(c1)) c1 = 0.f;
@@ -605,32 +693,42 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
     if (lane != kWave - 1) zbar[C - 1] += cin;
     if (gmed_lane != 0.f) atomicAdd(&A.gmed[pose], gmed_lane);
 
-    // ---- hand d L / d imp to the scatter kernel, reduce the pose gradient ----
+    // ---- back to INTERLEAVED: hand zbar to the scatter kernel, reduce the pose gradient ----
     // The volume scatter is a separate launch (scatter_patch_kernel): its thread <-> sample
     // mapping is chosen for LDS privatisation, not for the scan.
+    to_interleaved<C>(wb, lane, zbar, zi);
     if (A.zbar) {
         float *zo = A.zbar + w * A.N1;
 #pragma unroll
-        for (int j = 0; j < C; ++j)
-            if (n0 + j < A.N1) zo[n0 + j] = zbar[j];
+        for (int j = 0; j < C; ++j) {
+            int n = j * kWave + lane;
+            if (n < A.N1) zo[n] = zi[j];
+        }
     }
-    float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
     if (GPOSE) {
+        float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            int n = n0 + j;
-            float zb = zbar[j];
+            int n = j * kWave + lane;
+            float zb = zi[j];
             if (n < A.N1 && zb != 0.f) {
-                float kf = (float)(A.start + n);
-                float a0 = zb * gp0[j], a1 = zb * gp1[j], a2 = zb * gp2[j];
+                int k = A.start + n;
+                float q0, q1, q2;
+                if (KEEP_GRAD) {
+                    q0 = gi0[j]; q1 = gi1[j]; q2 = gi2[j];
+                } else {
+                    TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point(ps, 0, k), ray_point(ps, 1, k),
+                                                           ray_point(ps, 2, k));
+                    q0 = s.g0; q1 = s.g1; q2 = s.g2;
+                }
+                float kf = (float)k;
+                float a0 = zb * q0, a1 = zb * q1, a2 = zb * q2;
                 gs0 += a0; gs1 += a1; gs2 += a2;
                 gd0 = __builtin_fmaf(kf, a0, gd0);
                 gd1 = __builtin_fmaf(kf, a1, gd1);
                 gd2 = __builtin_fmaf(kf, a2, gd2);
             }
         }
-    }
-    if (GPOSE) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             gs0 += __shfl_xor(gs0, off, kWave);
@@ -659,14 +757,25 @@ __global__ __launch_bounds__(kBlock) void render_bwd_kernel(Args A)
 // VOLUME SCATTER.  gvol += sum over samples of zbar * (interpolation weights).
 // Naive per-sample global float atomics run ~10x below even the scattered-atomic
 // rate because every fan hammers the few hundred voxels around its apex
-// (measured: 17.5 ms for 33 M atomics).  Instead a block takes a PATCH of
-// kPatchRays adjacent rays x kPatchSteps consecutive steps of one pose, whose
+// (measured: 17.5 ms for 33 M atomics at config 3).  Instead a block takes a PATCH
+// of kPatchRays adjacent rays x kPatchSteps consecutive steps of one pose, whose
 // footprint is a small box of voxels; it accumulates the patch into an LDS tile
-// covering that box (ds_add_f32) and flushes each touched voxel ONCE.  Patches
-// whose box does not fit the tile fall back to direct global atomics.
-constexpr int kPatchRays = 16;
-constexpr int kPatchSteps = 64;
-constexpr int kTileCap = 12 * 1024; // floats (48 KiB): 3 blocks per CU
+// covering that box (ds_add_f32) and flushes each touched voxel ONCE.  In the
+// bricked layout the tile is a box of whole bricks, so the flush is made of
+// 128-B contiguous atomic runs (the full-rate shape of global_atomic_add_f32).
+// Patches whose box does not fit the tile fall back to direct global atomics.
+#ifndef DIFFUS_PATCH_RAYS
+#define DIFFUS_PATCH_RAYS 16
+#endif
+#ifndef DIFFUS_PATCH_STEPS
+#define DIFFUS_PATCH_STEPS 64
+#endif
+#ifndef DIFFUS_TILE_CAP
+#define DIFFUS_TILE_CAP (12 * 1024)
+#endif
+constexpr int kPatchRays = DIFFUS_PATCH_RAYS;
+constexpr int kPatchSteps = DIFFUS_PATCH_STEPS;
+constexpr int kTileCap = DIFFUS_TILE_CAP; // floats (48 KiB: 3 blocks per CU)
 constexpr int kSamplesPerThread = kPatchRays * kPatchSteps / kBlock; // 4
 
 struct Cell {
@@ -678,7 +787,7 @@ template <int SAMPLER>
 __device__ __forceinline__ Cell cell_of(const Args &A, const Pose &ps, int k)
 {
     Cell c;
-    const int dims[3] = {A.d0, A.d1, A.d2};
+    const int dims[3] = {A.G.d0, A.G.d1, A.G.d2};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float p = ray_point(ps, a, k);
@@ -714,17 +823,32 @@ __device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
     }
 }
 
-template <int SAMPLER>
+// tile units: voxels (canonical) or bricks (bricked)
+template <int LAYOUT>
+__device__ __forceinline__ int tile_unit(int v, int axis)
+{
+    if (LAYOUT == DIFFUS_CANONICAL) return v;
+    return axis == 2 ? (v >> 1) : (v >> 2);
+}
+
+template <int SAMPLER, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_groups, int step_groups)
 {
-    __shared__ float tile[kTileCap];
-    __shared__ int s_lo[3], s_hi[3];
+    // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
+    // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
+    // The tile therefore accumulates in 32-bit FIXED POINT with a per-patch power-of-two
+    // scale 2^fx chosen so that even all 1024 samples landing on one voxel cannot
+    // overflow: max|zbar| * 2^fx < 2^20.  Quantum = 2^-20 of the patch's largest
+    // contribution; integer adds commute, so a tile sum is bitwise reproducible.
+    __shared__ int tile[kTileCap];
+    __shared__ int s_lo[3], s_hi[3], s_max;
+    constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
 
     // patch -> (pose, ray group, step group); the XCD remap keeps a pose on one XCD
-    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int sg = L % step_groups;
-    const int rg = (L / step_groups) % ray_groups;
-    const int pose = L / (step_groups * ray_groups);
+    const unsigned Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int sg = Lb % step_groups;
+    const int rg = (Lb / step_groups) % ray_groups;
+    const int pose = Lb / (step_groups * ray_groups);
     const int tid = threadIdx.x;
     // thread -> ray (tid / 16) and 4 consecutive steps ((tid % 16) * 4 ..)
     const int ray = rg * kPatchRays + tid / (kPatchSteps / kSamplesPerThread);
@@ -736,11 +860,13 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         s_lo[tid] = 0x7fffffff;
         s_hi[tid] = -1;
     }
+    if (tid == 3) s_max = 0;
     Pose ps;
     load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     Cell cells[kSamplesPerThread];
     float zb[kSamplesPerThread];
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    float zmax = 0.f;
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) {
         int n = nbase + q;
@@ -748,11 +874,12 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         if (ray_ok && n < A.N1) zb[q] = A.zbar[w * A.N1 + n];
         if (!finitef(zb[q])) zb[q] = 0.f;
         cells[q] = cell_of<SAMPLER>(A, ps, A.start + n);
+        zmax = fmaxf(zmax, fabsf(zb[q]));
         if (zb[q] != 0.f) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                lo[a] = min(lo[a], cells[q].i0[a]);
-                hi[a] = max(hi[a], cells[q].i1[a]);
+                lo[a] = min(lo[a], tile_unit<LAYOUT>(cells[q].i0[a], a));
+                hi[a] = max(hi[a], tile_unit<LAYOUT>(cells[q].i1[a], a));
             }
         }
     }
@@ -765,6 +892,8 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
             hi[a] = max(hi[a], __shfl_xor(hi[a], off, kWave));
         }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off, kWave));
     __syncthreads();
     if ((tid & 63) == 0) {
 #pragma unroll
@@ -772,40 +901,53 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
             atomicMin(&s_lo[a], lo[a]);
             atomicMax(&s_hi[a], hi[a]);
         }
+        atomicMax(&s_max, __float_as_int(zmax)); // non-negative floats order like their bit patterns
     }
     __syncthreads();
     const int l0 = s_lo[0], l1 = s_lo[1], l2 = s_lo[2];
     if (s_hi[0] < 0) return; // nothing to add in this patch (block-uniform)
     const int b0 = s_hi[0] - l0 + 1, b1 = s_hi[1] - l1 + 1, b2 = s_hi[2] - l2 + 1;
-    const long vol_tile = (long)b0 * b1 * b2;
-    const long s0 = (long)A.d1 * A.d2;
+    const long vol_tile = (long)b0 * b1 * b2 * UNIT;
 
     if (vol_tile > kTileCap) { // block-uniform fallback: direct atomics
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q)
             if (zb[q] != 0.f)
                 for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
-                    if (v != 0.f) atomicAdd(A.gvol + i * s0 + (long)j * A.d2 + k, v);
+                    if (v != 0.f) atomicAdd(A.gvol + vox_off<LAYOUT>(A.G, i, j, k), v);
                 });
         return;
     }
     const int nt = (int)vol_tile;
-    for (int e = tid; e < nt; e += kBlock) tile[e] = 0.f;
+    const int fx = 20 - __builtin_amdgcn_frexp_expf(__int_as_float(s_max)); // max|zbar| * 2^fx in [2^19, 2^20)
+    for (int e = tid; e < nt; e += kBlock) tile[e] = 0;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q)
         if (zb[q] != 0.f)
             for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
-                atomicAdd(&tile[((i - l0) * b1 + (j - l1)) * b2 + (k - l2)], v);
+                int e;
+                if (LAYOUT == DIFFUS_CANONICAL)
+                    e = ((i - l0) * b1 + (j - l1)) * b2 + (k - l2);
+                else
+                    e = ((((i >> 2) - l0) * b1 + ((j >> 2) - l1)) * b2 + ((k >> 1) - l2)) * kBrickFloats +
+                        (((i & 3) << 3) | ((j & 3) << 1) | (k & 1));
+                atomicAdd(&tile[e], __float2int_rn(ldexpf(v, fx)));
             });
     __syncthreads();
     const int b12 = b1 * b2;
     for (int e = tid; e < nt; e += kBlock) {
-        float v = tile[e];
-        if (v != 0.f) {
-            int i = e / b12, rem = e - i * b12;
+        int v = tile[e];
+        if (v != 0) {
+            int u = e / UNIT, o = e - u * UNIT;
+            int i = u / b12, rem = u - i * b12;
             int j = rem / b2, k = rem - j * b2;
-            atomicAdd(A.gvol + (l0 + i) * s0 + (long)(l1 + j) * A.d2 + (l2 + k), v);
+            long g;
+            if (LAYOUT == DIFFUS_CANONICAL)
+                g = ((long)(l0 + i) * A.G.d1 + (l1 + j)) * A.G.d2 + (l2 + k);
+            else
+                g = (((long)(l0 + i) * A.G.nb1 + (l1 + j)) * A.G.nb2 + (l2 + k)) * kBrickFloats + o;
+            atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
         }
     }
 }
@@ -813,7 +955,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
 // ----------------------------------------------------------------------------
 // start > 0: median over rays of r[:, start] (reference :243), one block per pose.
 // Lower median like torch.median; NaN if any NaN.  Also zeroes gmed[p].
-template <int SAMPLER>
+template <int SAMPLER, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
 {
     extern __shared__ float vals[];
@@ -829,10 +971,10 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
             int k = A.start + q;
             float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
             if (SAMPLER == DIFFUS_NEAREST) {
-                int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
-                zz[q] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+                int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+                zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
             } else {
-                zz[q] = tri_sample<false>(A.vol, A.d0, A.d1, A.d2, p0, p1, p2).v;
+                zz[q] = tri_sample<LAYOUT, false>(A.vol, A.G, p0, p1, p2).v;
             }
         }
         float v = reflect(zz[0], zz[1]);
@@ -866,28 +1008,27 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
 
 // start > 0, backward: route gmed[p] to the ray that supplied the median
 // (torch.median's backward).  One thread per pose; runs after render_bwd_kernel.
-template <int SAMPLER>
+template <int SAMPLER, int LAYOUT>
 __global__ void median_bwd_kernel(Args A)
 {
     const int pose = blockIdx.x * blockDim.x + threadIdx.x;
     if (pose >= A.P) return;
     const int i = A.who[pose];
     const float gm = A.gmed[pose];
-    if (i < 0 || gm == 0.f || !(fabsf(gm) < __builtin_inff())) return;
+    if (i < 0 || gm == 0.f || !finitef(gm)) return;
     const long w = (long)pose * A.R + i;
     Pose ps;
     load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
-    float zz[2], g0[2], g1[2], g2[2], pp[2][3];
+    float zz[2], g0[2], g1[2], g2[2];
     for (int q = 0; q < 2; ++q) {
         int k = A.start + q;
-        for (int c = 0; c < 3; ++c) pp[q][c] = ray_point(ps, c, k);
+        float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
         if (SAMPLER == DIFFUS_NEAREST) {
-            int i0 = nearest_index(pp[q][0], A.d0), i1 = nearest_index(pp[q][1], A.d1),
-                i2 = nearest_index(pp[q][2], A.d2);
-            zz[q] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+            int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+            zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
             g0[q] = g1[q] = g2[q] = 0.f;
         } else {
-            TriSample s = tri_sample<true>(A.vol, A.d0, A.d1, A.d2, pp[q][0], pp[q][1], pp[q][2]);
+            TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, p0, p1, p2);
             zz[q] = s.v; g0[q] = s.g0; g1[q] = s.g1; g2[q] = s.g2;
         }
     }
@@ -895,16 +1036,13 @@ __global__ void median_bwd_kernel(Args A)
     float inv = __fdiv_rn(1.f, s);
     float zb[2] = {gm * (-2.f * zz[1] * inv * inv), gm * (2.f * zz[0] * inv * inv)};
     for (int q = 0; q < 2; ++q) {
-        if (!(fabsf(zb[q]) < __builtin_inff()) || zb[q] == 0.f) continue;
+        if (!finitef(zb[q]) || zb[q] == 0.f) continue;
         int k = A.start + q;
         if (A.gvol) {
-            if (SAMPLER == DIFFUS_NEAREST) {
-                int i0 = nearest_index(pp[q][0], A.d0), i1 = nearest_index(pp[q][1], A.d1),
-                    i2 = nearest_index(pp[q][2], A.d2);
-                atomicAdd(A.gvol + ((long)i0 * A.d1 + i1) * A.d2 + i2, zb[q]);
-            } else {
-                tri_scatter(A.gvol, A.d0, A.d1, A.d2, pp[q][0], pp[q][1], pp[q][2], zb[q]);
-            }
+            Cell c = cell_of<SAMPLER>(A, ps, k);
+            for_each_corner<SAMPLER>(c, zb[q], [&](int a, int b, int cc, float v) {
+                if (v != 0.f) atomicAdd(A.gvol + vox_off<LAYOUT>(A.G, a, b, cc), v);
+            });
         }
         if (SAMPLER == DIFFUS_TRILINEAR) {
             float kf = (float)k;
@@ -952,7 +1090,7 @@ __global__ __launch_bounds__(kBlock) void reduce_gsrc_kernel(const float *__rest
 
 // trace_ray + custom_nearest_sampler + compute_reflection_coeff
 // (reference src/renderer.py:90-180, :741-759, :27-33, :65-68): one thread per sample.
-template <int SAMPLER>
+template <int SAMPLER, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void trace_rays_kernel(Args A, float *__restrict__ imp, float *__restrict__ refl,
                                                             long long *__restrict__ idx)
 {
@@ -966,16 +1104,16 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(Args A, float *__res
         const int nq = (refl && k + 1 < A.S) ? 2 : 1;
         for (int q = 0; q < nq; ++q) {
             float p0 = ray_point(ps, 0, k + q), p1 = ray_point(ps, 1, k + q), p2 = ray_point(ps, 2, k + q);
-            int i0 = nearest_index(p0, A.d0), i1 = nearest_index(p1, A.d1), i2 = nearest_index(p2, A.d2);
+            int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
             if (q == 0 && idx) {
                 idx[t] = i0;
                 idx[total + t] = i1;
                 idx[2 * total + t] = i2;
             }
             if (SAMPLER == DIFFUS_NEAREST)
-                zz[q] = A.vol[((long)i0 * A.d1 + i1) * A.d2 + i2];
+                zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
             else
-                zz[q] = tri_sample<false>(A.vol, A.d0, A.d1, A.d2, p0, p1, p2).v;
+                zz[q] = tri_sample<LAYOUT, false>(A.vol, A.G, p0, p1, p2).v;
         }
         if (imp) imp[t] = zz[0];
         if (refl && k + 1 < A.S) refl[w * (A.S - 1) + k] = reflect(zz[0], zz[1]);
@@ -1007,8 +1145,68 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
 }
 
 // ----------------------------------------------------------------------------
+// canonical <-> bricked conversion.  A block moves 4 x 4 x 64 voxels (32 bricks,
+// 4 KiB): 16 canonical rows of 256 B on one side, 4 KiB contiguous on the other,
+// through an LDS transpose so that both sides are coalesced.
+constexpr int kConvZ = 64;
+template <bool TO_BRICKED, bool ACCUMULATE>
+__global__ __launch_bounds__(kBlock) void brick_convert_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                               Geom G)
+{
+    __shared__ float t[16][kConvZ + 1];
+    const int bz0 = blockIdx.x * (kConvZ / 2); // first brick along dim 2
+    const int by = blockIdx.y, bx = blockIdx.z;
+    const int tid = threadIdx.x;
+    const long brick0 = ((long)bx * G.nb1 + by) * G.nb2 + bz0;
+    if (TO_BRICKED) {
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int row = e / kConvZ, zz = e - row * kConvZ;
+            int x = bx * 4 + (row >> 2), y = by * 4 + (row & 3), z = bz0 * 2 + zz;
+            t[row][zz] = (x < G.d0 && y < G.d1 && z < G.d2) ? in[((long)x * G.d1 + y) * G.d2 + z] : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int brick = e >> 5, off = e & 31;
+            if (bz0 + brick < G.nb2) out[(brick0 + brick) * kBrickFloats + off] = t[off >> 1][brick * 2 + (off & 1)];
+        }
+    } else {
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int brick = e >> 5, off = e & 31;
+            if (bz0 + brick < G.nb2) t[off >> 1][brick * 2 + (off & 1)] = in[(brick0 + brick) * kBrickFloats + off];
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int row = e / kConvZ, zz = e - row * kConvZ;
+            int x = bx * 4 + (row >> 2), y = by * 4 + (row & 3), z = bz0 * 2 + zz;
+            if (x < G.d0 && y < G.d1 && z < G.d2) {
+                long o = ((long)x * G.d1 + y) * G.d2 + z;
+                if (ACCUMULATE)
+                    out[o] += t[row][zz];
+                else
+                    out[o] = t[row][zz];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // host side
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Geom make_geom(int d0, int d1, int d2)
+{
+    Geom G;
+    G.d0 = d0; G.d1 = d1; G.d2 = d2;
+    G.nb1 = (d1 + 3) / 4;
+    G.nb2 = (d2 + 1) / 2;
+    return G;
+}
+
+size_t bricked_floats(int d0, int d1, int d2)
+{
+    Geom G = make_geom(d0, d1, d2);
+    return (size_t)((d0 + 3) / 4) * G.nb1 * G.nb2 * kBrickFloats;
+}
 
 struct Workspace {
     float *med;
@@ -1043,17 +1241,18 @@ int chunk_for(int N1)
 }
 
 int check_common(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
-                 int dirs_dtype, int P, int R, int S, int start, int sampler)
+                 int dirs_dtype, int P, int R, int S, int start, int sampler, int layout, bool need_scan)
 {
     if (!vol || !src || !dirs) return DIFFUS_EINVAL;
     if (d0 <= 0 || d1 <= 0 || d2 <= 0 || P <= 0 || R <= 0 || S <= 0) return DIFFUS_EINVAL;
     if ((src_dtype != DIFFUS_F32 && src_dtype != DIFFUS_F64) || (dirs_dtype != DIFFUS_F32 && dirs_dtype != DIFFUS_F64))
         return DIFFUS_EINVAL;
     if (sampler != DIFFUS_NEAREST && sampler != DIFFUS_TRILINEAR) return DIFFUS_EINVAL;
+    if (layout != DIFFUS_CANONICAL && layout != DIFFUS_BRICKED) return DIFFUS_EINVAL;
     if (start < 0 || start > S - 1) return DIFFUS_EINVAL;
     if (start > 0 && start > S - 2) return DIFFUS_EINVAL; // reference raises IndexError at :243
     if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24)) return DIFFUS_EUNSUPPORTED; // float(dim-1) must be exact
-    if (S - start > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
+    if (need_scan && S - start > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
     if (start > 0 && (size_t)R * sizeof(float) > 64 * 1024) return DIFFUS_EUNSUPPORTED; // median LDS
     return DIFFUS_OK;
 }
@@ -1062,7 +1261,8 @@ Args make_args(const float *vol, int d0, int d1, int d2, const void *src, int sr
                int dirs_dtype, int P, int R, int S, int start, float alpha, const Workspace &ws)
 {
     Args A{};
-    A.vol = vol; A.d0 = d0; A.d1 = d1; A.d2 = d2;
+    A.vol = vol;
+    A.G = make_geom(d0, d1, d2);
     A.src = src; A.dirs = dirs;
     A.src_f64 = src_dtype == DIFFUS_F64; A.dir_f64 = dirs_dtype == DIFFUS_F64;
     A.P = P; A.R = R; A.S = S; A.start = start; A.N1 = S - start;
@@ -1071,39 +1271,72 @@ Args make_args(const float *vol, int d0, int d1, int d2, const void *src, int sr
     return A;
 }
 
-template <int SAMPLER>
-int launch_median(const Args &A, hipStream_t st)
+int last_launch() { return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH; }
+
+// (sampler, layout) -> compile-time constants
+template <typename F>
+int dispatch_sl(int sampler, int layout, F &&f)
 {
-    hipLaunchKernelGGL(median_kernel<SAMPLER>, dim3(A.P), dim3(kBlock), sizeof(float) * (size_t)A.R, st, A);
-    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+    if (sampler == DIFFUS_NEAREST)
+        return layout == DIFFUS_CANONICAL
+                   ? f(std::integral_constant<int, DIFFUS_NEAREST>{}, std::integral_constant<int, DIFFUS_CANONICAL>{})
+                   : f(std::integral_constant<int, DIFFUS_NEAREST>{}, std::integral_constant<int, DIFFUS_BRICKED>{});
+    return layout == DIFFUS_CANONICAL
+               ? f(std::integral_constant<int, DIFFUS_TRILINEAR>{}, std::integral_constant<int, DIFFUS_CANONICAL>{})
+               : f(std::integral_constant<int, DIFFUS_TRILINEAR>{}, std::integral_constant<int, DIFFUS_BRICKED>{});
 }
 
-template <int SAMPLER>
-int launch_fwd(const Args &A, hipStream_t st)
+int launch_median(const Args &A, int sampler, int layout, hipStream_t st)
+{
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        hipLaunchKernelGGL((median_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(A.P), dim3(kBlock),
+                           sizeof(float) * (size_t)A.R, st, A);
+        return last_launch();
+    });
+}
+
+int launch_fwd(const Args &A, int sampler, int layout, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+        switch (chunk_for(A.N1)) {
+        case 2: hipLaunchKernelGGL((render_fwd_kernel<2, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+        case 4: hipLaunchKernelGGL((render_fwd_kernel<4, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+        case 8: hipLaunchKernelGGL((render_fwd_kernel<8, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+        default: hipLaunchKernelGGL((render_fwd_kernel<16, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+        }
+        return last_launch();
+    });
+}
+
+template <int SM, int LY, bool GPOSE>
+int launch_bwd_t(const Args &A, hipStream_t st)
 {
     const long waves = (long)A.P * A.R;
     const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     switch (chunk_for(A.N1)) {
-    case 2: hipLaunchKernelGGL((render_fwd_kernel<2, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    case 4: hipLaunchKernelGGL((render_fwd_kernel<4, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    case 8: hipLaunchKernelGGL((render_fwd_kernel<8, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    default: hipLaunchKernelGGL((render_fwd_kernel<16, SAMPLER>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SM, LY, GPOSE, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: // 16 samples per lane need ~300 registers: one wave per block so the whole 512-entry file is available
+        hipLaunchKernelGGL((render_bwd_kernel<16, SM, LY, GPOSE, 1>), dim3((unsigned)waves), dim3(kWave), 0, st, A);
+        break;
     }
-    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+    return last_launch();
 }
 
-template <int SAMPLER, bool GPOSE>
-int launch_bwd(const Args &A, hipStream_t st)
+int launch_bwd(const Args &A, int sampler, int layout, bool pose, hipStream_t st)
 {
-    const long waves = (long)A.P * A.R;
-    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    switch (chunk_for(A.N1)) {
-    case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    default: hipLaunchKernelGGL((render_bwd_kernel<16, SAMPLER, GPOSE>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    }
-    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+        if constexpr (SM == DIFFUS_NEAREST) {
+            return launch_bwd_t<SM, LY, false>(A, st);
+        } else {
+            return pose ? launch_bwd_t<SM, LY, true>(A, st) : launch_bwd_t<SM, LY, false>(A, st);
+        }
+    });
 }
 
 } // namespace
@@ -1118,7 +1351,7 @@ const char *diffus_strerror(int code)
     switch (code) {
     case DIFFUS_OK: return "ok";
     case DIFFUS_EINVAL: return "invalid argument";
-    case DIFFUS_EUNSUPPORTED: return "unsupported shape (S - start > 1024, volume too large, or too many rays for start > 0)";
+    case DIFFUS_EUNSUPPORTED: return "unsupported shape (S - start > 1024, a volume edge > 2^24, or too many rays for start > 0)";
     case DIFFUS_ELAUNCH: return "HIP launch failure";
     case DIFFUS_EWORKSPACE: return "workspace too small (see diffus_workspace_bytes)";
     default: return "unknown diffus error";
@@ -1131,11 +1364,41 @@ size_t diffus_workspace_bytes(int P, int R, int S, int start)
     return carve(nullptr, P, R, S - start).bytes;
 }
 
-int diffus_render_fwd(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
-                      int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler, float *frame,
-                      int64_t *idx, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+size_t diffus_bricked_floats(int d0, int d1, int d2)
 {
-    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler);
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
+    return bricked_floats(d0, d1, d2);
+}
+
+int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked, diffus_stream_t stream)
+{
+    if (!vol || !bricked || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    dim3 grid((G.nb2 + kConvZ / 2 - 1) / (kConvZ / 2), G.nb1, (d0 + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
+    hipLaunchKernelGGL((brick_convert_kernel<true, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, vol, bricked, G);
+    return last_launch();
+}
+
+int diffus_unbrick_volume(const float *bricked, int d0, int d1, int d2, float *vol, int accumulate,
+                          diffus_stream_t stream)
+{
+    if (!vol || !bricked || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    dim3 grid((G.nb2 + kConvZ / 2 - 1) / (kConvZ / 2), G.nb1, (d0 + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
+    if (accumulate)
+        hipLaunchKernelGGL((brick_convert_kernel<false, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G);
+    else
+        hipLaunchKernelGGL((brick_convert_kernel<false, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G);
+    return last_launch();
+}
+
+int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                      float *frame, int64_t *idx, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
     if (!frame) return DIFFUS_EINVAL;
     Workspace ws = carve(workspace, P, R, S - start);
@@ -1145,18 +1408,18 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, const void *src,
     A.frame = frame;
     A.idx = (long long *)idx;
     if (start > 0) {
-        rc = sampler == DIFFUS_NEAREST ? launch_median<DIFFUS_NEAREST>(A, st) : launch_median<DIFFUS_TRILINEAR>(A, st);
+        rc = launch_median(A, sampler, layout, st);
         if (rc) return rc;
     }
-    return sampler == DIFFUS_NEAREST ? launch_fwd<DIFFUS_NEAREST>(A, st) : launch_fwd<DIFFUS_TRILINEAR>(A, st);
+    return launch_fwd(A, sampler, layout, st);
 }
 
-int diffus_render_bwd(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
-                      int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler, const float *gframe,
-                      float *gvol, float *gsrc, float *gdirs, void *workspace, size_t workspace_bytes,
-                      diffus_stream_t stream)
+int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                      const float *gframe, float *gvol, float *gsrc, float *gdirs, void *workspace,
+                      size_t workspace_bytes, diffus_stream_t stream)
 {
-    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler);
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
     if (!gframe) return DIFFUS_EINVAL;
     if (!gvol && !gsrc && !gdirs) return DIFFUS_OK;
@@ -1176,30 +1439,28 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, const void *src,
     A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
     A.gdirs = pose ? gdirs : nullptr;
     if (start > 0) { // recompute the median (and zero gmed)
-        rc = sampler == DIFFUS_NEAREST ? launch_median<DIFFUS_NEAREST>(A, st) : launch_median<DIFFUS_TRILINEAR>(A, st);
+        rc = launch_median(A, sampler, layout, st);
         if (rc) return rc;
     }
-    if (sampler == DIFFUS_NEAREST)
-        rc = launch_bwd<DIFFUS_NEAREST, false>(A, st);
-    else
-        rc = pose ? launch_bwd<DIFFUS_TRILINEAR, true>(A, st) : launch_bwd<DIFFUS_TRILINEAR, false>(A, st);
+    rc = launch_bwd(A, sampler, layout, pose, st);
     if (rc) return rc;
     if (gvol) {
         const int rgs = (R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
         const unsigned nb = (unsigned)((long)P * rgs * sgs);
-        if (sampler == DIFFUS_NEAREST)
-            hipLaunchKernelGGL(scatter_patch_kernel<DIFFUS_NEAREST>, dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
-        else
-            hipLaunchKernelGGL(scatter_patch_kernel<DIFFUS_TRILINEAR>, dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
-        if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
+        rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+            hipLaunchKernelGGL((scatter_patch_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nb), dim3(kBlock),
+                               0, st, A, rgs, sgs);
+            return last_launch();
+        });
+        if (rc) return rc;
     }
     if (start > 0) {
         const unsigned nb = (unsigned)((P + 63) / 64);
-        if (sampler == DIFFUS_NEAREST)
-            hipLaunchKernelGGL(median_bwd_kernel<DIFFUS_NEAREST>, dim3(nb), dim3(64), 0, st, A);
-        else
-            hipLaunchKernelGGL(median_bwd_kernel<DIFFUS_TRILINEAR>, dim3(nb), dim3(64), 0, st, A);
-        if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
+        rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+            hipLaunchKernelGGL((median_bwd_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nb), dim3(64), 0, st, A);
+            return last_launch();
+        });
+        if (rc) return rc;
     }
     if (pose && gsrc) {
         hipLaunchKernelGGL(reduce_gsrc_kernel, dim3(P), dim3(kBlock), 0, st, ws.gsrc_part, gsrc, R);
@@ -1208,12 +1469,11 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, const void *src,
     return DIFFUS_OK;
 }
 
-int diffus_trace_rays(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
-                      int dirs_dtype, int P, int R, int S, int sampler, float *imp, float *refl, int64_t *idx,
-                      diffus_stream_t stream)
+int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype, int P, int R, int S, int sampler, float *imp, float *refl,
+                      int64_t *idx, diffus_stream_t stream)
 {
-    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, sampler);
-    if (rc == DIFFUS_EUNSUPPORTED && S > DIFFUS_MAX_SAMPLES) rc = DIFFUS_OK; // no scan here: any S
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, sampler, layout, false);
     if (rc) return rc;
     if (!imp && !refl && !idx) return DIFFUS_OK;
     Workspace ws = carve(nullptr, P, R, S);
@@ -1222,13 +1482,11 @@ int diffus_trace_rays(const float *vol, int d0, int d1, int d2, const void *src,
     unsigned nblk = (unsigned)((total + kBlock - 1) / kBlock);
     if (nblk > 256u * 16u) nblk = 256u * 16u;
     hipStream_t st = (hipStream_t)stream;
-    if (sampler == DIFFUS_NEAREST)
-        hipLaunchKernelGGL(trace_rays_kernel<DIFFUS_NEAREST>, dim3(nblk), dim3(kBlock), 0, st, A, imp, refl,
-                           (long long *)idx);
-    else
-        hipLaunchKernelGGL(trace_rays_kernel<DIFFUS_TRILINEAR>, dim3(nblk), dim3(kBlock), 0, st, A, imp, refl,
-                           (long long *)idx);
-    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        hipLaunchKernelGGL((trace_rays_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nblk), dim3(kBlock), 0, st,
+                           A, imp, refl, (long long *)idx);
+        return last_launch();
+    });
 }
 
 int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stream_t stream)
@@ -1244,7 +1502,7 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stre
     case 8: hipLaunchKernelGGL(echo_traces_kernel<8>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
     default: hipLaunchKernelGGL(echo_traces_kernel<16>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
     }
-    return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH;
+    return last_launch();
 }
 
 } // extern "C"

@@ -17,12 +17,17 @@ Differences from the reference, all deliberate:
     d / d directions for trilinear (the reference raises, SURVEY D3);
   * a float `start` is honoured as the fraction of num_samples the code intends
     (:237-238); the reference crashes on it inside its visualisation (:774);
-  * `render_poses` batches P poses in one launch.
+  * `render_poses` batches P poses in one launch;
+  * `layout=` selects the HBM layout the kernels read: "canonical" (the caller's
+    tensor), "bricked" (a cached 4x4x2-brick copy, DESIGN.md §Data layout) or
+    "auto"; a `BrickedVolume` keeps a volume (e.g. a learnable impedance map)
+    permanently bricked so that no conversion happens per step.
 """
 from __future__ import annotations
 
 import ctypes as C
 import logging
+import weakref
 from typing import Optional
 
 import torch
@@ -32,7 +37,35 @@ from . import _lib
 log = logging.getLogger("diffus_amd")
 
 _SAMPLERS = {"nearest": _lib.NEAREST, "prop": _lib.NEAREST, "trilinear": _lib.TRILINEAR}
+_LAYOUTS = ("auto", "canonical", "bricked")
 _workspaces: dict = {}
+_brick_cache: list = []     # [(weakref(source tensor), version, bricked copy)]   (at most 2 entries)
+_brick_seen: list = []      # [(weakref(source tensor), version, calls)]
+_AUTO_BRICK_SAMPLES = 1 << 18
+
+
+class BrickedVolume:
+    """A (d0,d1,d2) float32 volume stored in the bricked HBM layout.
+
+    `data` is the flat bricked tensor (diffus_bricked_floats elements); it may
+    require grad, in which case gradients come back in the same layout -- an
+    optimiser can update it in place, element-wise, without ever converting.
+    """
+
+    def __init__(self, data: torch.Tensor, shape):
+        self.data = data
+        self.shape = tuple(int(x) for x in shape)
+
+    @classmethod
+    def from_dense(cls, volume: torch.Tensor) -> "BrickedVolume":
+        return cls(brick_volume(volume), volume.shape)
+
+    def to_dense(self) -> torch.Tensor:
+        return unbrick_volume(self.data.detach(), self.shape)
+
+    @property
+    def device(self):
+        return self.data.device
 
 
 def _device_for(t: torch.Tensor) -> torch.device:
@@ -66,6 +99,63 @@ def _stream(dev) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def brick_volume(volume: torch.Tensor) -> torch.Tensor:
+    """canonical (d0,d1,d2) -> flat bricked float32 tensor on the GPU (diffus_brick_volume)."""
+    lib = _lib.load()
+    dev = _device_for(volume)
+    v = volume.detach().to(device=dev, dtype=torch.float32).contiguous()
+    d0, d1, d2 = v.shape
+    with torch.cuda.device(dev):
+        out = torch.empty(lib.diffus_bricked_floats(d0, d1, d2), dtype=torch.float32, device=dev)
+        rc = lib.diffus_brick_volume(_ptr(v), d0, d1, d2, _ptr(out), _stream(dev))
+    _lib.check(rc, "diffus_brick_volume")
+    return out
+
+
+def unbrick_volume(bricked: torch.Tensor, shape, out: Optional[torch.Tensor] = None, accumulate=False):
+    """flat bricked tensor -> canonical (d0,d1,d2) float32 (diffus_unbrick_volume)."""
+    lib = _lib.load()
+    d0, d1, d2 = (int(x) for x in shape)
+    dev = bricked.device
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty((d0, d1, d2), dtype=torch.float32, device=dev)
+            accumulate = False
+        rc = lib.diffus_unbrick_volume(_ptr(bricked), d0, d1, d2, _ptr(out), int(bool(accumulate)), _stream(dev))
+    _lib.check(rc, "diffus_unbrick_volume")
+    return out
+
+
+def _bricked_copy(vol: torch.Tensor, src_tensor: torch.Tensor, want: str, samples: int):
+    """Return the cached bricked copy of `vol` if the layout policy asks for one, else None.
+
+    Entries are keyed by the IDENTITY of the caller's tensor (weak reference) and
+    its in-place version counter -- never by address, which the allocator reuses.
+    """
+    if want == "canonical":
+        return None
+    ver = src_tensor._version
+    _brick_cache[:] = [e for e in _brick_cache if e[0]() is not None]
+    for ref, v, b in _brick_cache:
+        if ref() is src_tensor and v == ver:
+            return b
+    _brick_seen[:] = [e for e in _brick_seen if e[0]() is not None][-16:]
+    calls = 1
+    for i, (ref, v, n) in enumerate(_brick_seen):
+        if ref() is src_tensor and v == ver:
+            calls = n + 1
+            _brick_seen[i] = (ref, v, calls)
+            break
+    else:
+        _brick_seen.append((weakref.ref(src_tensor), ver, 1))
+    if want == "auto" and samples < _AUTO_BRICK_SAMPLES and calls < 2:
+        return None
+    b = brick_volume(vol)
+    _brick_cache.append((weakref.ref(src_tensor), ver, b))
+    del _brick_cache[:-2]
+    return b
+
+
 def resolve_start(start, num_samples: int) -> int:
     """reference src/renderer.py:237-240."""
     if type(start) is float:
@@ -78,11 +168,22 @@ def resolve_start(start, num_samples: int) -> int:
 class _Problem:
     """Validated, device-resident arguments of one (batched) call."""
 
-    def __init__(self, volume, sources, directions, S, start, alpha, sampler):
-        if volume.dim() != 3:
-            raise ValueError(f"volume must be 3-D, got shape {tuple(volume.shape)}")
-        self.dev = _device_for(volume)
-        self.vol = volume.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+    def __init__(self, volume, sources, directions, S, start, alpha, sampler, layout="auto", shape=None):
+        if layout not in _LAYOUTS + ("prebricked",):
+            raise ValueError(f"unknown layout {layout!r}")
+        if layout == "prebricked":          # `volume` is BrickedVolume.data, `shape` its dense shape
+            self.dev = _device_for(volume)
+            self.shape = tuple(shape)
+            self.vol = None
+            self.bricked = volume.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+        else:
+            if volume.dim() != 3:
+                raise ValueError(f"volume must be 3-D, got shape {tuple(volume.shape)}")
+            self.dev = _device_for(volume)
+            self.shape = tuple(volume.shape)
+            self.vol = volume.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+            self.bricked = None
+        self._layout_req, self._vol_src = layout, volume
         sd, dd = _pose_dtype(sources), _pose_dtype(directions)
         self.src = sources.detach().to(device=self.dev, dtype=sd).reshape(-1, 3).contiguous()
         d = directions.detach().to(device=self.dev, dtype=dd)
@@ -100,10 +201,14 @@ class _Problem:
         self.sampler = _SAMPLERS[sampler]
         self.src_dt = _lib.DIFFUS_F64 if sd == torch.float64 else _lib.DIFFUS_F32
         self.dir_dt = _lib.DIFFUS_F64 if dd == torch.float64 else _lib.DIFFUS_F32
+        if self.bricked is None:
+            self.bricked = _bricked_copy(self.vol, volume, layout, self.P * self.R * self.N1)
+        self.layout = _lib.BRICKED if self.bricked is not None else _lib.CANONICAL
 
     def common(self):
-        d0, d1, d2 = self.vol.shape
-        return (_ptr(self.vol), d0, d1, d2, _ptr(self.src), self.src_dt, _ptr(self.dirs), self.dir_dt,
+        d0, d1, d2 = self.shape
+        v = self.bricked if self.layout == _lib.BRICKED else self.vol
+        return (_ptr(v), d0, d1, d2, self.layout, _ptr(self.src), self.src_dt, _ptr(self.dirs), self.dir_dt,
                 self.P, self.R, self.S, self.start, self.alpha, self.sampler)
 
     def workspace(self):
@@ -115,9 +220,9 @@ class _RenderFn(torch.autograd.Function):
     """frame = render(volume, sources, directions); backward via diffus_render_bwd."""
 
     @staticmethod
-    def forward(ctx, volume, sources, directions, S, start, alpha, sampler, want_idx):
+    def forward(ctx, volume, sources, directions, S, start, alpha, sampler, want_idx, layout, shape):
         lib = _lib.load()
-        pb = _Problem(volume, sources, directions, S, start, alpha, sampler)
+        pb = _Problem(volume, sources, directions, S, start, alpha, sampler, layout, shape)
         with torch.cuda.device(pb.dev):
             frame = torch.empty((pb.P, pb.R, pb.N1), dtype=torch.float32, device=pb.dev)
             idx = torch.empty((3, pb.P, pb.R, pb.N1), dtype=torch.int64, device=pb.dev) if want_idx else None
@@ -140,14 +245,20 @@ class _RenderFn(torch.autograd.Function):
         need_v, need_s, need_d = ctx.needs_input_grad[:3]
         with torch.cuda.device(pb.dev):
             g = gframe.detach().to(device=pb.dev, dtype=torch.float32).contiguous()
-            gvol = torch.zeros_like(pb.vol) if need_v else None
+            gvol = None
+            if need_v:      # gradient buffer in the layout the kernels ran in
+                gvol = torch.zeros_like(pb.bricked if pb.layout == _lib.BRICKED else pb.vol)
             gsrc = torch.empty((pb.P, 3), dtype=torch.float32, device=pb.dev) if need_s else None
             gdirs = torch.empty((pb.P, pb.R, 3), dtype=torch.float32, device=pb.dev) if need_d else None
             ws = pb.workspace()
             rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(gsrc), _ptr(gdirs),
                                        _ptr(ws), ws.numel(), _stream(pb.dev))
         _lib.check(rc, "diffus_render_bwd")
-        out_v = gvol.to(device=vdev, dtype=vdt) if need_v else None
+        out_v = None
+        if need_v:
+            if pb._layout_req != "prebricked" and pb.layout == _lib.BRICKED:
+                gvol = unbrick_volume(gvol, pb.shape)       # back to the caller's (d0,d1,d2)
+            out_v = gvol.to(device=vdev, dtype=vdt)
         out_s = gsrc.reshape(sshape).to(device=sdev, dtype=sdt) if need_s else None
         out_d = None
         if need_d:
@@ -158,14 +269,14 @@ class _RenderFn(torch.autograd.Function):
             else:
                 out_d = gdirs.sum(0).reshape(dshape)
             out_d = out_d.to(device=ddev, dtype=ddt)
-        return out_v, out_s, out_d, None, None, None, None, None
+        return out_v, out_s, out_d, None, None, None, None, None, None, None
 
 
 def render_poses(volume, sources, directions, num_samples, attenuation_coeff, start=0, sampler="nearest",
-                 return_indices=False):
+                 return_indices=False, layout="auto"):
     """Batched hot path: P poses in one launch.
 
-    volume (d0,d1,d2); sources (P,3) or (3,); directions (P,R,3) or (R,3) shared.
+    volume (d0,d1,d2) tensor or BrickedVolume; sources (P,3) or (3,); directions (P,R,3) or (R,3) shared.
     -> frame (P,R,num_samples-start) float32 [, idx (3,P,R,N1) int64].
     Differentiable in volume (both samplers) and in sources/directions (trilinear).
     """
@@ -174,22 +285,26 @@ def render_poses(volume, sources, directions, num_samples, attenuation_coeff, st
     start = resolve_start(start, num_samples)
     if start > 0 and start >= num_samples - 1:
         raise IndexError("index 0 is out of bounds for dimension 1 with size 0")  # reference :243
-    frame, idx = _RenderFn.apply(volume, sources, directions, num_samples, start, attenuation_coeff,
-                                 sampler, bool(return_indices))
+    if isinstance(volume, BrickedVolume):
+        frame, idx = _RenderFn.apply(volume.data, sources, directions, num_samples, start, attenuation_coeff,
+                                     sampler, bool(return_indices), "prebricked", volume.shape)
+    else:
+        frame, idx = _RenderFn.apply(volume, sources, directions, num_samples, start, attenuation_coeff,
+                                     sampler, bool(return_indices), layout, None)
     return (frame, idx) if return_indices else frame
 
 
-def trace_rays(volume, sources, directions, num_samples, sampler="nearest", want=("imp", "refl", "idx")):
+def trace_rays(volume, sources, directions, num_samples, sampler="nearest", want=("imp", "refl", "idx"),
+               layout="auto"):
     """Stage 1 alone (diffus_trace_rays): -> dict with imp (P,R,S), refl (P,R,S-1), idx (3,P,R,S)."""
     lib = _lib.load()
-    pb = _Problem(volume, sources, directions, num_samples, 0, 0.0, sampler)
+    pb = _Problem(volume, sources, directions, num_samples, 0, 0.0, sampler, layout)
     with torch.cuda.device(pb.dev):
         imp = torch.empty((pb.P, pb.R, pb.S), dtype=torch.float32, device=pb.dev) if "imp" in want else None
         refl = torch.empty((pb.P, pb.R, pb.S - 1), dtype=torch.float32, device=pb.dev) if "refl" in want else None
         idx = torch.empty((3, pb.P, pb.R, pb.S), dtype=torch.int64, device=pb.dev) if "idx" in want else None
-        d0, d1, d2 = pb.vol.shape
-        rc = lib.diffus_trace_rays(_ptr(pb.vol), d0, d1, d2, _ptr(pb.src), pb.src_dt, _ptr(pb.dirs), pb.dir_dt,
-                                   pb.P, pb.R, pb.S, pb.sampler, _ptr(imp), _ptr(refl), _ptr(idx), _stream(pb.dev))
+        c = pb.common()
+        rc = lib.diffus_trace_rays(*c[:12], pb.sampler, _ptr(imp), _ptr(refl), _ptr(idx), _stream(pb.dev))
     _lib.check(rc, "diffus_trace_rays")
     return {"imp": imp, "refl": refl, "idx": idx}
 
@@ -250,7 +365,7 @@ class UltrasoundRenderer:
                         angle: float = 45.0, plot: bool = True, artifacts: bool = False, ax=None, cmap=None,
                         std_radial: float = 0.01, std_local: float = 0.15, max_sigma: float = 4.0,
                         alpha: float = 5, start: float = 0, *, sampler: str = "nearest",
-                        return_indices: bool = True, **kwargs):
+                        return_indices: bool = True, layout: str = "auto", **kwargs):
         """Simulate the fan frame of one pose (reference src/renderer.py:201-275).
 
         volume (d0,d1,d2) impedance; source (3,); directions (n_rays,3) unit vectors.
@@ -265,7 +380,7 @@ class UltrasoundRenderer:
         if torch.as_tensor(source).numel() != 3:
             raise ValueError("source must have 3 components")
         res = render_poses(volume, source, directions, self.num_samples, self.attenuation_coeff, start=start,
-                           sampler=sampler, return_indices=return_indices)
+                           sampler=sampler, return_indices=return_indices, layout=layout)
         dev = volume.device
         if return_indices:
             frame, idx = res

@@ -55,6 +55,12 @@ extern "C" {
 #define DIFFUS_TRILINEAR 1 /* grid_sample(bilinear, border, align_corners=True) semantics;
                               the only mode with a pose gradient */
 
+/* volume layout (argument `layout` of the calls below; applies to `vol` and, in
+ * the backward, to `gvol`) */
+#define DIFFUS_CANONICAL 0 /* the caller's (d0,d1,d2) row-major tensor */
+#define DIFFUS_BRICKED   1 /* 4x4x2-voxel bricks of 32 floats (one 128-B line), row-major over
+                              (ceil(d0/4), ceil(d1/4), ceil(d2/2)); made by diffus_brick_volume */
+
 /* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples,
  * at most 16 -> N1 <= 1024 */
 #define DIFFUS_MAX_SAMPLES 1024
@@ -69,6 +75,24 @@ const char *diffus_strerror(int code);
 size_t diffus_workspace_bytes(int P, int R, int S, int start);
 
 /*
+ * Data layout in HBM.  The reference indexes a dense (d0,d1,d2) tensor with dim 2
+ * contiguous (src/renderer.py:750-758) while every demo fan lies in a plane of
+ * constant dim 2 (src/cone.py:258) -- the worst case for that layout.  The
+ * kernels therefore also accept a bricked copy (DIFFUS_BRICKED).  These two calls
+ * convert; both are coalesced streaming passes over the volume.
+ *   diffus_bricked_floats  number of floats of the bricked buffer (>= d0*d1*d2)
+ *   diffus_brick_volume    canonical -> bricked (padding voxels are written as 0)
+ *   diffus_unbrick_volume  bricked -> canonical; accumulate != 0 adds instead of
+ *                          storing (used to fold a bricked gradient into a
+ *                          canonical one)
+ */
+size_t diffus_bricked_floats(int d0, int d1, int d2);
+int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked,
+                        diffus_stream_t stream);
+int diffus_unbrick_volume(const float *bricked, int d0, int d1, int d2, float *vol,
+                          int accumulate, diffus_stream_t stream);
+
+/*
  * Forward: replaces UltrasoundRenderer.plot_beam_frame with artifacts=False
  * (reference src/renderer.py:201-275) and everything under it: trace_ray
  * (:90-180), custom_nearest_sampler (:741-759), compute_reflection_coeff
@@ -81,7 +105,7 @@ size_t diffus_workspace_bytes(int P, int R, int S, int start);
  *   idx    out, nullable: (3,P,R,N1) int64 -- the x,y,z index planes the
  *          reference returns, already cropped to [:, start:]
  */
-int diffus_render_fwd(const float *vol, int d0, int d1, int d2,
+int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
                       const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype,
                       int P, int R, int S, int start, float alpha, int sampler,
@@ -94,14 +118,15 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2,
  * reference's sub-functions, SURVEY.md §3.2 / App. A.4, without storing any
  * dense system): given gframe = dL/dframe (P,R,N1) it recomputes the forward
  * per ray and produces any of
- *   gvol   nullable (d0,d1,d2) float32, ACCUMULATED with float atomics
+ *   gvol   nullable, float32 in the SAME layout as vol ((d0,d1,d2) canonical or
+ *          diffus_bricked_floats() bricked), ACCUMULATED with float atomics
  *          (caller zeroes it; shared by all poses)
  *   gsrc   nullable (P,3) float32, overwritten   (trilinear only, else zeros)
  *   gdirs  nullable (P,R,3) float32, overwritten (trilinear only, else zeros)
  * With start > 0 the median written into column 0 (reference :243-244) routes
  * its gradient to the ray that supplied the median, like torch.median.
  */
-int diffus_render_bwd(const float *vol, int d0, int d1, int d2,
+int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout,
                       const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype,
                       int P, int R, int S, int start, float alpha, int sampler,
@@ -119,7 +144,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2,
  *   refl  (P,R,S-1) float32  reflection coefficients (simulate_rays' R)
  *   idx   (3,P,R,S) int64    rounded, clamped voxel indices x,y,z
  */
-int diffus_trace_rays(const float *vol, int d0, int d1, int d2,
+int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout,
                       const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype,
                       int P, int R, int S, int sampler,

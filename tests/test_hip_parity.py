@@ -97,13 +97,14 @@ def test_echo_adversarial_growth(da, oracle):
 
 
 # ----------------------------------------------------------------------------- stage 1: sampling
+@pytest.mark.parametrize("layout", ["canonical", "bricked"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
-def test_trace_rays_vs_oracle(da, oracle, vols, sampler):
+def test_trace_rays_vs_oracle(da, oracle, vols, sampler, layout):
     g = load_golden("g5_small_frames")
     for t in [str(x) for x in g["tags"]]:
         n, S = int(g[f"{t}_n"]), int(g[f"{t}_S"])
         src, dirs = g[f"{t}_source"], g[f"{t}_directions"]
-        out = da.trace_rays(cuda(vols[n]), torch.from_numpy(src), torch.from_numpy(dirs), S, sampler)
+        out = da.trace_rays(cuda(vols[n]), torch.from_numpy(src), torch.from_numpy(dirs), S, sampler, layout=layout)
         ix, iy, iz, imp_n = oracle.sample_nearest(vols[n], src, dirs, S)
         idx = out["idx"][:, 0].cpu().numpy()
         np.testing.assert_array_equal(idx[0], ix, err_msg=t)
@@ -127,14 +128,15 @@ def test_trilinear_vs_grid_sample_golden(da):
 
 
 # ----------------------------------------------------------------------------- whole frames vs the reference
-def test_plot_beam_frame_golden_small(da, oracle, vols):
+@pytest.mark.parametrize("layout", ["canonical", "bricked"])
+def test_plot_beam_frame_golden_small(da, oracle, vols, layout):
     g = load_golden("g5_small_frames")
     for t in [str(x) for x in g["tags"]]:
         n, S, alpha, start = int(g[f"{t}_n"]), int(g[f"{t}_S"]), float(g[f"{t}_alpha"]), int(g[f"{t}_start"])
         R = da.UltrasoundRenderer(S, alpha)
         vol = cuda(vols[n])
         x, y, z, f = R.plot_beam_frame(vol, torch.from_numpy(g[f"{t}_source"]), torch.from_numpy(g[f"{t}_directions"]),
-                                       plot=False, start=start)
+                                       plot=False, start=start, layout=layout)
         assert x.dtype == torch.int64 and f.dtype == torch.float32 and f.device == vol.device
         np.testing.assert_array_equal(x.cpu().numpy(), g[f"{t}_x"], err_msg=t)
         np.testing.assert_array_equal(y.cpu().numpy(), g[f"{t}_y"], err_msg=t)
@@ -181,11 +183,12 @@ def test_config2_golden(da, vol256):
 @pytest.mark.parametrize("S,start,R", [(2, 0, 2), (3, 1, 3), (48, 46, 5), (65, 0, 1), (130, 1, 7), (257, 0, 3),
                                        (513, 0, 2), (1024, 0, 3), (1030, 6, 2)])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
-def test_shapes_and_edges_vs_oracle(da, oracle, vols, S, start, R, sampler):
+@pytest.mark.parametrize("layout", ["canonical", "bricked"])
+def test_shapes_and_edges_vs_oracle(da, oracle, vols, S, start, R, sampler, layout):
     src, dirs = pose_ring(64, 3, R)
     vol = vols[64]
     f = da.render_poses(cuda(vol), torch.from_numpy(src), torch.from_numpy(dirs), S, 2e-3, start=start,
-                        sampler=sampler).cpu().numpy()
+                        sampler=sampler, layout=layout).cpu().numpy()
     assert f.shape == (3, R, S - start)
     for p in range(3):
         _, _, _, fo = oracle.plot_beam_frame(vol, src[p], dirs[p], S, 2e-3, start, sampler=sampler)
@@ -208,18 +211,20 @@ def test_zero_impedance_and_degenerate_volume(da, oracle):
     vol[10:14, :, :] = 0.0        # Z1+Z2 = 0 -> NaN r -> echoes zero from there on (reference :408)
     src = np.array([2.0, 16.0, 16.0], np.float32)
     dirs = np.array([[1.0, 0.0, 0.0], [0.9, 0.1, 0.0]], np.float32)
-    for sampler in ("nearest", "trilinear"):
+    for sampler, layout in (("nearest", "canonical"), ("trilinear", "canonical"), ("nearest", "bricked"),
+                            ("trilinear", "bricked")):
         f = da.render_poses(cuda(vol), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
-                            sampler=sampler).cpu().numpy()[0]
+                            sampler=sampler, layout=layout).cpu().numpy()[0]
         _, _, _, fo = oracle.plot_beam_frame(vol, src, dirs, 30, 1e-3, 0, sampler=sampler)
         assert np.all(np.isfinite(f))
         np.testing.assert_allclose(f, fo, rtol=1e-5, atol=1e-6)
         assert np.all(f[0, 12:] == 0)
     flat = phantom(32)[:, :, :1].copy()   # d2 == 1: the paired dim-2 load must not be used
-    f = da.render_poses(cuda(flat), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
-                        sampler="trilinear").cpu().numpy()[0]
     _, _, _, fo = oracle.plot_beam_frame(flat, src, dirs, 30, 1e-3, 0, sampler="trilinear")
-    assert maxnorm_rel(f, fo) < 2e-5
+    for layout in ("canonical", "bricked"):
+        f = da.render_poses(cuda(flat), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
+                            sampler="trilinear", layout=layout).cpu().numpy()[0]
+        assert maxnorm_rel(f, fo) < 2e-5
 
 
 # ----------------------------------------------------------------------------- gradients
@@ -236,9 +241,10 @@ def _autograd_case(vol_np, src, dirs, S, alpha, start, sampler, gseed=0):
         (d.grad.numpy() if d.grad is not None else None)
 
 
+@pytest.mark.parametrize("layout", ["canonical", "bricked"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
 @pytest.mark.parametrize("S,start", [(48, 0), (48, 7), (150, 0), (300, 12), (700, 0)])
-def test_backward_vs_float64_autograd(da, vols, sampler, S, start):
+def test_backward_vs_float64_autograd(da, vols, sampler, S, start, layout):
     n = 64
     src, dirs = pose_ring(n, 4, 6)
     src, dirs = src[1], dirs[1].copy()
@@ -249,7 +255,7 @@ def test_backward_vs_float64_autograd(da, vols, sampler, S, start):
     vol = cuda(vols[n]).requires_grad_(True)
     s = torch.from_numpy(src).cuda().requires_grad_(True)
     d = torch.from_numpy(dirs).cuda().requires_grad_(True)
-    f = da.render_poses(vol, s, d, S, alpha, start=start, sampler=sampler)[0]
+    f = da.render_poses(vol, s, d, S, alpha, start=start, sampler=sampler, layout=layout)[0]
     assert maxnorm_rel(f.detach().cpu().numpy(), f_ref) < 2e-5
     (f * up.cuda()).sum().backward()
     assert maxnorm_rel(vol.grad.cpu().numpy(), gv_ref) < 1e-3
@@ -330,8 +336,8 @@ def test_full_size_batch_vs_oracle_and_properties(da, oracle, vol256):
     src, dirs = pose_ring(256, P, R)
     vol = cuda(vol256)
     s, d = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
-    for sampler in ("nearest", "trilinear"):
-        f = da.render_poses(vol, s, d, S, alpha, sampler=sampler)
+    for sampler, layout in (("nearest", "bricked"), ("trilinear", "bricked"), ("trilinear", "canonical")):
+        f = da.render_poses(vol, s, d, S, alpha, sampler=sampler, layout=layout)
         assert f.shape == (P, R, S)
         fc = f.cpu().numpy()
         assert np.all(np.isfinite(fc)) and np.all(fc[:, :, 0] == 0)
@@ -339,9 +345,11 @@ def test_full_size_batch_vs_oracle_and_properties(da, oracle, vol256):
             _, _, _, fo = oracle.plot_beam_frame(vol256, src[p], dirs[p], S, alpha, 0, sampler=sampler)
             assert maxnorm_rel(fc[p], fo) < 2e-5, (sampler, p)
         # determinism and batch-independence of the forward
-        f2 = da.render_poses(vol, s[5:6], d[5:6], S, alpha, sampler=sampler)
+        f2 = da.render_poses(vol, s[5:6], d[5:6], S, alpha, sampler=sampler, layout=layout)
         assert torch.equal(f2[0], f[5])
-        assert torch.equal(da.render_poses(vol, s, d, S, alpha, sampler=sampler), f)
+        assert torch.equal(da.render_poses(vol, s, d, S, alpha, sampler=sampler, layout=layout), f)
+        if layout == "bricked":       # the layout must not change a single bit of the frame
+            assert torch.equal(da.render_poses(vol, s, d, S, alpha, sampler=sampler, layout="canonical"), f)
 
 
 def test_full_size_backward_properties(da, vol256):
@@ -363,3 +371,52 @@ def test_full_size_backward_properties(da, vol256):
     # zero upstream gradient -> zero gradients
     g0 = torch.autograd.grad(f, (vol, s, d), grad_outputs=torch.zeros_like(f))
     assert all(torch.all(x == 0) for x in g0)
+
+
+# ----------------------------------------------------------------------------- bricked layout
+@pytest.mark.parametrize("shape", [(4, 4, 2), (5, 7, 3), (64, 64, 64), (33, 70, 129), (1, 1, 1), (3, 2, 131)])
+def test_brick_roundtrip(da, shape):
+    g = torch.Generator().manual_seed(1)
+    v = torch.randn(shape, generator=g).cuda()
+    b = da.brick_volume(v)
+    d0, d1, d2 = shape
+    assert b.numel() == ((d0 + 3) // 4) * ((d1 + 3) // 4) * ((d2 + 1) // 2) * 32
+    assert torch.equal(da.unbrick_volume(b, shape), v)
+    # element placement: brick-major, (x&3, y&3, z&1) inside
+    x, y, z = d0 - 1, d1 // 2, d2 - 1
+    nb1, nb2 = (d1 + 3) // 4, (d2 + 1) // 2
+    off = (((x >> 2) * nb1 + (y >> 2)) * nb2 + (z >> 1)) * 32 + ((x & 3) << 3 | (y & 3) << 1 | (z & 1))
+    assert b[off] == v[x, y, z]
+    acc = torch.ones(shape, device="cuda")
+    da.unbrick_volume(b, shape, out=acc, accumulate=True)
+    assert torch.equal(acc, v + 1)
+
+
+def test_bricked_volume_parameter(da, vols):
+    # a learnable volume kept bricked: gradients come back bricked and match the dense path
+    n, S, alpha = 64, 120, 1e-3
+    src, dirs = pose_ring(n, 3, 8)
+    dense = cuda(vols[n]).requires_grad_(True)
+    bv = da.BrickedVolume.from_dense(cuda(vols[n]))
+    bv.data.requires_grad_(True)
+    s, d = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+    f1 = da.render_poses(dense, s, d, S, alpha, sampler="trilinear", layout="canonical")
+    f2 = da.render_poses(bv, s, d, S, alpha, sampler="trilinear")
+    assert torch.equal(f1, f2)
+    (f1 ** 2).sum().backward()
+    (f2 ** 2).sum().backward()
+    g2 = da.unbrick_volume(bv.data.grad, bv.shape)
+    assert maxnorm_rel(g2.cpu().numpy(), dense.grad.cpu().numpy()) < 1e-5
+    assert torch.equal(bv.to_dense(), dense.detach())
+
+
+def test_brick_cache_tracks_inplace_updates(da, vols):
+    n, S = 64, 60
+    src, dirs = pose_ring(n, 2, 8)
+    v = cuda(vols[n])
+    s, d = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+    f1 = da.render_poses(v, s, d, S, 1e-3, layout="bricked")
+    v.mul_(1.0).add_(torch.where(v > 1e6, 5e4, 0.0))       # in-place edit bumps the version counter
+    f2 = da.render_poses(v, s, d, S, 1e-3, layout="bricked")
+    f3 = da.render_poses(v, s, d, S, 1e-3, layout="canonical")
+    assert torch.equal(f2, f3) and not torch.equal(f1, f2)
