@@ -7,18 +7,23 @@
 
 Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays x
 512 steps.  One *step* = one pass of the hot path over one batch of poses:
-  forward frame (diffus_render_fwd) -> loss = sum(frame^2) per pose ->
-  zero the volume gradient -> backward (diffus_render_bwd: d/d volume,
-  d/d source, d/d directions) -> gather of the per-pose losses over ranks.
+  forward frame (diffus_render_fwd)
+  -> loss_p = sum(frame_p^2), dL/dframe = 2 frame (diffus_loss_sumsq)
+  -> zero the volume-gradient buffer
+  -> backward (diffus_render_bwd: d/d volume, d/d source, d/d directions)
+  -> bricked gradient -> the caller's canonical (d0,d1,d2) tensor
+  -> gather of the per-pose losses over ranks (RCCL, N > 1).
 Workload at N=1 = BASELINE config 3 (32 poses of the config-2 shape on one GPU;
 a single 256x512 frame is only 256 wavefronts, i.e. launch-latency-bound, and is
 reported separately as `single_pose`).  Multi-GPU: poses shard contiguously over
 ranks, 32 per GPU (weak scaling; N=8 is BASELINE config 4), the volume is
-replicated, the only collective is one all_gather of P losses (RCCL).
+replicated, the only collective is one all_gather of P losses.
 
-Inputs are resident in HBM before the timed region.  Kernel durations for the
-roofline come from HIP events recorded on the launch stream (torch's current
-stream, which is the one handed to the C-ABI).
+Inputs (volume -- canonical and its bricked copy --, poses) are resident in HBM
+before the timed region.  The step is issued either eagerly or, by default, as a
+captured hipGraph replay (the C-ABI never syncs or allocates, so it captures).
+Kernel durations for the roofline come from HIP events recorded on the launch
+stream (torch's current stream, which is the one handed to the C-ABI).
 """
 from __future__ import annotations
 
@@ -29,7 +34,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,12 +42,20 @@ sys.path.insert(0, ROOT)
 from diffus_amd import _lib  # noqa: E402
 from diffus_amd.phantom import phantom, pose_ring  # noqa: E402
 
-# algorithmic bytes per ray-step, no-reuse model (SURVEY §8d / DESIGN.md §Roofline)
+# Algorithmic bytes per ray-step, no-reuse model (SURVEY §8d / DESIGN.md §Roofline), per kernel:
+#   fwd      8 corner reads x 4 B + 4 B frame write                         = 36 (nearest: 4 + 4 = 8)
+#   bwd scan 4 B gframe read + 8 x 4 B corner re-reads                      = 36 (nearest: 8)
+#   scatter  8 corners x (4 B read + 4 B write) atomic RMW on the gradient  = 64 (nearest: 8)
 BYTES = {
-    "trilinear": {"fwd": 36, "bwd": 100, "bwd_pose_only": 36},
-    "nearest": {"fwd": 8, "bwd": 16, "bwd_pose_only": 8},
+    "trilinear": {"render_fwd_kernel": 36, "render_bwd_kernel": 36, "scatter_patch_kernel": 64},
+    "nearest": {"render_fwd_kernel": 8, "render_bwd_kernel": 8, "scatter_patch_kernel": 8},
 }
 HBM_PEAK_GBS = 8000.0
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+
+
+def vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
 class HotPath:
@@ -57,18 +69,18 @@ class HotPath:
         self.S, self.start, self.alpha = S, start, alpha
         self.sampler = {"nearest": 0, "trilinear": 1}[sampler]
         dev = vol.device
-        N1 = S - start
-        self.frame = torch.empty((self.P, self.R, N1), dtype=torch.float32, device=dev)
+        self.N1 = S - start
+        self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
         self.gframe = torch.empty_like(self.frame)
         d0, d1, d2 = vol.shape
+        self.dims = (d0, d1, d2)
         self.gvol = torch.empty_like(vol) if want_gvol else None       # canonical gradient, what the caller gets
         if self.layout == 1:
             # HBM-resident bricked copy of the (constant) volume, made once outside the timed region;
             # the bricked gradient scratch is zeroed, filled and converted back EVERY step.
             nb = self.lib.diffus_bricked_floats(d0, d1, d2)
             self.vol_k = torch.empty(nb, dtype=torch.float32, device=dev)
-            _lib.check(self.lib.diffus_brick_volume(C.c_void_p(vol.data_ptr()), d0, d1, d2,
-                                                    C.c_void_p(self.vol_k.data_ptr()), self.stream()), "brick")
+            _lib.check(self.lib.diffus_brick_volume(vp(vol), d0, d1, d2, vp(self.vol_k), self.stream()), "brick")
             self.gvol_k = torch.empty(nb, dtype=torch.float32, device=dev) if want_gvol else None
         else:
             self.vol_k, self.gvol_k = vol, self.gvol
@@ -77,29 +89,24 @@ class HotPath:
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
         nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, S, start), 256)
         self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        self.dims = (d0, d1, d2)
-        self.common = (C.c_void_p(self.vol_k.data_ptr()), d0, d1, d2, self.layout, C.c_void_p(src.data_ptr()), 0,
-                       C.c_void_p(dirs.data_ptr()), 0, self.P, self.R, S, start, float(alpha), self.sampler)
+        self.common = (vp(self.vol_k), d0, d1, d2, self.layout, vp(src), 0, vp(dirs), 0, self.P, self.R, S, start,
+                       float(alpha), self.sampler)
 
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def fwd(self):
-        rc = self.lib.diffus_render_fwd(*self.common, C.c_void_p(self.frame.data_ptr()), None,
-                                        C.c_void_p(self.ws.data_ptr()), self.ws.numel(), self.stream())
-        _lib.check(rc, "diffus_render_fwd")
+        _lib.check(self.lib.diffus_render_fwd(*self.common, vp(self.frame), None, vp(self.ws), self.ws.numel(),
+                                              self.stream()), "diffus_render_fwd")
 
-    def bwd(self):
-        rc = self.lib.diffus_render_bwd(*self.common, C.c_void_p(self.gframe.data_ptr()),
-                                        C.c_void_p(self.gvol_k.data_ptr()) if self.gvol_k is not None else None,
-                                        C.c_void_p(self.gsrc.data_ptr()), C.c_void_p(self.gdirs.data_ptr()),
-                                        C.c_void_p(self.ws.data_ptr()), self.ws.numel(), self.stream())
-        _lib.check(rc, "diffus_render_bwd")
+    def bwd(self, stages=_lib.BWD_ALL):
+        _lib.check(self.lib.diffus_render_bwd(*self.common, vp(self.gframe), vp(self.gvol_k), vp(self.gsrc),
+                                              vp(self.gdirs), stages, vp(self.ws), self.ws.numel(), self.stream()),
+                   "diffus_render_bwd")
 
     def loss_and_grad(self):
-        # L_p = sum(frame_p^2); dL/dframe = 2 frame
-        torch.mul(self.frame, 2.0, out=self.gframe)
-        torch.sum(self.frame * self.frame, dim=(1, 2), out=self.loss)
+        _lib.check(self.lib.diffus_loss_sumsq(vp(self.frame), self.P, self.R * self.N1, vp(self.loss),
+                                              vp(self.gframe), self.stream()), "diffus_loss_sumsq")
 
     def zero_grad(self):
         if self.gvol_k is not None:
@@ -108,9 +115,8 @@ class HotPath:
     def finish_grad(self):
         """bricked gradient -> the caller's canonical (d0,d1,d2) tensor."""
         if self.layout == 1 and self.gvol is not None:
-            rc = self.lib.diffus_unbrick_volume(C.c_void_p(self.gvol_k.data_ptr()), *self.dims,
-                                                C.c_void_p(self.gvol.data_ptr()), 0, self.stream())
-            _lib.check(rc, "diffus_unbrick_volume")
+            _lib.check(self.lib.diffus_unbrick_volume(vp(self.gvol_k), *self.dims, vp(self.gvol), 0, self.stream()),
+                       "diffus_unbrick_volume")
 
     def step(self):
         self.fwd()
@@ -120,17 +126,19 @@ class HotPath:
         self.finish_grad()
 
 
-def time_events(fn, iters):
-    """Average device time of fn() in ms, HIP events on the current (launch) stream."""
+def time_events(fn, iters, pre=None):
+    """Device time of fn() in ms (mean, median, min): HIP events on the current (launch) stream."""
     e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     for i in range(iters):
+        if pre is not None:
+            pre()
         e0[i].record()
         fn()
         e1[i].record()
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
-    return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+    return {"mean": sum(ts) / len(ts), "median": ts[len(ts) // 2], "min": ts[0]}
 
 
 def cpu_baseline(budget_rays=64, budget_steps=256):
@@ -172,7 +180,7 @@ def cpu_baseline(budget_rays=64, budget_steps=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--poses", type=int, default=32, help="poses per GPU")
     ap.add_argument("--rays", type=int, default=256)
@@ -181,6 +189,7 @@ def main():
     ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
     ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
     ap.add_argument("--layout", default="bricked", choices=["bricked", "canonical"])
+    ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alpha", type=float, default=1e-4)
     args = ap.parse_args()
@@ -211,8 +220,27 @@ def main():
                  layout=args.layout)
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
 
+    # --- the step: eager launches, or one captured hipGraph (compute) + the collective ---
+    graph = None
+    side = torch.cuda.Stream()
+    if not args.eager:
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    hp.step()
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                hp.step()
+        except Exception as e:  # capture unsupported -> eager, and say so
+            print(f"hipGraph capture failed ({e!r}); running eagerly", file=sys.stderr)
+            graph = None
+
     def step():
-        hp.step()
+        if graph is not None:
+            graph.replay()
+        else:
+            hp.step()
         if dist is not None:
             dist.all_gather_into_tensor(losses_all, hp.loss)   # the one collective: P losses over xGMI
 
@@ -236,26 +264,47 @@ def main():
     ray_steps = P_total * args.rays * args.samples
     value = ray_steps * args.steps / dt
 
-    # per-kernel device time (HIP events on the launch stream), rank-local
+    # --- per-kernel device time (HIP events on the launch stream), rank-local ---
     it = max(10, min(args.steps, 50))
-    fwd_ms = time_events(hp.fwd, it)
-    bwd_ms = time_events(hp.bwd, it)
+    hp.fwd(); hp.loss_and_grad()
+    k_ms = {"render_fwd_kernel": time_events(hp.fwd, it),
+            "render_bwd_kernel": time_events(lambda: hp.bwd(_lib.BWD_SCAN), it)}
+    if not args.no_gvol:
+        k_ms["scatter_patch_kernel"] = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), it, pre=hp.zero_grad)
     local_rs = args.poses * args.rays * args.samples
     b = BYTES[args.sampler]
-    bwd_bytes = b["bwd_pose_only"] if args.no_gvol else b["bwd"]
-    dom = "bwd" if bwd_ms[0] >= fwd_ms[0] else "fwd"
-    dom_ms = bwd_ms[0] if dom == "bwd" else fwd_ms[0]
-    dom_bytes = (bwd_bytes if dom == "bwd" else b["fwd"]) * local_rs
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    dom = max(k_ms, key=lambda k: k_ms[k]["mean"])
+    dom_ms = k_ms[dom]["mean"]
+    achieved = b[dom] * local_rs / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    if os.path.exists(PMC_SUMMARY):      # HBM bytes per launch from the committed PMC passes (profiles/)
+        try:
+            pm = json.load(open(PMC_SUMMARY))
+            if pm.get("workload_ray_steps") == local_rs and pm.get("sampler") == args.sampler:
+                traffic = pm["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
 
-    # single-pose latency (BASELINE config 2): 1 pose, fwd + bwd
+    # --- single-pose latency (BASELINE config 2): 1 pose, fwd + bwd, eager and graph-replayed ---
     hp1 = HotPath(vol, src[:1].contiguous(), dirs[:1].contiguous(), args.samples, args.alpha, args.sampler,
                   want_gvol=not args.no_gvol, layout=args.layout)
     for _ in range(5):
         hp1.step()
     sp = time_events(hp1.step, 20)
+    sp_graph = None
+    try:
+        with torch.cuda.stream(side):
+            hp1.step()
+        side.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=side):
+            hp1.step()
+        sp_graph = time_events(g1.replay, 20)
+    except Exception:
+        pass
 
     if rank == 0:
+        grads = "d/dsource, d/ddirections" if args.no_gvol else "d/dvolume, d/dsource, d/ddirections"
         out = {
             "metric": "ray-steps/sec fwd+bwd",
             "value": value,
@@ -270,30 +319,32 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE config {'3' if ngpu == 1 else '4-style'}: {args.poses} poses/GPU x {args.rays} rays x "
-                             f"{args.samples} steps through a {args.n}^3 analytic head phantom; {args.sampler} sampling; "
-                             f"forward + backward ({'d/dsource, d/ddirections' if args.no_gvol else 'd/dvolume, d/dsource, d/ddirections'}) "
-                             f"+ per-pose loss gather"),
+                "workload": (f"BASELINE config {'3' if ngpu == 1 else '4-style'}: {args.poses} poses/GPU x "
+                             f"{args.rays} rays x {args.samples} steps through a {args.n}^3 analytic head phantom; "
+                             f"{args.sampler} sampling; forward + sum-of-squares loss + backward ({grads}) "
+                             f"+ canonical gradient + per-pose loss gather"),
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": 0, "alpha": args.alpha,
-                "layout": args.layout,
+                "layout": args.layout, "issue": "hipGraph replay" if graph is not None else "eager",
                 "parallelism": f"poses sharded x{ngpu}, volume replicated",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"render_{dom}_kernel",
+                "kernel": dom,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "bytes_per_ray_step": dom_bytes / local_rs,
+                "traffic": traffic,
+                "bytes_per_ray_step": b[dom],
+                "ray_steps_per_launch": local_rs,
                 "launch_ms": dom_ms,
-                "fwd_ms": {"mean": fwd_ms[0], "median": fwd_ms[1], "min": fwd_ms[2]},
-                "bwd_ms": {"mean": bwd_ms[0], "median": bwd_ms[1], "min": bwd_ms[2]},
+                "kernels_ms": k_ms,
+                "whole_step_algorithmic_GBs": (sum(b[k] for k in k_ms) * local_rs) / (dt / args.steps) / 1e9,
             },
-            "single_pose": {"workload": "BASELINE config 2: 1 pose, fwd+bwd", "ms_per_step": sp[1],
-                            "value": args.rays * args.samples / (sp[1] * 1e-3)},
+            "single_pose": {"workload": "BASELINE config 2: 1 pose x 256 rays x 512 steps, fwd+bwd",
+                            "eager_ms": sp["median"], "graph_ms": sp_graph["median"] if sp_graph else None,
+                            "value": args.rays * args.samples / ((sp_graph or sp)["median"] * 1e-3)},
         }
         if ngpu == 1 and not args.no_cpu_baseline:
             try:

@@ -13,11 +13,13 @@ LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so
 
 EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
            "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume",
-           "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces")
+           "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces",
+           "diffus_loss_sumsq")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED = 0, 1
+BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
 MAX_SAMPLES = 1024
 
 _lib = None
@@ -47,7 +49,9 @@ def load():
     lib.diffus_render_fwd.restype = i
     lib.diffus_render_fwd.argtypes = common + [vp, vp, vp, sz, vp]
     lib.diffus_render_bwd.restype = i
-    lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, vp, sz, vp]
+    lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, i, vp, sz, vp]
+    lib.diffus_loss_sumsq.restype = i
+    lib.diffus_loss_sumsq.argtypes = [vp, i, C.c_long, vp, vp, vp]
     lib.diffus_trace_rays.restype = i
     lib.diffus_trace_rays.argtypes = [vp, i, i, i, i, vp, i, vp, i, i, i, i, i, vp, vp, vp, vp]
     lib.diffus_bricked_floats.restype = sz

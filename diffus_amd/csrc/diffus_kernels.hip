@@ -935,19 +935,27 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
                 atomicAdd(&tile[e], __float2int_rn(ldexpf(v, fx)));
             });
     __syncthreads();
+    // Flush every touched entry once.  No integer division per entry (the first version's
+    // e -> (i,j,k) by three divisions was 80 us of VALU at config 3): walk (i, m = j*b2+k)
+    // and split m with one exact float-reciprocal division by the tiny b2.
     const int b12 = b1 * b2;
-    for (int e = tid; e < nt; e += kBlock) {
-        int v = tile[e];
-        if (v != 0) {
-            int u = e / UNIT, o = e - u * UNIT;
-            int i = u / b12, rem = u - i * b12;
-            int j = rem / b2, k = rem - j * b2;
-            long g;
-            if (LAYOUT == DIFFUS_CANONICAL)
-                g = ((long)(l0 + i) * A.G.d1 + (l1 + j)) * A.G.d2 + (l2 + k);
-            else
-                g = (((long)(l0 + i) * A.G.nb1 + (l1 + j)) * A.G.nb2 + (l2 + k)) * kBrickFloats + o;
-            atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
+    const float rb2 = __frcp_rn((float)b2);
+    constexpr int LPU = (UNIT == 1) ? 1 : UNIT;          // lanes per tile unit
+    const int o = (UNIT == 1) ? 0 : (tid & (LPU - 1));   // float inside the brick
+    const int msub = tid / LPU, mstep = kBlock / LPU;
+    for (int i = 0; i < b0; ++i) {
+        for (int m = msub; m < b12; m += mstep) {
+            int v = tile[(i * b12 + m) * UNIT + o];
+            if (v != 0) {
+                int j = __float2int_rz(((float)m + 0.5f) * rb2); // exact: m < 2^14, b2 <= 2^14
+                int k = m - j * b2;
+                long g;
+                if (LAYOUT == DIFFUS_CANONICAL)
+                    g = ((long)(l0 + i) * A.G.d1 + (l1 + j)) * A.G.d2 + (l2 + k);
+                else
+                    g = (((long)(l0 + i) * A.G.nb1 + (l1 + j)) * A.G.nb2 + (l2 + k)) * kBrickFloats + o;
+                atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
+            }
         }
     }
 }
@@ -1190,6 +1198,44 @@ __global__ __launch_bounds__(kBlock) void brick_convert_kernel(const float *__re
 }
 
 // ----------------------------------------------------------------------------
+// Energy loss used by the benchmarks and examples: loss[p] = sum(frame[p]^2),
+// gframe = 2 * frame, in one pass (float4 streaming; one block per pose, fixed
+// reduction order => deterministic).
+__global__ __launch_bounds__(1024) void loss_sumsq_kernel(const float *__restrict__ frame, float *__restrict__ loss,
+                                                          float *__restrict__ gframe, long n)
+{
+    __shared__ float sm[16];
+    const float *f = frame + (long)blockIdx.x * n;
+    float *g = gframe ? gframe + (long)blockIdx.x * n : nullptr;
+    float acc = 0.f;
+    const bool vec = ((n & 3) == 0) && ((((uintptr_t)f) & 15) == 0) && (!g || (((uintptr_t)g) & 15) == 0);
+    if (vec) {
+        const float4 *f4 = reinterpret_cast<const float4 *>(f);
+        float4 *g4 = reinterpret_cast<float4 *>(g);
+        for (long i = threadIdx.x; i < n / 4; i += blockDim.x) {
+            float4 v = f4[i];
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (g) g4[i] = make_float4(2.f * v.x, 2.f * v.y, 2.f * v.z, 2.f * v.w);
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += blockDim.x) {
+            float v = f[i];
+            acc += v * v;
+            if (g) g[i] = 2.f * v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+        loss[blockIdx.x] = t;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // host side
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -1416,35 +1462,39 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, cons
 
 int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
-                      const float *gframe, float *gvol, float *gsrc, float *gdirs, void *workspace,
+                      const float *gframe, float *gvol, float *gsrc, float *gdirs, int stages, void *workspace,
                       size_t workspace_bytes, diffus_stream_t stream)
 {
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
     if (!gframe) return DIFFUS_EINVAL;
+    if (stages < 1 || stages > DIFFUS_BWD_ALL) return DIFFUS_EINVAL;
     if (!gvol && !gsrc && !gdirs) return DIFFUS_OK;
+    const bool do_scan = stages & DIFFUS_BWD_SCAN, do_scatter = stages & DIFFUS_BWD_SCATTER;
     Workspace ws = carve(workspace, P, R, S - start);
     if (!workspace || workspace_bytes < ws.bytes) return DIFFUS_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool pose = sampler == DIFFUS_TRILINEAR && (gsrc || gdirs);
-    if (sampler == DIFFUS_NEAREST) { // integer indices: no pose gradient (reference :754-758)
+    if (sampler == DIFFUS_NEAREST && do_scan) { // integer indices: no pose gradient (reference :754-758)
         if (gsrc && hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)P * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
         if (gdirs && hipMemsetAsync(gdirs, 0, sizeof(float) * (size_t)P * R * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
-        if (!gvol) return DIFFUS_OK;
     }
+    if (sampler == DIFFUS_NEAREST && !gvol) return DIFFUS_OK;
     Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.gframe = gframe;
     A.gvol = gvol;
     A.zbar = gvol ? ws.zbar : nullptr;
     A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
     A.gdirs = pose ? gdirs : nullptr;
-    if (start > 0) { // recompute the median (and zero gmed)
-        rc = launch_median(A, sampler, layout, st);
+    if (do_scan) {
+        if (start > 0) { // recompute the median (and zero gmed)
+            rc = launch_median(A, sampler, layout, st);
+            if (rc) return rc;
+        }
+        rc = launch_bwd(A, sampler, layout, pose, st);
         if (rc) return rc;
     }
-    rc = launch_bwd(A, sampler, layout, pose, st);
-    if (rc) return rc;
-    if (gvol) {
+    if (gvol && do_scatter) {
         const int rgs = (R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
         const unsigned nb = (unsigned)((long)P * rgs * sgs);
         rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
@@ -1454,7 +1504,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
         });
         if (rc) return rc;
     }
-    if (start > 0) {
+    if (start > 0 && do_scan) {
         const unsigned nb = (unsigned)((P + 63) / 64);
         rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
             hipLaunchKernelGGL((median_bwd_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nb), dim3(64), 0, st, A);
@@ -1462,7 +1512,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
         });
         if (rc) return rc;
     }
-    if (pose && gsrc) {
+    if (pose && gsrc && do_scan) {
         hipLaunchKernelGGL(reduce_gsrc_kernel, dim3(P), dim3(kBlock), 0, st, ws.gsrc_part, gsrc, R);
         if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
     }
@@ -1487,6 +1537,13 @@ int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout, cons
                            A, imp, refl, (long long *)idx);
         return last_launch();
     });
+}
+
+int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe, diffus_stream_t stream)
+{
+    if (!frame || !loss || P <= 0 || n <= 0) return DIFFUS_EINVAL;
+    hipLaunchKernelGGL(loss_sumsq_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, frame, loss, gframe, n);
+    return last_launch();
 }
 
 int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stream_t stream)

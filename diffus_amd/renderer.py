@@ -251,7 +251,7 @@ class _RenderFn(torch.autograd.Function):
             gsrc = torch.empty((pb.P, 3), dtype=torch.float32, device=pb.dev) if need_s else None
             gdirs = torch.empty((pb.P, pb.R, 3), dtype=torch.float32, device=pb.dev) if need_d else None
             ws = pb.workspace()
-            rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(gsrc), _ptr(gdirs),
+            rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(gsrc), _ptr(gdirs), _lib.BWD_ALL,
                                        _ptr(ws), ws.numel(), _stream(pb.dev))
         _lib.check(rc, "diffus_render_bwd")
         out_v = None

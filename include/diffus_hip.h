@@ -125,13 +125,23 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
  *   gdirs  nullable (P,R,3) float32, overwritten (trilinear only, else zeros)
  * With start > 0 the median written into column 0 (reference :243-244) routes
  * its gradient to the ray that supplied the median, like torch.median.
+ *
+ * `stages` selects which launches run: DIFFUS_BWD_SCAN (the per-ray adjoint
+ * scan: pose gradients, and d L/d impedance per sample into the workspace),
+ * DIFFUS_BWD_SCATTER (workspace -> gvol through LDS tiles), or DIFFUS_BWD_ALL.
+ * Running them as two calls with the same workspace equals one ALL call; it
+ * exists so the scatter can be timed / overlapped on its own.
  */
+#define DIFFUS_BWD_SCAN    1
+#define DIFFUS_BWD_SCATTER 2
+#define DIFFUS_BWD_ALL     3
 int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout,
                       const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype,
                       int P, int R, int S, int start, float alpha, int sampler,
                       const float *gframe,
                       float *gvol, float *gsrc, float *gdirs,
+                      int stages,
                       void *workspace, size_t workspace_bytes,
                       diffus_stream_t stream);
 
@@ -159,6 +169,14 @@ int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout,
  */
 int diffus_echo_traces(const float *refl, int B, int N, float *echo,
                        diffus_stream_t stream);
+
+/*
+ * Utility, not a reference function: the energy loss the benchmarks and examples
+ * optimise.  loss[p] = sum(frame[p,:]^2) over the n floats of pose p, and (if
+ * gframe != NULL) gframe = d loss / d frame = 2 * frame, in one streaming pass.
+ */
+int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe,
+                      diffus_stream_t stream);
 
 #ifdef __cplusplus
 }
