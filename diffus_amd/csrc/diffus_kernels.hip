@@ -773,6 +773,15 @@ __global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
 #ifndef DIFFUS_TILE_CAP
 #define DIFFUS_TILE_CAP (12 * 1024)
 #endif
+#ifdef DIFFUS_STAMP // diagnostic build only (tools/): per-block phase timestamps of the scatter kernel
+__device__ unsigned long long *g_stamps = nullptr;
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(i) ((void)0)
+#endif
 constexpr int kPatchRays = DIFFUS_PATCH_RAYS;
 constexpr int kPatchSteps = DIFFUS_PATCH_STEPS;
 constexpr int kTileCap = DIFFUS_TILE_CAP; // floats (48 KiB: 3 blocks per CU)
@@ -856,6 +865,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     const bool ray_ok = ray < A.R;
     const long w = (long)pose * A.R + (ray_ok ? ray : 0);
 
+    STAMP(0);
     if (tid < 3) {
         s_lo[tid] = 0x7fffffff;
         s_hi[tid] = -1;
@@ -883,6 +893,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
             }
         }
     }
+    STAMP(1);
     // block bounding box: wave reduce, then one LDS atomic per wave
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -904,6 +915,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         atomicMax(&s_max, __float_as_int(zmax)); // non-negative floats order like their bit patterns
     }
     __syncthreads();
+    STAMP(2);
     const int l0 = s_lo[0], l1 = s_lo[1], l2 = s_lo[2];
     if (s_hi[0] < 0) return; // nothing to add in this patch (block-uniform)
     const int b0 = s_hi[0] - l0 + 1, b1 = s_hi[1] - l1 + 1, b2 = s_hi[2] - l2 + 1;
@@ -922,6 +934,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     const int fx = 20 - __builtin_amdgcn_frexp_expf(__int_as_float(s_max)); // max|zbar| * 2^fx in [2^19, 2^20)
     for (int e = tid; e < nt; e += kBlock) tile[e] = 0;
     __syncthreads();
+    STAMP(3);
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q)
         if (zb[q] != 0.f)
@@ -935,6 +948,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
                 atomicAdd(&tile[e], __float2int_rn(ldexpf(v, fx)));
             });
     __syncthreads();
+    STAMP(4);
     // Flush every touched entry once.  No integer division per entry (the first version's
     // e -> (i,j,k) by three divisions was 80 us of VALU at config 3): walk (i, m = j*b2+k)
     // and split m with one exact float-reciprocal division by the tiny b2.
@@ -958,6 +972,13 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
             }
         }
     }
+    STAMP(5);
+#ifdef DIFFUS_STAMP
+    if (threadIdx.x == 0 && g_stamps) {
+        g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)nt;
+        g_stamps[(size_t)blockIdx.x * 8 + 7] = 1;
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -1545,6 +1566,13 @@ int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gfr
     hipLaunchKernelGGL(loss_sumsq_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, frame, loss, gframe, n);
     return last_launch();
 }
+
+#ifdef DIFFUS_STAMP
+int diffus_debug_set_stamps(unsigned long long *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stream_t stream)
 {

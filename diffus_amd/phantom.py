@@ -59,8 +59,8 @@ def cone_directions_np(direction, opening_angle: float, n_rays: int) -> np.ndarr
     about the normalised first two components of `direction`; dim-2 component 0.
     Computed in float64, returned as float32 (the reference builds a float32
     tensor from float64 rows)."""
-    d = np.array(direction[:2], dtype=np.float64)
-    d = d / np.linalg.norm(d)
+    d = np.array(direction[:2])          # keeps the caller's dtype, like the reference (float32 tensors
+    d = d / np.linalg.norm(d)            # are normalised in float32 there)
     ortho = np.array([-d[1], d[0]])
     ang = np.linspace(-opening_angle / 2, opening_angle / 2, n_rays)
     v = np.cos(ang)[:, None] * d[None, :] + np.sin(ang)[:, None] * ortho[None, :]

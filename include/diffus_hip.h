@@ -114,9 +114,11 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
                       diffus_stream_t stream);
 
 /*
- * Backward of diffus_render_fwd (what torch autograd would do through the
- * reference's sub-functions, SURVEY.md §3.2 / App. A.4, without storing any
- * dense system): given gframe = dL/dframe (P,R,N1) it recomputes the forward
+ * Backward of diffus_render_fwd: what torch autograd does through the
+ * reference's sub-functions custom_nearest_sampler (reference
+ * src/renderer.py:741-759) -> compute_reflection_coeff (:27-33) ->
+ * compute_echo_traces (:439-457) -> attenuation (:256-259), see SURVEY.md §3.2 /
+ * App. A.4, without storing any dense system: given gframe = dL/dframe (P,R,N1) it recomputes the forward
  * per ray and produces any of
  *   gvol   nullable, float32 in the SAME layout as vol ((d0,d1,d2) canonical or
  *          diffus_bricked_floats() bricked), ACCUMULATED with float atomics

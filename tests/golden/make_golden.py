@@ -204,9 +204,11 @@ def main():
     if want("g8"):
         out = {}
         cases = [((-0.3, -0.95), 0.85, 64), ((1.0, 0.0), 1.0471975511965976, 256), ((0.2, 0.7, 15.0), 0.3, 5),
-                 ((-1.0, 0.4), 1.2, 200), ((0.0, -3.0), 2.0, 2)]
+                 ((-1.0, 0.4), 1.2, 200), ((0.0, -3.0), 2.0, 2),
+                 (torch.tensor([-0.3, -0.95, 15.0]), 0.85, 64),          # float32 tensor, as the demos pass
+                 (torch.tensor([3, -4]), 0.5, 7)]                        # integer tensor
         for j, (dvec, op, n) in enumerate(cases):
-            out[f"c{j}_direction"] = np.array(dvec, dtype=np.float64)
+            out[f"c{j}_direction"] = np.array(dvec)            # dtype preserved: it changes the rounding
             out[f"c{j}_opening"] = np.float64(op)
             out[f"c{j}_n"] = np.int64(n)
             out[f"c{j}_out"] = ref_cone(dvec, op, n).numpy()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of scatter_patch_kernel (build with -DDIFFUS_STAMP)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["DIFFUS_LIB"] = os.path.abspath(sys.argv[1])
+from bench import HotPath
+from diffus_amd import _lib
+from diffus_amd.phantom import phantom, pose_ring
+lib = _lib.load()
+vol = torch.from_numpy(phantom(256)).cuda()
+src, dirs = pose_ring(256, 32, 256)
+hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), 512, 1e-4, "trilinear")
+hp.fwd(); hp.loss_and_grad(); hp.zero_grad(); hp.bwd(_lib.BWD_SCAN)
+nblk = 32 * 16 * 8
+st = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
+lib.diffus_debug_set_stamps.argtypes = [C.c_void_p]
+assert lib.diffus_debug_set_stamps(C.c_void_p(st.data_ptr())) == 0
+for _ in range(3):
+    st.zero_(); hp.zero_grad(); hp.bwd(_lib.BWD_SCATTER)
+torch.cuda.synchronize()
+s = st.cpu().numpy().reshape(nblk, 8)
+done = s[:, 7] == 1
+print("blocks", nblk, "completed-with-tile", done.sum(), "early-exit/fallback", (~done).sum())
+d = np.diff(s[done][:, :6].astype(np.int64), axis=1)
+names = ["load+cells", "bbox-reduce", "zero", "lds-add", "flush"]
+tot = (s[done][:, 5] - s[done][:, 0])
+print("cycles/block: mean %.0f median %.0f max %.0f" % (tot.mean(), np.median(tot), tot.max()))
+for i, n in enumerate(names):
+    print("  %-12s mean %8.0f  median %8.0f  max %8.0f  share %.1f%%" % (n, d[:, i].mean(), np.median(d[:, i]), d[:, i].max(), 100 * d[:, i].sum() / tot.sum()))
+print("tile entries: mean %.0f max %.0f" % (s[done][:, 6].mean(), s[done][:, 6].max()))
+nd = s[~done]
+if len(nd):
+    e = (nd[:, 2] > 0)
+    print("not-done blocks that reached bbox:", e.sum())
+span = s[:, :6][s[:, :6] > 0]
+print("kernel span (cycles, min start..max end): %.0f" % (span.max() - span.min()))

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<TAG>/ (tools/collect_profiles.sh) into committed summaries under profiles/:
+  profiles/<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats, copied as is
+  profiles/<TAG>_kernel_times.txt    per-kernel median/max of the batch (largest-grid) launches
+  profiles/<TAG>_pmc_summary.json    HBM-side bytes per launch per kernel, corrected as
+                                     MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE (KiB) x 2 (gfx950
+                                     tallies 128-B reads as 64 B; confirmed here on brick_convert_kernel,
+                                     a known 64 MiB read) + WRITE_SIZE (KiB, exact)
+bench.py reads the JSON to fill roofline.traffic.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("<")[0].split("(")[0]
+
+
+def rows(pattern):
+    f = glob.glob(os.path.join(src, pattern))
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+# 1. kernel stats as produced by rocprofv3
+ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if ks:
+    shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
+
+# 2. per-kernel durations of the batch launches (largest grid of each kernel = the P=32 workload)
+tr = rows("trace/**/*kernel_trace.csv") or rows("trace/*/*kernel_trace.csv")
+by = collections.defaultdict(list)
+for r in tr:
+    g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    by[short(r["Kernel_Name"])].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+lines = []
+dur = {}
+for k, v in sorted(by.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+    g = max(x for x, _ in v)
+    d = sorted(t for x, t in v if x == g)
+    dur[k] = {"launches": len(d), "avg_us": sum(d) / len(d), "median_us": d[len(d) // 2], "max_us": d[-1], "grid_threads": g}
+    lines.append("%-28s grid=%9d launches=%4d avg=%8.1f us median=%8.1f us max=%8.1f us" % (k, g, len(d), dur[k]["avg_us"], dur[k]["median_us"], d[-1]))
+open(f"profiles/{tag}_kernel_times.txt", "w").write(
+    "# batch launches (largest grid per kernel) from rocprofv3 --kernel-trace; bench.py --steps 30 --eager\n" + "\n".join(lines) + "\n")
+
+# 3. PMC passes
+def pmc(name):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows(f"pmc_{name}/*/*counter_collection.csv"):
+        out[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    res = {}
+    for k, cs in out.items():
+        res[k] = {}
+        for c, v in cs.items():
+            g = max(x for x, _ in v)
+            vals = sorted(t for x, t in v if x == g)
+            res[k][c] = vals[len(vals) // 2]
+    return res
+
+
+fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
+tcc, atom = pmc("TCC_HIT_sum_TCC_MISS_sum"), pmc("TCC_EA0_ATOMIC_sum")
+summary = {"tag": tag, "workload_ray_steps": 32 * 256 * 512, "sampler": "trilinear",
+           "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  [FETCH_SIZE x2 on gfx950]",
+           "calibration": {}, "kernels": {}}
+if "brick_convert_kernel" in fetch:
+    summary["calibration"] = {"kernel": "brick_convert_kernel (reads 64 MiB, writes 64 MiB)",
+                              "FETCH_SIZE_KiB": fetch["brick_convert_kernel"].get("FETCH_SIZE"),
+                              "WRITE_SIZE_KiB": write.get("brick_convert_kernel", {}).get("WRITE_SIZE"),
+                              "expected_KiB": 65536}
+for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "brick_convert_kernel", "loss_sumsq_kernel"):
+    if k not in fetch:
+        continue
+    f, w = fetch[k].get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
+    e = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+    if k in tcc:
+        h, m = tcc[k].get("TCC_HIT_sum", 0), tcc[k].get("TCC_MISS_sum", 0)
+        e["l2_hit_rate"] = h / (h + m) if h + m else None
+    if k in atom:
+        e["TCC_EA0_ATOMIC"] = atom[k].get("TCC_EA0_ATOMIC_sum")
+    if k in dur:
+        e.update({"avg_us": dur[k]["avg_us"], "median_us": dur[k]["median_us"]})
+    summary["kernels"][k] = e
+json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+print(open(f"profiles/{tag}_kernel_times.txt").read())
+print(json.dumps(summary, indent=1))
