@@ -100,16 +100,35 @@ __device__ __forceinline__ Mat mat_scale(const Mat &m, int e)
 __device__ __forceinline__ int mat_renorm(Mat &m)
 {
     float mx = fmaxf(fmaxf(fabsf(m.a), fabsf(m.b)), fmaxf(fabsf(m.c), fabsf(m.d)));
-    int ex = 0;
-    if (mx > 0.f && mx < __builtin_inff()) {
-        ex = __builtin_amdgcn_frexp_expf(mx);
-        m = mat_scale(m, -ex);
-    }
+    // v_frexp_exp_i32_f32 returns 0 for +-0, inf and NaN: no branch needed, ldexp(x, 0) is a no-op
+    int ex = __builtin_amdgcn_frexp_expf(mx);
+    m = mat_scale(m, -ex);
     return ex;
 }
 
 __device__ __forceinline__ bool finitef(float x) { return fabsf(x) < __builtin_inff(); }
 __device__ __forceinline__ bool mat_finite(const Mat &m) { return finitef(m.a) && finitef(m.b) && finitef(m.c) && finitef(m.d); }
+
+// Wave-wide min/max of an int by the classic DPP ladder (row_shr 1,2,3,4,8, row_bcast 15,31):
+// 7 VALU+DPP steps instead of 6 ds_bpermute round trips.  Result valid in every lane (readlane 63).
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_reduce_minmax(int v)
+{
+#define DIFFUS_DPP_STEP(ctrl, rmask, bmask)                                                   \
+    {                                                                                         \
+        int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, bmask, false);                 \
+        v = IS_MIN ? min(v, o) : max(v, o);                                                   \
+    }
+    DIFFUS_DPP_STEP(0x111, 0xf, 0xf) // row_shr:1
+    DIFFUS_DPP_STEP(0x112, 0xf, 0xf) // row_shr:2
+    DIFFUS_DPP_STEP(0x113, 0xf, 0xf) // row_shr:3
+    DIFFUS_DPP_STEP(0x114, 0xf, 0xe) // row_shr:4
+    DIFFUS_DPP_STEP(0x118, 0xf, 0xc) // row_shr:8
+    DIFFUS_DPP_STEP(0x142, 0xa, 0xf) // row_bcast:15
+    DIFFUS_DPP_STEP(0x143, 0xc, 0xf) // row_bcast:31
+#undef DIFFUS_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 __device__ __forceinline__ Mat mat_shfl_up(const Mat &m, int off)
 {
@@ -131,9 +150,21 @@ struct Pose {
     int pmode; // 0: f32 src, f32 dir; 1: f64 src, f32 dir; 2: f64 dir (src any)
 };
 
+// PM = 0: both inputs are f32 (the common case) -- compile-time: no f64 code, no mode branches.
+// PM = 1: dtypes resolved at run time.
+template <int PM = 1>
 __device__ __forceinline__ void load_pose(Pose &ps, const void *src, int src_f64, const void *dirs, int dir_f64,
                                           long pose, long ray_lin)
 {
+    if (PM == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ps.sf[c] = ((const float *)src)[pose * 3 + c];
+            ps.df[c] = ((const float *)dirs)[ray_lin * 3 + c];
+        }
+        ps.pmode = 0;
+        return;
+    }
     for (int c = 0; c < 3; ++c) {
         if (src_f64) {
             ps.sd[c] = ((const double *)src)[pose * 3 + c];
@@ -155,10 +186,11 @@ __device__ __forceinline__ void load_pose(Pose &ps, const void *src, int src_f64
 
 // p_c = source_c + float(k) * dir_c with the reference's rounding sequence
 // (src/renderer.py:119-124, cast to f32 at :751).  No FMA contraction.
+template <int PM = 1>
 __device__ __forceinline__ float ray_point(const Pose &ps, int c, int k)
 {
     float stepf = (float)k;
-    if (ps.pmode == 0) {
+    if (PM == 0 || ps.pmode == 0) {
         return __fadd_rn(ps.sf[c], __fmul_rn(stepf, ps.df[c]));
     } else if (ps.pmode == 1) {
         float t = __fmul_rn(stepf, ps.df[c]);
@@ -195,14 +227,16 @@ struct Geom {
     int nb1, nb2; // bricks along dim 1 / dim 2
 };
 
+// 32-bit element offsets (the host refuses volumes of 2^30 floats or more): 64-bit address
+// arithmetic was 28 % of the forward kernel's instructions.
 template <int LAYOUT>
-__device__ __forceinline__ long vox_off(const Geom &G, int x, int y, int z)
+__device__ __forceinline__ unsigned vox_off(const Geom &G, int x, int y, int z)
 {
     if (LAYOUT == DIFFUS_CANONICAL) {
-        return ((long)x * G.d1 + y) * G.d2 + z;
+        return ((unsigned)x * (unsigned)G.d1 + (unsigned)y) * (unsigned)G.d2 + (unsigned)z;
     } else {
-        long brick = ((long)(x >> 2) * G.nb1 + (y >> 2)) * G.nb2 + (z >> 1);
-        return brick * kBrickFloats + (((x & 3) << 3) | ((y & 3) << 1) | (z & 1));
+        unsigned brick = ((unsigned)(x >> 2) * (unsigned)G.nb1 + (unsigned)(y >> 2)) * (unsigned)G.nb2 + (unsigned)(z >> 1);
+        return brick * kBrickFloats + (unsigned)(((x & 3) << 3) | ((y & 3) << 1) | (z & 1));
     }
 }
 
@@ -237,23 +271,25 @@ __device__ __forceinline__ void load_zpair(const float *__restrict__ vol, const 
                                            float &lo, float &hi)
 {
     if (LAYOUT == DIFFUS_CANONICAL) {
-        const float *row = vol + ((long)x * G.d1 + y) * G.d2;
+        const unsigned row = ((unsigned)x * (unsigned)G.d1 + (unsigned)y) * (unsigned)G.d2;
         if (G.d2 >= 2) {
             int b = min(c.i0, G.d2 - 2);
-            F2 v = *reinterpret_cast<const F2 *>(row + b);
+            F2 v = *reinterpret_cast<const F2 *>(vol + (row + (unsigned)b));
             lo = (c.i0 == b) ? v.x : v.y;
             hi = v.y;
         } else {
-            lo = hi = row[0];
+            lo = hi = vol[row];
         }
     } else {
-        if (!(c.i0 & 1) && c.i1 == c.i0 + 1) { // same brick, 8-byte aligned pair
-            float2 v = *reinterpret_cast<const float2 *>(vol + vox_off<LAYOUT>(G, x, y, c.i0));
+        // the aligned pair (z&~1, z|1) of the brick holding z0 in ONE 8-byte load; when z0 is odd
+        // its upper neighbour lives in the next brick: one more 4-byte load for those lanes only
+        float2 v = *reinterpret_cast<const float2 *>(vol + vox_off<LAYOUT>(G, x, y, c.i0 & ~1));
+        if (!(c.i0 & 1)) {
             lo = v.x;
-            hi = v.y;
+            hi = (c.i1 != c.i0) ? v.y : v.x;
         } else {
-            lo = vol[vox_off<LAYOUT>(G, x, y, c.i0)];
-            hi = vol[vox_off<LAYOUT>(G, x, y, c.i1)];
+            lo = v.y;
+            hi = (c.i1 != c.i0) ? vol[vox_off<LAYOUT>(G, x, y, c.i1)] : v.y;
         }
     }
 }
@@ -295,8 +331,16 @@ __device__ __forceinline__ TriSample tri_sample(const float *__restrict__ vol, c
     return s;
 }
 
-// reflection coefficient (reference src/renderer.py:33): IEEE f32 sub, add, div
+// reflection coefficient (reference src/renderer.py:33): IEEE f32 sub, add, div -- used by the
+// stage-wise kernels, whose outputs are compared bit for bit with the oracle
 __device__ __forceinline__ float reflect(float z1, float z2) { return __fdiv_rn(z2 - z1, z1 + z2); }
+
+// Hot-kernel arithmetic.  The fused kernels are VALU-bound (PMC: VALU busy 57 %, ~4 cycles per
+// instruction), and an IEEE f32 division is ~12 instructions, ocml expf ~20.  v_rcp_f32 / v_exp_f32
+// are accurate to ~1 ulp, far inside the 1e-5 frame tolerance; 0/0 stays NaN, x/0 stays +-inf.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float reflect_fast(float z1, float z2) { return fast_div(z2 - z1, z1 + z2); }
 
 // ----------------------------------------------------------------------------
 struct Args {
@@ -386,30 +430,112 @@ __device__ __forceinline__ void to_interleaved(float *wb, int lane, const float 
     wave_lds_sync();
 }
 
-// Impedance (and for the trilinear backward its spatial gradient) at the wave's
-// samples, INTERLEAVED mapping.  n >= N1 yields a harmless dummy.
-template <int C, int SAMPLER, int LAYOUT, bool GRAD>
+// Column / depth parts of a voxel offset: off(x,y,z) = col_off(x,y) + z_off(z).
+template <int LAYOUT>
+__device__ __forceinline__ unsigned col_off(const Geom &G, int x, int y)
+{
+    // v_mul_u32_u24 is full rate, v_mul_lo_u32 quarter rate; every factor here is < 2^24 except the
+    // final row stride, which is applied as a shift (bricked) or one 32-bit multiply (canonical)
+    if (LAYOUT == DIFFUS_CANONICAL)
+        return (__umul24((unsigned)x, (unsigned)G.d1) + (unsigned)y) * (unsigned)G.d2;
+    return ((__umul24((unsigned)(x >> 2), (unsigned)G.nb1) + (unsigned)(y >> 2)) * (unsigned)G.nb2 << 5) +
+           (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
+}
+template <int LAYOUT>
+__device__ __forceinline__ unsigned z_off(int z)
+{
+    if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)z;
+    return (unsigned)(z >> 1) * kBrickFloats + (unsigned)(z & 1);
+}
+
+// lerps of one trilinear sample from its 8 corner values (order 000,001,010,011,100,101,110,111 =
+// dim0,dim1,dim2 bits); same operation sequence as oracle/diffus_oracle.c orc_sample_trilinear
+template <bool GRAD>
+__device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a, const Axis &b, const Axis &c)
+{
+    float e00 = v[1] - v[0], e01 = v[3] - v[2], e10 = v[5] - v[4], e11 = v[7] - v[6];
+    float c00 = __fadd_rn(v[0], __fmul_rn(c.t, e00)), c01 = __fadd_rn(v[2], __fmul_rn(c.t, e01));
+    float c10 = __fadd_rn(v[4], __fmul_rn(c.t, e10)), c11 = __fadd_rn(v[6], __fmul_rn(c.t, e11));
+    float f0 = c01 - c00, f1 = c11 - c10;
+    float q0 = __fadd_rn(c00, __fmul_rn(b.t, f0)), q1 = __fadd_rn(c10, __fmul_rn(b.t, f1));
+    float g = q1 - q0;
+    TriSample s;
+    s.v = __fadd_rn(q0, __fmul_rn(a.t, g));
+    if (GRAD) {
+        float h0 = __fadd_rn(e00, __fmul_rn(b.t, e01 - e00));
+        float h1 = __fadd_rn(e10, __fmul_rn(b.t, e11 - e10));
+        s.g0 = g * a.m;
+        s.g1 = __fadd_rn(f0, __fmul_rn(a.t, f1 - f0)) * b.m;
+        s.g2 = __fadd_rn(h0, __fmul_rn(a.t, h1 - h0)) * c.m;
+    } else {
+        s.g0 = s.g1 = s.g2 = 0.f;
+    }
+    return s;
+}
+
+// Impedance (and for the trilinear backward its spatial gradient) at the wave's samples,
+// INTERLEAVED mapping.  Written for memory-level parallelism: phase A computes the addresses of
+// up to 8 samples x 8 corners and issues every load with NO branch in between (lanes past the
+// end of the ray re-read the last sample instead of being masked), phase B recomputes the cheap
+// interpolation weights and consumes the values.  The first version (load -> use per corner,
+// behind exec-mask branches) made hipcc emit `s_waitcnt vmcnt(0)` after almost every load:
+// ~50 dependent memory round trips per wave, 43 % of wave time in SQ_WAIT_ANY.
+template <int C, int SAMPLER, int LAYOUT, bool GRAD, int PM>
 __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps, int lane, float (&z)[C],
                                                    float (&g0)[C], float (&g1)[C], float (&g2)[C])
 {
+    constexpr int G = (C < 8) ? C : 8;
+    constexpr int NV = (SAMPLER == DIFFUS_NEAREST) ? 1 : 8;
+    const float *__restrict__ vol = A.vol;
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        int n = j * kWave + lane;
-        z[j] = 1.f;
-        if (GRAD) g0[j] = g1[j] = g2[j] = 0.f;
-        if (n < A.N1) {
+    for (int gb = 0; gb < C; gb += G) {
+        float raw[G][NV];
+        float ta[G], tb[G], tc[G]; // interpolation weights, kept for phase B
+        unsigned mk[G];            // border-rule bits of the three axes (gradient only)
+        // ---- phase A: addresses + loads
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            int n = min((gb + jj) * kWave + lane, A.N1 - 1);
             int k = A.start + n;
-            float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
-            if (SAMPLER == DIFFUS_NEAREST) {
+            float p0 = ray_point<PM>(ps, 0, k), p1 = ray_point<PM>(ps, 1, k), p2 = ray_point<PM>(ps, 2, k);
+            if constexpr (SAMPLER == DIFFUS_NEAREST) {
                 int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
-                z[j] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
+                raw[jj][0] = vol[col_off<LAYOUT>(A.G, i0, i1) + z_off<LAYOUT>(i2)];
             } else {
-                TriSample s = tri_sample<LAYOUT, GRAD>(A.vol, A.G, p0, p1, p2);
-                z[j] = s.v;
+                Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1), c = tri_axis(p2, A.G.d2);
+                unsigned c00 = col_off<LAYOUT>(A.G, a.i0, b.i0), c01 = col_off<LAYOUT>(A.G, a.i0, b.i1);
+                unsigned c10 = col_off<LAYOUT>(A.G, a.i1, b.i0), c11 = col_off<LAYOUT>(A.G, a.i1, b.i1);
+                unsigned z0 = z_off<LAYOUT>(c.i0), z1 = z_off<LAYOUT>(c.i1);
+                raw[jj][0] = vol[c00 + z0]; raw[jj][1] = vol[c00 + z1];
+                raw[jj][2] = vol[c01 + z0]; raw[jj][3] = vol[c01 + z1];
+                raw[jj][4] = vol[c10 + z0]; raw[jj][5] = vol[c10 + z1];
+                raw[jj][6] = vol[c11 + z0]; raw[jj][7] = vol[c11 + z1];
+                ta[jj] = a.t; tb[jj] = b.t; tc[jj] = c.t;
+                if (GRAD) mk[jj] = (a.m != 0.f ? 1u : 0u) | (b.m != 0.f ? 2u : 0u) | (c.m != 0.f ? 4u : 0u);
+            }
+        }
+        // ---- phase B: interpolation
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const int j = gb + jj;
+            const bool live = j * kWave + lane < A.N1;
+            if constexpr (SAMPLER == DIFFUS_NEAREST) {
+                z[j] = live ? raw[jj][0] : 1.f;
+                if (GRAD) g0[j] = g1[j] = g2[j] = 0.f;
+            } else {
+                Axis a, b, c;
+                a.t = ta[jj]; b.t = tb[jj]; c.t = tc[jj];
                 if (GRAD) {
-                    g0[j] = s.g0;
-                    g1[j] = s.g1;
-                    g2[j] = s.g2;
+                    a.m = (mk[jj] & 1u) ? 1.f : 0.f;
+                    b.m = (mk[jj] & 2u) ? 1.f : 0.f;
+                    c.m = (mk[jj] & 4u) ? 1.f : 0.f;
+                }
+                TriSample sm = tri_lerp<GRAD>(raw[jj], a, b, c);
+                z[j] = live ? sm.v : 1.f;
+                if (GRAD) {
+                    g0[j] = live ? sm.g0 : 0.f;
+                    g1[j] = live ? sm.g1 : 0.f;
+                    g2[j] = live ? sm.g2 : 0.f;
                 }
             }
         }
@@ -428,7 +554,7 @@ __device__ __forceinline__ void reflect_chunk(const Args &A, int n0, const float
     for (int j = 0; j < C; ++j) {
         int n = n0 + j;
         float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
-        float v = reflect(zp, z[j]);
+        float v = reflect_fast(zp, z[j]);
         if (n == 1 && A.start > 0) v = medv;
         r[j] = (n >= 1 && n < A.N1) ? v : 0.f;
     }
@@ -438,7 +564,7 @@ __device__ __forceinline__ void reflect_chunk(const Args &A, int n0, const float
 // dense solves of reference src/renderer.py:367-457).  r[j] is the reflection
 // coefficient entering sample n = lane*C + j (0 where there is none); e[j] gets
 // echo_n = (P_n)01/(P_n)11 with NaN -> 0 (reference :408).
-template <int C>
+template <int C, bool FAST = false>
 __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float (&e)[C])
 {
     // local product of the chunk, then inclusive scan over lanes (lower lanes on the left)
@@ -462,14 +588,14 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
     for (int j = 0; j < C; ++j) {
         Pm = mat_step(Pm, r[j]);
         mat_renorm(Pm);
-        float v = __fdiv_rn(Pm.b, Pm.d);
+        float v = FAST ? fast_div(Pm.b, Pm.d) : __fdiv_rn(Pm.b, Pm.d);
         e[j] = (v == v) ? v : 0.f; // nan_to_num(nan=0)
     }
 }
 
 // ----------------------------------------------------------------------------
 // FORWARD  (replaces reference src/renderer.py:201-275 with artifacts=False)
-template <int C, int SAMPLER, int LAYOUT, int WPB>
+template <int C, int SAMPLER, int LAYOUT, int WPB, int PM>
 __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
 {
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
@@ -482,19 +608,19 @@ __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
     float *wb = lds[wib];
 
     Pose ps;
-    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
     float zi[C], z[C], r[C], e[C], u0[C], u1[C], u2[C];
-    gather_interleaved<C, SAMPLER, LAYOUT, false>(A, ps, lane, zi, u0, u1, u2);
+    gather_interleaved<C, SAMPLER, LAYOUT, false, PM>(A, ps, lane, zi, u0, u1, u2);
     to_chunked<C>(wb, lane, zi, z);
     float zprev = __shfl_up(z[C - 1], 1, kWave);
     float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, n0, z, zprev, medv, r);
-    echo_chunk<C>(r, lane, e);
+    echo_chunk<C, true>(r, lane, e);
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        // attenuation, reference :256-259: f32(-alpha) * f32(n), expf, multiply
-        float att = expf(__fmul_rn(A.neg_alpha, (float)(n0 + j)));
+        // attenuation, reference :256-259: f32(-alpha) * f32(n), exp, multiply
+        float att = fast_exp(__fmul_rn(A.neg_alpha, (float)(n0 + j)));
         e[j] = __fmul_rn(e[j], att);
     }
     to_interleaved<C>(wb, lane, e, zi);
@@ -513,9 +639,9 @@ __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
             int n = j * kWave + lane;
             if (n < A.N1) {
                 int k = A.start + n;
-                ix[n] = nearest_index(ray_point(ps, 0, k), A.G.d0);
-                ix[plane + n] = nearest_index(ray_point(ps, 1, k), A.G.d1);
-                ix[2 * plane + n] = nearest_index(ray_point(ps, 2, k), A.G.d2);
+                ix[n] = nearest_index(ray_point<PM>(ps, 0, k), A.G.d0);
+                ix[plane + n] = nearest_index(ray_point<PM>(ps, 1, k), A.G.d1);
+                ix[2 * plane + n] = nearest_index(ray_point<PM>(ps, 2, k), A.G.d2);
             }
         }
     }
@@ -531,7 +657,7 @@ __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
 // W_n = 2^{e_n-e_{n-1}} (Gbar'_n + U'_n):  Tbar_n = P'_{n-1}^T W_n,  U'_{n-1} = W_n T_n^T.
 // The chunk of one lane is an affine map U_in -> U_out; lanes are combined with a
 // reverse Hillis-Steele scan of affine maps (A, B, beta):  X -> A + X (B 2^beta)^T.
-template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB>
+template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM>
 __global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
 {
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
@@ -545,10 +671,10 @@ __global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
     float *wb = lds[wib];
 
     Pose ps;
-    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
     float zi[C], gi0[C], gi1[C], gi2[C], z[C], r[C], gb[C];
-    gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD>(A, ps, lane, zi, gi0, gi1, gi2);
+    gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD, PM>(A, ps, lane, zi, gi0, gi1, gi2);
     to_chunked<C>(wb, lane, zi, z);
     {
         // upstream gradient row, read as 256-B runs, attenuation folded in
@@ -556,7 +682,7 @@ __global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = j * kWave + lane;
-            zi[j] = (n < A.N1) ? gin[n] * expf(__fmul_rn(A.neg_alpha, (float)n)) : 0.f;
+            zi[j] = (n < A.N1) ? gin[n] * fast_exp(__fmul_rn(A.neg_alpha, (float)n)) : 0.f;
         }
         to_chunked<C>(wb, lane, zi, gb);
     }
@@ -602,9 +728,10 @@ __global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
         Pm = mat_step(Pm, r[j]);
         ex[j] = mat_renorm(Pm);
         esum += ex[j];
-        float e = __fdiv_rn(Pm.b, Pm.d);
+        float rd = __builtin_amdgcn_rcpf(Pm.d);
+        float e = Pm.b * rd;
         float g = (e == e) ? gb[j] : 0.f; // echoes zeroed by nan_to_num are constants
-        float q = __fdiv_rn(g, Pm.d);
+        float q = g * rd;
         gu[j] = (g != 0.f) ? q : 0.f;
         rho[j] = (e == e) ? e : 0.f;
         // past a non-finite reflection coefficient every echo is the constant 0
@@ -677,7 +804,7 @@ __global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
         }
         float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
         float s = zp + z[j];
-        float inv = __fdiv_rn(1.f, s);
+        float inv = __builtin_amdgcn_rcpf(s);
         float dz = 2.f * zp * inv * inv;     // d r / d Z_n
         float dzp = -2.f * z[j] * inv * inv; // d r / d Z_{n-1}
         float c1 = rb * dz, c0 = rb * dzp;
@@ -717,8 +844,8 @@ __global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
                 if (KEEP_GRAD) {
                     q0 = gi0[j]; q1 = gi1[j]; q2 = gi2[j];
                 } else {
-                    TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point(ps, 0, k), ray_point(ps, 1, k),
-                                                           ray_point(ps, 2, k));
+                    TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point<PM>(ps, 0, k), ray_point<PM>(ps, 1, k),
+                                                           ray_point<PM>(ps, 2, k));
                     q0 = s.g0; q1 = s.g1; q2 = s.g2;
                 }
                 float kf = (float)k;
@@ -792,14 +919,14 @@ struct Cell {
     float t[3];
 };
 
-template <int SAMPLER>
+template <int SAMPLER, int PM = 1>
 __device__ __forceinline__ Cell cell_of(const Args &A, const Pose &ps, int k)
 {
     Cell c;
     const int dims[3] = {A.G.d0, A.G.d1, A.G.d2};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float p = ray_point(ps, a, k);
+        float p = ray_point<PM>(ps, a, k);
         if (SAMPLER == DIFFUS_NEAREST) {
             c.i0[a] = c.i1[a] = nearest_index(p, dims[a]);
             c.t[a] = 0.f;
@@ -840,7 +967,7 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
     return axis == 2 ? (v >> 1) : (v >> 2);
 }
 
-template <int SAMPLER, int LAYOUT>
+template <int SAMPLER, int LAYOUT, int PM>
 __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_groups, int step_groups)
 {
     // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
@@ -872,7 +999,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     }
     if (tid == 3) s_max = 0;
     Pose ps;
-    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     Cell cells[kSamplesPerThread];
     float zb[kSamplesPerThread];
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
@@ -883,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         zb[q] = 0.f;
         if (ray_ok && n < A.N1) zb[q] = A.zbar[w * A.N1 + n];
         if (!finitef(zb[q])) zb[q] = 0.f;
-        cells[q] = cell_of<SAMPLER>(A, ps, A.start + n);
+        cells[q] = cell_of<SAMPLER, PM>(A, ps, A.start + n);
         zmax = fmaxf(zmax, fabsf(zb[q]));
         if (zb[q] != 0.f) {
 #pragma unroll
@@ -894,17 +1021,13 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         }
     }
     STAMP(1);
-    // block bounding box: wave reduce, then one LDS atomic per wave
+    // block bounding box: DPP wave reduce, then one LDS atomic per wave
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            lo[a] = min(lo[a], __shfl_xor(lo[a], off, kWave));
-            hi[a] = max(hi[a], __shfl_xor(hi[a], off, kWave));
-        }
+        lo[a] = wave_reduce_minmax<true>(lo[a]);
+        hi[a] = wave_reduce_minmax<false>(hi[a]);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off, kWave));
+    zmax = __int_as_float(wave_reduce_minmax<false>(__float_as_int(zmax))); // zmax >= 0: bits order like floats
     __syncthreads();
     if ((tid & 63) == 0) {
 #pragma unroll
@@ -935,18 +1058,37 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     for (int e = tid; e < nt; e += kBlock) tile[e] = 0;
     __syncthreads();
     STAMP(3);
+    // tile index = ex(i) + ey(j) + ez(k): three separable parts, each evaluated for the two
+    // coordinates of its axis only (6 small computations per sample instead of 8 full ones)
+    auto part = [&](int v, int axis) -> int {
+        if (LAYOUT == DIFFUS_CANONICAL)
+            return axis == 0 ? (v - l0) * b1 * b2 : (axis == 1 ? (v - l1) * b2 : (v - l2));
+        return axis == 0 ? (((v >> 2) - l0) * b1 * b2 * kBrickFloats + ((v & 3) << 3))
+                         : (axis == 1 ? (((v >> 2) - l1) * b2 * kBrickFloats + ((v & 3) << 1))
+                                      : (((v >> 1) - l2) * kBrickFloats + (v & 1)));
+    };
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q)
-        if (zb[q] != 0.f)
-            for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
-                int e;
-                if (LAYOUT == DIFFUS_CANONICAL)
-                    e = ((i - l0) * b1 + (j - l1)) * b2 + (k - l2);
-                else
-                    e = ((((i >> 2) - l0) * b1 + ((j >> 2) - l1)) * b2 + ((k >> 1) - l2)) * kBrickFloats +
-                        (((i & 3) << 3) | ((j & 3) << 1) | (k & 1));
-                atomicAdd(&tile[e], __float2int_rn(ldexpf(v, fx)));
-            });
+        if (zb[q] != 0.f) {
+            const Cell &c = cells[q];
+            const float sc = ldexpf(zb[q], fx);
+            if (SAMPLER == DIFFUS_NEAREST) {
+                atomicAdd(&tile[part(c.i0[0], 0) + part(c.i0[1], 1) + part(c.i0[2], 2)], __float2int_rn(sc));
+            } else {
+                const int ex0 = part(c.i0[0], 0), ex1 = part(c.i1[0], 0), ey0 = part(c.i0[1], 1), ey1 = part(c.i1[1], 1),
+                          ez0 = part(c.i0[2], 2), ez1 = part(c.i1[2], 2);
+                const float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1, wc1 = c.t[2], wc0 = 1.f - wc1;
+                const float w00 = sc * wa0 * wb0, w01 = sc * wa0 * wb1, w10 = sc * wa1 * wb0, w11 = sc * wa1 * wb1;
+                atomicAdd(&tile[ex0 + ey0 + ez0], __float2int_rn(w00 * wc0));
+                atomicAdd(&tile[ex0 + ey0 + ez1], __float2int_rn(w00 * wc1));
+                atomicAdd(&tile[ex0 + ey1 + ez0], __float2int_rn(w01 * wc0));
+                atomicAdd(&tile[ex0 + ey1 + ez1], __float2int_rn(w01 * wc1));
+                atomicAdd(&tile[ex1 + ey0 + ez0], __float2int_rn(w10 * wc0));
+                atomicAdd(&tile[ex1 + ey0 + ez1], __float2int_rn(w10 * wc1));
+                atomicAdd(&tile[ex1 + ey1 + ez0], __float2int_rn(w11 * wc0));
+                atomicAdd(&tile[ex1 + ey1 + ez1], __float2int_rn(w11 * wc1));
+            }
+        }
     __syncthreads();
     STAMP(4);
     // Flush every touched entry once.  No integer division per entry (the first version's
@@ -963,11 +1105,11 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
             if (v != 0) {
                 int j = __float2int_rz(((float)m + 0.5f) * rb2); // exact: m < 2^14, b2 <= 2^14
                 int k = m - j * b2;
-                long g;
+                unsigned g;
                 if (LAYOUT == DIFFUS_CANONICAL)
-                    g = ((long)(l0 + i) * A.G.d1 + (l1 + j)) * A.G.d2 + (l2 + k);
+                    g = ((unsigned)(l0 + i) * (unsigned)A.G.d1 + (unsigned)(l1 + j)) * (unsigned)A.G.d2 + (unsigned)(l2 + k);
                 else
-                    g = (((long)(l0 + i) * A.G.nb1 + (l1 + j)) * A.G.nb2 + (l2 + k)) * kBrickFloats + o;
+                    g = (((unsigned)(l0 + i) * (unsigned)A.G.nb1 + (unsigned)(l1 + j)) * (unsigned)A.G.nb2 + (unsigned)(l2 + k)) * kBrickFloats + (unsigned)o;
                 atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
             }
         }
@@ -1319,6 +1461,7 @@ int check_common(const float *vol, int d0, int d1, int d2, const void *src, int 
     if (start < 0 || start > S - 1) return DIFFUS_EINVAL;
     if (start > 0 && start > S - 2) return DIFFUS_EINVAL; // reference raises IndexError at :243
     if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24)) return DIFFUS_EUNSUPPORTED; // float(dim-1) must be exact
+    if (bricked_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;    // 32-bit element offsets
     if (need_scan && S - start > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
     if (start > 0 && (size_t)R * sizeof(float) > 64 * 1024) return DIFFUS_EUNSUPPORTED; // median LDS
     return DIFFUS_OK;
@@ -1362,36 +1505,49 @@ int launch_median(const Args &A, int sampler, int layout, hipStream_t st)
     });
 }
 
-int launch_fwd(const Args &A, int sampler, int layout, hipStream_t st)
+template <int SM, int LY, int PM>
+int launch_fwd_t(const Args &A, hipStream_t st)
 {
     const long waves = (long)A.P * A.R;
     const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(A.N1)) {
+    case 2: hipLaunchKernelGGL((render_fwd_kernel<2, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 4: hipLaunchKernelGGL((render_fwd_kernel<4, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: hipLaunchKernelGGL((render_fwd_kernel<8, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: hipLaunchKernelGGL((render_fwd_kernel<16, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    }
+    return last_launch();
+}
+
+int launch_fwd(const Args &A, int sampler, int layout, hipStream_t st)
+{
+    const bool f32 = !A.src_f64 && !A.dir_f64;
     return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
         constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
-        switch (chunk_for(A.N1)) {
-        case 2: hipLaunchKernelGGL((render_fwd_kernel<2, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-        case 4: hipLaunchKernelGGL((render_fwd_kernel<4, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-        case 8: hipLaunchKernelGGL((render_fwd_kernel<8, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-        default: hipLaunchKernelGGL((render_fwd_kernel<16, SM, LY, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-        }
-        return last_launch();
+        return f32 ? launch_fwd_t<SM, LY, 0>(A, st) : launch_fwd_t<SM, LY, 1>(A, st);
     });
+}
+
+template <int SM, int LY, bool GPOSE, int PM>
+int launch_bwd_p(const Args &A, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(A.N1)) {
+    case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: // 16 samples per lane need ~300 registers: one wave per block so the whole 512-entry file is available
+        hipLaunchKernelGGL((render_bwd_kernel<16, SM, LY, GPOSE, 1, PM>), dim3((unsigned)waves), dim3(kWave), 0, st, A);
+        break;
+    }
+    return last_launch();
 }
 
 template <int SM, int LY, bool GPOSE>
 int launch_bwd_t(const Args &A, hipStream_t st)
 {
-    const long waves = (long)A.P * A.R;
-    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    switch (chunk_for(A.N1)) {
-    case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SM, LY, GPOSE, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, kWavesPerBlock>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    default: // 16 samples per lane need ~300 registers: one wave per block so the whole 512-entry file is available
-        hipLaunchKernelGGL((render_bwd_kernel<16, SM, LY, GPOSE, 1>), dim3((unsigned)waves), dim3(kWave), 0, st, A);
-        break;
-    }
-    return last_launch();
+    return (!A.src_f64 && !A.dir_f64) ? launch_bwd_p<SM, LY, GPOSE, 0>(A, st) : launch_bwd_p<SM, LY, GPOSE, 1>(A, st);
 }
 
 int launch_bwd(const Args &A, int sampler, int layout, bool pose, hipStream_t st)
@@ -1518,9 +1674,13 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
     if (gvol && do_scatter) {
         const int rgs = (R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
         const unsigned nb = (unsigned)((long)P * rgs * sgs);
+        const bool f32 = !A.src_f64 && !A.dir_f64;
         rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
-            hipLaunchKernelGGL((scatter_patch_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nb), dim3(kBlock),
-                               0, st, A, rgs, sgs);
+            constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+            if (f32)
+                hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
+            else
+                hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
             return last_launch();
         });
         if (rc) return rc;
