@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alpha", type=float, default=1e-4)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 logic on a single GPU (every rank on cuda:0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,8 +203,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -241,8 +247,12 @@ def main():
             graph.replay()
         else:
             hp.step()
-        if dist is not None:
+        if dist is not None and args.dist_backend == "nccl":
             dist.all_gather_into_tensor(losses_all, hp.loss)   # the one collective: P losses over xGMI
+        elif dist is not None:                                  # gloo rehearsal: through host memory
+            out = torch.empty(P_total, dtype=torch.float32)
+            dist.all_gather_into_tensor(out, hp.loss.cpu())
+            losses_all.copy_(out)
 
     def barrier():
         if dist is not None:
@@ -258,9 +268,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank must hold all P losses, in pose order, and they must be finite
+        assert torch.isfinite(losses_all).all() and float(losses_all.abs().min()) > 0, "loss gather failed"
     ray_steps = P_total * args.rays * args.samples
     value = ray_steps * args.steps / dt
 

@@ -8,6 +8,8 @@ from .cone import fan_directions_torch, generate_cone_directions  # noqa: F401
 from .renderer import (BrickedVolume, UltrasoundRenderer, brick_volume, compute_echo_traces,  # noqa: F401
                        render_poses, resolve_start, trace_rays, unbrick_volume)
 
-__all__ = ["UltrasoundRenderer", "compute_echo_traces", "render_poses", "trace_rays", "resolve_start",
+from .splat import differentiable_splat, rotate_around_apex, splat_frames  # noqa: F401,E402
+
+__all__ = ["differentiable_splat", "rotate_around_apex", "splat_frames", "UltrasoundRenderer", "compute_echo_traces", "render_poses", "trace_rays", "resolve_start",
            "generate_cone_directions", "fan_directions_torch", "DiffusError", "BrickedVolume", "brick_volume",
            "unbrick_volume"]

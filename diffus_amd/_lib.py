@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so
 EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
            "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces",
-           "diffus_loss_sumsq")
+           "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
@@ -62,6 +62,12 @@ def load():
     lib.diffus_unbrick_volume.argtypes = [vp, i, i, i, vp, i, vp]
     lib.diffus_echo_traces.restype = i
     lib.diffus_echo_traces.argtypes = [vp, i, i, vp, vp]
+    lib.diffus_splat_workspace_bytes.restype = sz
+    lib.diffus_splat_workspace_bytes.argtypes = [i, i, i]
+    lib.diffus_splat_fwd.restype = i
+    lib.diffus_splat_fwd.argtypes = [vp, vp, vp, i, C.c_long, i, i, i, f, vp, vp, sz, vp]
+    lib.diffus_splat_bwd.restype = i
+    lib.diffus_splat_bwd.argtypes = [vp, vp, i, C.c_long, i, i, f, vp, vp, vp, sz, vp]
     if lib.diffus_abi_version() != 1:
         raise DiffusError("libdiffus_hip.so ABI version mismatch")
     _lib = lib

@@ -173,6 +173,32 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo,
                        diffus_stream_t stream);
 
 /*
+ * Scan conversion (the step after the path): replaces
+ * differentiable_splat (reference src/renderer.py:694-737) for P frames at once.
+ *   c0, c1  (P,n) float32: the two plotted coordinates of every sample (the
+ *           caller picks the two highest-variance axes like :702-710 and casts)
+ *   val     (P,n) float32 intensities
+ *   cols    0, or the row length when the n samples of a pose form a (n/cols, cols)
+ *           grid of rays x steps (a performance hint only: results are identical)
+ *   out     (P,W,H) float32: per pose the (W,H) image the reference returns
+ * Pixel = clamp(round_half_even(coord), 0, size-1) (:717-718); of the samples
+ * landing on one pixel the LAST in flattened order wins (index_put without
+ * accumulation, :721-722); weight is 1 where any landed; both planes are blurred
+ * with the normalised Gaussian of size int(6 sigma)|1 (zero padding, :725-734) and
+ * divided with eps 1e-8 (:735); the result is transposed (:737).
+ * diffus_splat_bwd: gout (P,W,H) -> gval (P,n), every sample receiving the
+ * gradient of its pixel, exactly as torch autograd does through the reference.
+ * sigma <= 8 (kernel half-width <= 24).
+ */
+size_t diffus_splat_workspace_bytes(int P, int H, int W);
+int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, long n, int cols,
+                     int H, int W, float sigma, float *out,
+                     void *workspace, size_t workspace_bytes, diffus_stream_t stream);
+int diffus_splat_bwd(const float *c0, const float *c1, int P, long n,
+                     int H, int W, float sigma, const float *gout, float *gval,
+                     void *workspace, size_t workspace_bytes, diffus_stream_t stream);
+
+/*
  * Utility, not a reference function: the energy loss the benchmarks and examples
  * optimise.  loss[p] = sum(frame[p,:]^2) over the n floats of pose p, and (if
  * gframe != NULL) gframe = d loss / d frame = 2 * frame, in one streaming pass.

@@ -243,6 +243,38 @@ def main():
         save("g9_trilinear", n=np.int64(n), S=np.int64(S), alpha=np.float64(alpha), source=src_t.numpy(),
              directions=dir_t.numpy(), imp=imp.numpy(), frame=frame.numpy())
 
+    # ---- G11: differentiable_splat (+ rotate_around_apex), forward and autograd ----------
+    if want("g11"):
+        torch.set_grad_enabled(True)
+        out = {}
+        v = torch.from_numpy(phantom(64))
+        s, d = pose_ring(64, 4, 32)
+        cases = [("a", 0, 4, 64, 64, 1.5, None), ("b", 1, 0, 64, 64, 2.0, None), ("c", 2, 10, 48, 80, 1.0, None),
+                 ("d", 3, 0, 64, 64, 2.0, "rot"), ("e", 0, 4, 64, 64, 0.7, "perm")]
+        for tag, p, start, H, W, sigma, mode in cases:
+            with torch.no_grad():
+                x, y, z, f = (torch.from_numpy(a) for a in ref_frame(v, torch.from_numpy(s[p]), torch.from_numpy(d[p]), 64, 1e-3, start))
+            if mode == "rot":       # float coordinates, as after rotate_around_apex in the REUBEN demos
+                with quiet():
+                    xr, yr = ref.rotate_around_apex(x.flatten().float(), y.flatten().float(), (32.0, 5.0), (float(-d[p][16][0]), float(-d[p][16][1])))
+                out[f"{tag}_rot_x"] = xr.numpy(); out[f"{tag}_rot_y"] = yr.numpy()
+                x, y = xr.reshape(x.shape), yr.reshape(y.shape)
+            if mode == "perm":      # axes permuted as in `[DEMO] CT Render Lung` cell 17
+                x, y, z = z, x, y
+            fi = f.clone().requires_grad_(True)
+            with quiet():
+                o = ref.differentiable_splat(x, y, z, fi, H=H, W=W, sigma=sigma)
+            g = torch.Generator().manual_seed(7)
+            up = torch.randn(o.shape, generator=g)
+            (o * up).sum().backward()
+            out[f"{tag}_x"] = x.numpy(); out[f"{tag}_y"] = y.numpy(); out[f"{tag}_z"] = z.numpy()
+            out[f"{tag}_f"] = f.numpy(); out[f"{tag}_H"] = np.int64(H); out[f"{tag}_W"] = np.int64(W)
+            out[f"{tag}_sigma"] = np.float64(sigma); out[f"{tag}_out"] = o.detach().numpy()
+            out[f"{tag}_up"] = up.numpy(); out[f"{tag}_grad"] = fi.grad.numpy()
+        out["tags"] = np.array([c[0] for c in cases])
+        save("g11_splat", **out)
+        torch.set_grad_enabled(False)
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

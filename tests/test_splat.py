@@ -1,0 +1,88 @@
+"""Scan conversion: oracle vs the reference's golden outputs (CPU), and the HIP
+path vs both (GPU).  Golden G11 = differentiable_splat / rotate_around_apex run in the reference,
+forward and autograd, incl. float (rotated) and permuted coordinates."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, maxnorm_rel
+
+
+def _cases():
+    g = load_golden("g11_splat")
+    return g, [str(t) for t in g["tags"]]
+
+
+def test_oracle_splat_matches_reference():
+    from oracle import splat as osp
+    g, tags = _cases()
+    for t in tags:
+        H, W, sigma = int(g[f"{t}_H"]), int(g[f"{t}_W"]), float(g[f"{t}_sigma"])
+        out, _ = osp.splat(g[f"{t}_x"], g[f"{t}_y"], g[f"{t}_z"], g[f"{t}_f"], H, W, sigma)
+        assert out.shape == g[f"{t}_out"].shape == (W, H)
+        assert maxnorm_rel(out, g[f"{t}_out"]) < 2e-6, t
+        gr = osp.splat_grad(g[f"{t}_x"], g[f"{t}_y"], g[f"{t}_z"], g[f"{t}_f"], g[f"{t}_up"], H, W, sigma)
+        assert maxnorm_rel(gr, g[f"{t}_grad"]) < 2e-5, t
+    xr, yr = osp.rotate_around_apex(g["d_x"].ravel() * 0 + g["d_rot_x"] * 0 + 1, g["d_rot_y"] * 0 + 2, (3.0, 4.0), (0.0, 1.0))
+    np.testing.assert_allclose(xr, 1 - 128 + 3.0, rtol=1e-6)      # median (0,1): identity rotation
+    np.testing.assert_allclose(yr, 2 + 4.0, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_splat_matches_reference_and_oracle():
+    import diffus_amd
+    from oracle import splat as osp
+    g, tags = _cases()
+    for t in tags:
+        H, W, sigma = int(g[f"{t}_H"]), int(g[f"{t}_W"]), float(g[f"{t}_sigma"])
+        x, y, z = (torch.from_numpy(g[f"{t}_{c}"]).cuda() for c in "xyz")
+        f = torch.from_numpy(g[f"{t}_f"]).cuda().requires_grad_(True)
+        out = diffus_amd.differentiable_splat(x, y, z, f, H=H, W=W, sigma=sigma)
+        assert out.shape == (W, H) and out.dtype == torch.float32 and out.device == f.device
+        assert maxnorm_rel(out.detach().cpu().numpy(), g[f"{t}_out"]) < 2e-6, t
+        (out * torch.from_numpy(g[f"{t}_up"]).cuda()).sum().backward()
+        assert maxnorm_rel(f.grad.cpu().numpy(), g[f"{t}_grad"]) < 2e-5, t
+        o2, _ = osp.splat(g[f"{t}_x"], g[f"{t}_y"], g[f"{t}_z"], g[f"{t}_f"], H, W, sigma)
+        assert maxnorm_rel(out.detach().cpu().numpy(), o2) < 2e-6, t
+
+
+@pytest.mark.gpu
+def test_hip_rotate_around_apex_matches_reference():
+    import diffus_amd
+    g, _ = _cases()
+    x, y = torch.from_numpy(g["d_x"]).flatten(), torch.from_numpy(g["d_y"]).flatten()
+    # the golden holds the rotated coordinates the reference produced from the integer planes of case d
+    from diffus_amd.phantom import pose_ring
+    _, d = pose_ring(64, 4, 32)
+    # recover the un-rotated inputs: case d stored rotated coords as x,y; regenerate from the frame planes
+    R = diffus_amd.UltrasoundRenderer(64, 1e-3)
+    from diffus_amd.phantom import phantom
+    s, d = pose_ring(64, 4, 32)
+    xi, yi, zi, _ = R.plot_beam_frame(torch.from_numpy(phantom(64)).cuda(), torch.from_numpy(s[3]), torch.from_numpy(d[3]))
+    xr, yr = diffus_amd.rotate_around_apex(xi.flatten().float(), yi.flatten().float(), (32.0, 5.0),
+                                           (float(-d[3][16][0]), float(-d[3][16][1])))
+    np.testing.assert_allclose(xr.cpu().numpy(), g["d_rot_x"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(yr.cpu().numpy(), g["d_rot_y"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_splat_batched_and_full_size():
+    import diffus_amd
+    from oracle import splat as osp
+    from diffus_amd.phantom import phantom, pose_ring
+    vol = torch.from_numpy(phantom(256)).cuda()
+    s, d = pose_ring(256, 4, 256)
+    frames, idx = diffus_amd.render_poses(vol, torch.from_numpy(s), torch.from_numpy(d), 512, 1e-4, return_indices=True)
+    P = 4
+    from diffus_amd.splat import plot_axes
+    axes = [plot_axes(idx[0, p], idx[1, p], idx[2, p]) for p in range(P)]     # per pose, like the reference
+    c0 = torch.stack([idx[a0, p].reshape(-1).float() for p, (a0, a1) in enumerate(axes)])
+    c1 = torch.stack([idx[a1, p].reshape(-1).float() for p, (a0, a1) in enumerate(axes)])
+    imgs = diffus_amd.splat_frames(c0, c1, frames.reshape(P, -1), 256, 256, 2.0, cols=512)
+    assert torch.equal(imgs, diffus_amd.splat_frames(c0, c1, frames.reshape(P, -1), 256, 256, 2.0))   # the hint changes nothing
+    assert imgs.shape == (P, 256, 256) and torch.isfinite(imgs).all()
+    for p in (0, 3):
+        one = diffus_amd.differentiable_splat(idx[0, p], idx[1, p], idx[2, p], frames[p], 256, 256, 2.0)
+        assert torch.equal(one, imgs[p])
+        o, _ = osp.splat(idx[0, p].cpu().numpy(), idx[1, p].cpu().numpy(), idx[2, p].cpu().numpy(), frames[p].cpu().numpy(), 256, 256, 2.0)
+        assert maxnorm_rel(one.cpu().numpy(), o) < 2e-6
