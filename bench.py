@@ -87,6 +87,7 @@ class HotPath:
         self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
         self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
+        self.loss_ws = torch.empty(max(64 * self.P, 256), dtype=torch.uint8, device=dev)
         nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, S, start), 256)
         self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         self.common = (vp(self.vol_k), d0, d1, d2, self.layout, vp(src), 0, vp(dirs), 0, self.P, self.R, S, start,
@@ -106,7 +107,8 @@ class HotPath:
 
     def loss_and_grad(self):
         _lib.check(self.lib.diffus_loss_sumsq(vp(self.frame), self.P, self.R * self.N1, vp(self.loss),
-                                              vp(self.gframe), self.stream()), "diffus_loss_sumsq")
+                                              vp(self.gframe), vp(self.loss_ws), self.loss_ws.numel(), self.stream()),
+                   "diffus_loss_sumsq")
 
     def zero_grad(self):
         if self.gvol_k is not None:

@@ -51,7 +51,7 @@ def load():
     lib.diffus_render_bwd.restype = i
     lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, i, vp, sz, vp]
     lib.diffus_loss_sumsq.restype = i
-    lib.diffus_loss_sumsq.argtypes = [vp, i, C.c_long, vp, vp, vp]
+    lib.diffus_loss_sumsq.argtypes = [vp, i, C.c_long, vp, vp, vp, sz, vp]
     lib.diffus_trace_rays.restype = i
     lib.diffus_trace_rays.argtypes = [vp, i, i, i, i, vp, i, vp, i, i, i, i, i, vp, vp, vp, vp]
     lib.diffus_bricked_floats.restype = sz

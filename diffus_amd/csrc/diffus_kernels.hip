@@ -506,10 +506,17 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps
                 unsigned c00 = col_off<LAYOUT>(A.G, a.i0, b.i0), c01 = col_off<LAYOUT>(A.G, a.i0, b.i1);
                 unsigned c10 = col_off<LAYOUT>(A.G, a.i1, b.i0), c11 = col_off<LAYOUT>(A.G, a.i1, b.i1);
                 unsigned z0 = z_off<LAYOUT>(c.i0), z1 = z_off<LAYOUT>(c.i1);
+#ifdef DIFFUS_ABLATE_LOADS
+                raw[jj][0] = __uint_as_float(c00 + z0); raw[jj][1] = __uint_as_float(c00 + z1);
+                raw[jj][2] = __uint_as_float(c01 + z0); raw[jj][3] = __uint_as_float(c01 + z1);
+                raw[jj][4] = __uint_as_float(c10 + z0); raw[jj][5] = __uint_as_float(c10 + z1);
+                raw[jj][6] = __uint_as_float(c11 + z0); raw[jj][7] = __uint_as_float(c11 + z1);
+#else
                 raw[jj][0] = vol[c00 + z0]; raw[jj][1] = vol[c00 + z1];
                 raw[jj][2] = vol[c01 + z0]; raw[jj][3] = vol[c01 + z1];
                 raw[jj][4] = vol[c10 + z0]; raw[jj][5] = vol[c10 + z1];
                 raw[jj][6] = vol[c11 + z0]; raw[jj][7] = vol[c11 + z1];
+#endif
                 ta[jj] = a.t; tb[jj] = b.t; tc[jj] = c.t;
                 if (GRAD) mk[jj] = (a.m != 0.f ? 1u : 0u) | (b.m != 0.f ? 2u : 0u) | (c.m != 0.f ? 4u : 0u);
             }
@@ -530,7 +537,13 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps
                     b.m = (mk[jj] & 2u) ? 1.f : 0.f;
                     c.m = (mk[jj] & 4u) ? 1.f : 0.f;
                 }
+#ifdef DIFFUS_ABLATE_LERP
+                TriSample sm;
+                sm.v = raw[jj][0] + raw[jj][1] + raw[jj][2] + raw[jj][3] + raw[jj][4] + raw[jj][5] + raw[jj][6] + raw[jj][7] + a.t + b.t + c.t;
+                sm.g0 = sm.g1 = sm.g2 = 0.f;
+#else
                 TriSample sm = tri_lerp<GRAD>(raw[jj], a, b, c);
+#endif
                 z[j] = live ? sm.v : 1.f;
                 if (GRAD) {
                     g0[j] = live ? sm.g0 : 0.f;
@@ -616,7 +629,12 @@ __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
     float zprev = __shfl_up(z[C - 1], 1, kWave);
     float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, n0, z, zprev, medv, r);
+#ifdef DIFFUS_ABLATE_SCAN
+#pragma unroll
+    for (int j = 0; j < C; ++j) e[j] = r[j];
+#else
     echo_chunk<C, true>(r, lane, e);
+#endif
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         // attenuation, reference :256-259: f32(-alpha) * f32(n), exp, multiply
@@ -974,10 +992,12 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
     // The tile therefore accumulates in 32-bit FIXED POINT with a per-patch power-of-two
     // scale 2^fx chosen so that even all 1024 samples landing on one voxel cannot
-    // overflow: max|zbar| * 2^fx < 2^20.  Quantum = 2^-20 of the patch's largest
-    // contribution; integer adds commute, so a tile sum is bitwise reproducible.
+    // overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel can
+    // receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution,
+    // typically 2^-23..2^-26; integer adds commute, so a tile sum is bitwise reproducible.
     __shared__ int tile[kTileCap];
     __shared__ int s_lo[3], s_hi[3], s_max;
+    __shared__ float s_sum[kWavesPerBlock];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
 
     // patch -> (pose, ray group, step group); the XCD remap keeps a pose on one XCD
@@ -1028,6 +1048,11 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         hi[a] = wave_reduce_minmax<false>(hi[a]);
     }
     zmax = __int_as_float(wave_reduce_minmax<false>(__float_as_int(zmax))); // zmax >= 0: bits order like floats
+    float zsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) zsum += fabsf(zb[q]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) zsum += __shfl_xor(zsum, off, kWave);
     __syncthreads();
     if ((tid & 63) == 0) {
 #pragma unroll
@@ -1036,6 +1061,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
             atomicMax(&s_hi[a], hi[a]);
         }
         atomicMax(&s_max, __float_as_int(zmax)); // non-negative floats order like their bit patterns
+        s_sum[tid >> 6] = zsum;
     }
     __syncthreads();
     STAMP(2);
@@ -1054,7 +1080,9 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         return;
     }
     const int nt = (int)vol_tile;
-    const int fx = 20 - __builtin_amdgcn_frexp_expf(__int_as_float(s_max)); // max|zbar| * 2^fx in [2^19, 2^20)
+    // (s_sum total) * 2^fx in [2^28, 2^29): headroom for the rounding of each contribution
+    const float ztot = fmaxf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]), __int_as_float(s_max));
+    const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
     for (int e = tid; e < nt; e += kBlock) tile[e] = 0;
     __syncthreads();
     STAMP(3);
@@ -1079,14 +1107,20 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
                           ez0 = part(c.i0[2], 2), ez1 = part(c.i1[2], 2);
                 const float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1, wc1 = c.t[2], wc0 = 1.f - wc1;
                 const float w00 = sc * wa0 * wb0, w01 = sc * wa0 * wb1, w10 = sc * wa1 * wb0, w11 = sc * wa1 * wb1;
-                atomicAdd(&tile[ex0 + ey0 + ez0], __float2int_rn(w00 * wc0));
-                atomicAdd(&tile[ex0 + ey0 + ez1], __float2int_rn(w00 * wc1));
-                atomicAdd(&tile[ex0 + ey1 + ez0], __float2int_rn(w01 * wc0));
-                atomicAdd(&tile[ex0 + ey1 + ez1], __float2int_rn(w01 * wc1));
-                atomicAdd(&tile[ex1 + ey0 + ez0], __float2int_rn(w10 * wc0));
-                atomicAdd(&tile[ex1 + ey0 + ez1], __float2int_rn(w10 * wc1));
-                atomicAdd(&tile[ex1 + ey1 + ez0], __float2int_rn(w11 * wc0));
-                atomicAdd(&tile[ex1 + ey1 + ez1], __float2int_rn(w11 * wc1));
+                // clamped samples (outside the volume: more than half of a typical fan) have zero
+                // weights on half or more of their corners: do not spend an LDS atomic on a zero
+                auto add = [&](int e, float v) {
+                    int q = __float2int_rn(v);
+                    if (q != 0) atomicAdd(&tile[e], q);
+                };
+                add(ex0 + ey0 + ez0, w00 * wc0);
+                add(ex0 + ey0 + ez1, w00 * wc1);
+                add(ex0 + ey1 + ez0, w01 * wc0);
+                add(ex0 + ey1 + ez1, w01 * wc1);
+                add(ex1 + ey0 + ez0, w10 * wc0);
+                add(ex1 + ey0 + ez1, w10 * wc1);
+                add(ex1 + ey1 + ez0, w11 * wc0);
+                add(ex1 + ey1 + ez1, w11 * wc1);
             }
         }
     __syncthreads();
@@ -1574,27 +1608,29 @@ __global__ __launch_bounds__(kBlock) void splat_gather_kernel(const float *__res
 }
 
 // ----------------------------------------------------------------------------
-// Energy loss used by the benchmarks and examples: loss[p] = sum(frame[p]^2),
-// gframe = 2 * frame, in one pass (float4 streaming; one block per pose, fixed
-// reduction order => deterministic).
-__global__ __launch_bounds__(1024) void loss_sumsq_kernel(const float *__restrict__ frame, float *__restrict__ loss,
-                                                          float *__restrict__ gframe, long n)
+// Energy loss used by the benchmarks and examples: loss[p] = sum(frame[p]^2), gframe = 2 * frame,
+// in one streaming pass.  kLossSplit blocks per pose write partial sums, a second tiny kernel adds
+// them in a fixed order (deterministic; one block per pose alone used only P of the 256 CUs).
+constexpr int kLossSplit = 16;
+__global__ __launch_bounds__(kBlock) void loss_sumsq_kernel(const float *__restrict__ frame, float *__restrict__ part,
+                                                            float *__restrict__ gframe, long n)
 {
-    __shared__ float sm[16];
-    const float *f = frame + (long)blockIdx.x * n;
-    float *g = gframe ? gframe + (long)blockIdx.x * n : nullptr;
+    __shared__ float sm[kWavesPerBlock];
+    const long pz = blockIdx.y;
+    const float *f = frame + pz * n;
+    float *g = gframe ? gframe + pz * n : nullptr;
     float acc = 0.f;
     const bool vec = ((n & 3) == 0) && ((((uintptr_t)f) & 15) == 0) && (!g || (((uintptr_t)g) & 15) == 0);
     if (vec) {
         const float4 *f4 = reinterpret_cast<const float4 *>(f);
         float4 *g4 = reinterpret_cast<float4 *>(g);
-        for (long i = threadIdx.x; i < n / 4; i += blockDim.x) {
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n / 4; i += (long)kLossSplit * kBlock) {
             float4 v = f4[i];
             acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
             if (g) g4[i] = make_float4(2.f * v.x, 2.f * v.y, 2.f * v.z, 2.f * v.w);
         }
     } else {
-        for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)kLossSplit * kBlock) {
             float v = f[i];
             acc += v * v;
             if (g) g[i] = 2.f * v;
@@ -1604,11 +1640,16 @@ __global__ __launch_bounds__(1024) void loss_sumsq_kernel(const float *__restric
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
-        loss[blockIdx.x] = t;
-    }
+    if (threadIdx.x == 0) part[pz * kLossSplit + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ void loss_finish_kernel(const float *__restrict__ part, float *__restrict__ loss, int P)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float t = 0.f;
+    for (int i = 0; i < kLossSplit; ++i) t += part[p * kLossSplit + i];
+    loss[p] = t;
 }
 
 // ----------------------------------------------------------------------------
@@ -2004,10 +2045,14 @@ int diffus_splat_bwd(const float *c0, const float *c1, int P, long n, int H, int
     return last_launch();
 }
 
-int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe, diffus_stream_t stream)
+int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe, void *workspace,
+                      size_t workspace_bytes, diffus_stream_t stream)
 {
     if (!frame || !loss || P <= 0 || n <= 0) return DIFFUS_EINVAL;
-    hipLaunchKernelGGL(loss_sumsq_kernel, dim3(P), dim3(1024), 0, (hipStream_t)stream, frame, loss, gframe, n);
+    if (!workspace || workspace_bytes < sizeof(float) * (size_t)P * kLossSplit) return DIFFUS_EWORKSPACE;
+    float *part = (float *)workspace;
+    hipLaunchKernelGGL(loss_sumsq_kernel, dim3(kLossSplit, P), dim3(kBlock), 0, (hipStream_t)stream, frame, part, gframe, n);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, loss, P);
     return last_launch();
 }
 

@@ -204,6 +204,7 @@ int diffus_splat_bwd(const float *c0, const float *c1, int P, long n,
  * gframe != NULL) gframe = d loss / d frame = 2 * frame, in one streaming pass.
  */
 int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe,
+                      void *workspace, size_t workspace_bytes /* >= 64 * P bytes */,
                       diffus_stream_t stream);
 
 #ifdef __cplusplus

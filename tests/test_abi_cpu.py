@@ -81,7 +81,8 @@ def test_argument_validation_without_a_gpu(lib):
     assert lib.diffus_echo_traces(None, 1, 4, p, None) == -1
     assert lib.diffus_echo_traces(p, 1, 2000, p, None) == -2
     assert lib.diffus_brick_volume(None, 2, 2, 2, p, None) == -1
-    assert lib.diffus_loss_sumsq(p, 0, 4, p, None, None) == -1
+    assert lib.diffus_loss_sumsq(p, 0, 4, p, None, p, 1024, None) == -1
+    assert lib.diffus_loss_sumsq(p, 1, 4, p, None, None, 0, None) == -4
 
 
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
