@@ -675,8 +675,11 @@ __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
 // W_n = 2^{e_n-e_{n-1}} (Gbar'_n + U'_n):  Tbar_n = P'_{n-1}^T W_n,  U'_{n-1} = W_n T_n^T.
 // The chunk of one lane is an affine map U_in -> U_out; lanes are combined with a
 // reverse Hillis-Steele scan of affine maps (A, B, beta):  X -> A + X (B 2^beta)^T.
+#ifndef DIFFUS_BWD_MIN_WAVES
+#define DIFFUS_BWD_MIN_WAVES 1
+#endif
 template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM>
-__global__ __launch_bounds__(kWave *WPB) void render_bwd_kernel(Args A)
+__global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) void render_bwd_kernel(Args A)
 {
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 48 more registers

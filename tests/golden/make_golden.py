@@ -275,6 +275,34 @@ def main():
         save("g11_splat", **out)
         torch.set_grad_enabled(False)
 
+    # ---- G12: probe-pose helpers of src/cone.py (executed from the file via ast, like G8) -------
+    if want("g12"):
+        tree = ast.parse(open(os.path.join(REF, "src", "cone.py")).read())
+        names = ("voxel_to_world", "world_to_voxel", "compute_us_apex_and_direction", "cone_us_to_mri_world")
+        fns = [n_ for n_ in tree.body if isinstance(n_, ast.FunctionDef) and n_.name in names]
+        ns = {"np": np, "torch": torch}
+        exec(compile(ast.Module(body=fns, type_ignores=[]), "cone.py", "exec"), ns)
+        rng = np.random.default_rng(5)
+        out = {}
+        lines = [(-1.7, 300.0, 1.4, -60.0), (-0.6, 120.5, 0.9, 10.25), (-3.0, 50.0, 2.0, 75.0)]
+        for j, (ml, bl, mr, br) in enumerate(lines):
+            r = ns["compute_us_apex_and_direction"](ml, bl, mr, br)
+            out[f"l{j}_in"] = np.array([ml, bl, mr, br]); out[f"l{j}_apex"] = np.array(r["apex"])
+            out[f"l{j}_opening"] = np.float64(r["opening_angle"]); out[f"l{j}_dir"] = np.array(r["direction_vector"])
+        def affine():
+            A = np.eye(4); q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            A[:3, :3] = q * rng.uniform(0.4, 1.2, 3); A[:3, 3] = rng.normal(0, 40, 3)
+            return A
+        for j in range(3):
+            Au, At = affine(), affine()
+            apex = rng.uniform(0, 200, 3); d2 = rng.normal(size=2)
+            a, dv = ns["cone_us_to_mri_world"](apex, d2, Au, At)
+            out[f"a{j}_Au"] = Au; out[f"a{j}_At"] = At; out[f"a{j}_apex"] = apex; out[f"a{j}_d2"] = d2
+            out[f"a{j}_apex_t1"] = a; out[f"a{j}_dir_t1"] = dv
+            out[f"a{j}_v2w"] = ns["voxel_to_world"](apex, Au); out[f"a{j}_w2v"] = ns["world_to_voxel"](apex, At)
+        out["nl"] = np.int64(len(lines)); out["na"] = np.int64(3)
+        save("g12_pose_helpers", **out)
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

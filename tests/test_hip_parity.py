@@ -420,3 +420,30 @@ def test_brick_cache_tracks_inplace_updates(da, vols):
     f2 = da.render_poses(v, s, d, S, 1e-3, layout="bricked")
     f3 = da.render_poses(v, s, d, S, 1e-3, layout="canonical")
     assert torch.equal(f2, f3) and not torch.equal(f1, f2)
+
+
+# ----------------------------------------------------------------------------- end to end: pose registration
+def test_pose_registration_by_gradient_descent(da):
+    # what the reference's `[NW] alignement` notebook attempts and cannot do (no pose gradient):
+    # recover a perturbed probe pose by descending d loss / d (apex, median angle) through the HIP backward
+    n, R, S, alpha = 64, 48, 96, 1e-3
+    u = np.arange(n, dtype=np.float64) / (n - 1)
+    smooth = 1.6e6 + 3e5 * np.sin(6 * u)[:, None, None] * np.cos(5 * u)[None, :, None] * np.sin(4 * u + 1)[None, None, :]
+    vol = cuda(smooth.astype(np.float32))
+    true = da.FanPose((20.0, 30.0, 31.3), (0.8, 0.6), 0.9, R).cuda()
+    with torch.no_grad():
+        src, dirs = true()
+        target = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
+    pose = da.FanPose((21.2, 28.9, 31.9), (0.74, 0.67), 0.9, R).cuda()
+    opt = torch.optim.Adam(pose.parameters(), lr=0.05)
+    losses = []
+    for _ in range(150):
+        opt.zero_grad()
+        src, dirs = pose()
+        f = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
+        loss = ((f - target) ** 2).sum()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
+    assert torch.linalg.norm(pose.apex.detach() - true.apex.detach()) < 0.6

@@ -64,3 +64,32 @@ def test_shard_bounds_partition(P, world):
         assert b == c and b >= a and d >= c
     sizes = [b - a for a, b in spans]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_g12_pose_helpers_match_reference():
+    import diffus_amd
+    from conftest import load_golden
+    g = load_golden("g12_pose_helpers")
+    for j in range(int(g["nl"])):
+        r = diffus_amd.compute_us_apex_and_direction(*g[f"l{j}_in"])
+        np.testing.assert_array_equal(np.array(r["apex"]), g[f"l{j}_apex"])
+        assert r["opening_angle"] == g[f"l{j}_opening"]
+        np.testing.assert_array_equal(r["direction_vector"], g[f"l{j}_dir"])
+    for j in range(int(g["na"])):
+        a, d = diffus_amd.cone_us_to_mri_world(g[f"a{j}_apex"], g[f"a{j}_d2"], g[f"a{j}_Au"], g[f"a{j}_At"])
+        np.testing.assert_array_equal(a, g[f"a{j}_apex_t1"])
+        np.testing.assert_array_equal(d, g[f"a{j}_dir_t1"])
+        np.testing.assert_array_equal(diffus_amd.voxel_to_world(g[f"a{j}_apex"], g[f"a{j}_Au"]), g[f"a{j}_v2w"])
+        np.testing.assert_array_equal(diffus_amd.world_to_voxel(g[f"a{j}_apex"], g[f"a{j}_At"]), g[f"a{j}_w2v"])
+    with pytest.raises(RuntimeError):
+        diffus_amd.compute_us_apex_and_direction(1.0, 0.0, 1.0, 5.0)
+
+
+def test_fan_pose_module():
+    import diffus_amd
+    fp = diffus_amd.FanPose((88.0, -11.5, 110.0), (-0.3, -0.95), 0.85, 64, learn_opening=True)
+    src, dirs = fp()
+    ref = generate_cone_directions((-0.3, -0.95), 0.85, 64)
+    assert torch.allclose(dirs, ref, atol=2e-6) and src.shape == (3,)
+    (dirs[:, 0].sum() + src.sum()).backward()
+    assert fp.median_angle.grad is not None and fp.opening_angle.grad is not None and fp.apex.grad is not None
