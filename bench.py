@@ -121,6 +121,8 @@ class HotPath:
                        "diffus_unbrick_volume")
 
     def step(self):
+        # (a forked stream for zero_grad beside the forward was measured: the fork/join events cost
+        # more than the 10 us they hide -- 0.217 vs 0.202 ms/step -- so the step stays on one stream)
         self.fwd()
         self.loss_and_grad()
         self.zero_grad()

@@ -473,6 +473,9 @@ __device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a
     return s;
 }
 
+#ifndef DIFFUS_GATHER_GROUP
+#define DIFFUS_GATHER_GROUP 8
+#endif
 // Impedance (and for the trilinear backward its spatial gradient) at the wave's samples,
 // INTERLEAVED mapping.  Written for memory-level parallelism: phase A computes the addresses of
 // up to 8 samples x 8 corners and issues every load with NO branch in between (lanes past the
@@ -484,7 +487,7 @@ template <int C, int SAMPLER, int LAYOUT, bool GRAD, int PM>
 __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps, int lane, float (&z)[C],
                                                    float (&g0)[C], float (&g1)[C], float (&g2)[C])
 {
-    constexpr int G = (C < 8) ? C : 8;
+    constexpr int G = (C < DIFFUS_GATHER_GROUP) ? C : DIFFUS_GATHER_GROUP;
     constexpr int NV = (SAMPLER == DIFFUS_NEAREST) ? 1 : 8;
     const float *__restrict__ vol = A.vol;
 #pragma unroll
@@ -608,8 +611,11 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
 
 // ----------------------------------------------------------------------------
 // FORWARD  (replaces reference src/renderer.py:201-275 with artifacts=False)
+#ifndef DIFFUS_FWD_MIN_WAVES
+#define DIFFUS_FWD_MIN_WAVES 1
+#endif
 template <int C, int SAMPLER, int LAYOUT, int WPB, int PM>
-__global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
+__global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) void render_fwd_kernel(Args A)
 {
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     const int wib = threadIdx.x >> 6;
@@ -624,8 +630,18 @@ __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
     float zi[C], z[C], r[C], e[C], u0[C], u1[C], u2[C];
+#ifdef DIFFUS_ABLATE_GATHER
+#pragma unroll
+    for (int j = 0; j < C; ++j) zi[j] = ps.sf[0] + (float)(j * kWave + lane) * ps.df[1];
+#else
     gather_interleaved<C, SAMPLER, LAYOUT, false, PM>(A, ps, lane, zi, u0, u1, u2);
+#endif
+#ifdef DIFFUS_ABLATE_TRANSPOSE
+#pragma unroll
+    for (int j = 0; j < C; ++j) z[j] = zi[j];
+#else
     to_chunked<C>(wb, lane, zi, z);
+#endif
     float zprev = __shfl_up(z[C - 1], 1, kWave);
     float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, n0, z, zprev, medv, r);
@@ -641,13 +657,25 @@ __global__ __launch_bounds__(kWave *WPB) void render_fwd_kernel(Args A)
         float att = fast_exp(__fmul_rn(A.neg_alpha, (float)(n0 + j)));
         e[j] = __fmul_rn(e[j], att);
     }
+#ifdef DIFFUS_ABLATE_TRANSPOSE
+#pragma unroll
+    for (int j = 0; j < C; ++j) zi[j] = e[j];
+#else
     to_interleaved<C>(wb, lane, e, zi);
+#endif
     float *out = A.frame + w * A.N1;
+#ifdef DIFFUS_ABLATE_STORE
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) acc += zi[j];
+    if (acc == 123.456f) out[lane] = acc;
+#else
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         int n = j * kWave + lane;
         if (n < A.N1) out[n] = zi[j];
     }
+#endif
 
     if (A.idx) {
         const long plane = (long)A.P * A.R * A.N1;
