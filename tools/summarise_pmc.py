@@ -26,15 +26,20 @@ def short(n):
     return n.split("<")[0].split("(")[0]
 
 
+def newest(pattern, recursive=False):
+    f = glob.glob(os.path.join(src, pattern), recursive=recursive)
+    return max(f, key=os.path.getmtime) if f else None
+
+
 def rows(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f = newest(pattern)
+    return list(csv.DictReader(open(f))) if f else []
 
 
 # 1. kernel stats as produced by rocprofv3
-ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+ks = newest(os.path.join("trace", "**", "*kernel_stats.csv"), recursive=True)
 if ks:
-    shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
+    shutil.copy(ks, f"profiles/{tag}_kernel_stats.csv")
 
 # 2. per-kernel durations of the batch launches (largest grid of each kernel = the P=32 workload)
 tr = rows("trace/**/*kernel_trace.csv") or rows("trace/*/*kernel_trace.csv")
