@@ -61,10 +61,10 @@ def vp(t):
 class HotPath:
     """Pre-allocated buffers + direct C-ABI calls (what a captured training step does)."""
 
-    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="bricked"):
+    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="paired"):
         self.lib = _lib.load()
         self.vol, self.src, self.dirs = vol, src, dirs
-        self.layout = {"canonical": 0, "bricked": 1}[layout]
+        self.layout = {"canonical": 0, "bricked": 1, "paired": 2}[layout]
         self.P, self.R = dirs.shape[0], dirs.shape[1]
         self.S, self.start, self.alpha = S, start, alpha
         self.sampler = {"nearest": 0, "trilinear": 1}[sampler]
@@ -75,12 +75,16 @@ class HotPath:
         d0, d1, d2 = vol.shape
         self.dims = (d0, d1, d2)
         self.gvol = torch.empty_like(vol) if want_gvol else None       # canonical gradient, what the caller gets
-        if self.layout == 1:
-            # HBM-resident bricked copy of the (constant) volume, made once outside the timed region;
+        if self.layout != 0:
+            # HBM-resident converted copy of the (constant) volume, made once outside the timed region;
             # the bricked gradient scratch is zeroed, filled and converted back EVERY step.
             nb = self.lib.diffus_bricked_floats(d0, d1, d2)
-            self.vol_k = torch.empty(nb, dtype=torch.float32, device=dev)
-            _lib.check(self.lib.diffus_brick_volume(vp(vol), d0, d1, d2, vp(self.vol_k), self.stream()), "brick")
+            if self.layout == 1:
+                self.vol_k = torch.empty(nb, dtype=torch.float32, device=dev)
+                _lib.check(self.lib.diffus_brick_volume(vp(vol), d0, d1, d2, vp(self.vol_k), self.stream()), "brick")
+            else:
+                self.vol_k = torch.empty(self.lib.diffus_paired_floats(d0, d1, d2), dtype=torch.float32, device=dev)
+                _lib.check(self.lib.diffus_pair_volume(vp(vol), d0, d1, d2, vp(self.vol_k), self.stream()), "pair")
             self.gvol_k = torch.empty(nb, dtype=torch.float32, device=dev) if want_gvol else None
         else:
             self.vol_k, self.gvol_k = vol, self.gvol
@@ -116,7 +120,7 @@ class HotPath:
 
     def finish_grad(self):
         """bricked gradient -> the caller's canonical (d0,d1,d2) tensor."""
-        if self.layout == 1 and self.gvol is not None:
+        if self.layout != 0 and self.gvol is not None:
             _lib.check(self.lib.diffus_unbrick_volume(vp(self.gvol_k), *self.dims, vp(self.gvol), 0, self.stream()),
                        "diffus_unbrick_volume")
 
@@ -192,7 +196,7 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="volume edge")
     ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
     ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
-    ap.add_argument("--layout", default="bricked", choices=["bricked", "canonical"])
+    ap.add_argument("--layout", default="paired", choices=["paired", "bricked", "canonical"])
     ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alpha", type=float, default=1e-4)

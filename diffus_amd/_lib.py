@@ -12,13 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so")
 
 EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
-           "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume",
+           "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume", "diffus_paired_floats",
+           "diffus_pair_volume",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces",
            "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
-CANONICAL, BRICKED = 0, 1
+CANONICAL, BRICKED, PAIRED = 0, 1, 2
 BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
 MAX_SAMPLES = 1024
 
@@ -56,6 +57,10 @@ def load():
     lib.diffus_trace_rays.argtypes = [vp, i, i, i, i, vp, i, vp, i, i, i, i, i, vp, vp, vp, vp]
     lib.diffus_bricked_floats.restype = sz
     lib.diffus_bricked_floats.argtypes = [i, i, i]
+    lib.diffus_paired_floats.restype = sz
+    lib.diffus_paired_floats.argtypes = [i, i, i]
+    lib.diffus_pair_volume.restype = i
+    lib.diffus_pair_volume.argtypes = [vp, i, i, i, vp, vp]
     lib.diffus_brick_volume.restype = i
     lib.diffus_brick_volume.argtypes = [vp, i, i, i, vp, vp]
     lib.diffus_unbrick_volume.restype = i

@@ -222,9 +222,19 @@ __device__ __forceinline__ int nearest_index(float p, int dim)
 //              and neighbouring steps/rays land in the same line.
 constexpr int kBrickFloats = 32;
 
+//   PAIRED:    (volume only) 4x4 columns x ONE depth z, each voxel stored as the float2
+//              (v[z], v[min(z+1, d2-1)]): every trilinear column is one aligned 8-byte load whatever
+//              the parity of z, and a fan sheet uses all 128 bytes of each line it touches.  Twice
+//              the memory of the volume; the gradient of a PAIRED volume is BRICKED.
 struct Geom {
     int d0, d1, d2;
     int nb1, nb2; // bricks along dim 1 / dim 2
+};
+
+// layout of the gradient buffer that goes with a volume layout
+template <int LAYOUT>
+struct GradLayout {
+    static constexpr int value = (LAYOUT == DIFFUS_PAIRED) ? DIFFUS_BRICKED : LAYOUT;
 };
 
 // 32-bit element offsets (the host refuses volumes of 2^30 floats or more): 64-bit address
@@ -234,6 +244,9 @@ __device__ __forceinline__ unsigned vox_off(const Geom &G, int x, int y, int z)
 {
     if (LAYOUT == DIFFUS_CANONICAL) {
         return ((unsigned)x * (unsigned)G.d1 + (unsigned)y) * (unsigned)G.d2 + (unsigned)z;
+    } else if (LAYOUT == DIFFUS_PAIRED) { // index of the .x half of the pair at (x,y,z)
+        unsigned col = ((unsigned)(x >> 2) * (unsigned)G.nb1 + (unsigned)(y >> 2)) * (unsigned)G.d2 + (unsigned)z;
+        return col * kBrickFloats + (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
     } else {
         unsigned brick = ((unsigned)(x >> 2) * (unsigned)G.nb1 + (unsigned)(y >> 2)) * (unsigned)G.nb2 + (unsigned)(z >> 1);
         return brick * kBrickFloats + (unsigned)(((x & 3) << 3) | ((y & 3) << 1) | (z & 1));
@@ -270,7 +283,11 @@ template <int LAYOUT>
 __device__ __forceinline__ void load_zpair(const float *__restrict__ vol, const Geom &G, int x, int y, const Axis &c,
                                            float &lo, float &hi)
 {
-    if (LAYOUT == DIFFUS_CANONICAL) {
+    if (LAYOUT == DIFFUS_PAIRED) {
+        float2 v = *reinterpret_cast<const float2 *>(vol + vox_off<LAYOUT>(G, x, y, c.i0));
+        lo = v.x;
+        hi = v.y; // = v[min(z0+1, d2-1)] by construction
+    } else if (LAYOUT == DIFFUS_CANONICAL) {
         const unsigned row = ((unsigned)x * (unsigned)G.d1 + (unsigned)y) * (unsigned)G.d2;
         if (G.d2 >= 2) {
             int b = min(c.i0, G.d2 - 2);
@@ -438,6 +455,9 @@ __device__ __forceinline__ unsigned col_off(const Geom &G, int x, int y)
     // final row stride, which is applied as a shift (bricked) or one 32-bit multiply (canonical)
     if (LAYOUT == DIFFUS_CANONICAL)
         return (__umul24((unsigned)x, (unsigned)G.d1) + (unsigned)y) * (unsigned)G.d2;
+    if (LAYOUT == DIFFUS_PAIRED)
+        return ((__umul24((unsigned)(x >> 2), (unsigned)G.nb1) + (unsigned)(y >> 2)) * (unsigned)G.d2 << 5) +
+               (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
     return ((__umul24((unsigned)(x >> 2), (unsigned)G.nb1) + (unsigned)(y >> 2)) * (unsigned)G.nb2 << 5) +
            (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
 }
@@ -445,6 +465,7 @@ template <int LAYOUT>
 __device__ __forceinline__ unsigned z_off(int z)
 {
     if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)z;
+    if (LAYOUT == DIFFUS_PAIRED) return (unsigned)z << 5;
     return (unsigned)(z >> 1) * kBrickFloats + (unsigned)(z & 1);
 }
 
@@ -509,6 +530,15 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps
                 unsigned c00 = col_off<LAYOUT>(A.G, a.i0, b.i0), c01 = col_off<LAYOUT>(A.G, a.i0, b.i1);
                 unsigned c10 = col_off<LAYOUT>(A.G, a.i1, b.i0), c11 = col_off<LAYOUT>(A.G, a.i1, b.i1);
                 unsigned z0 = z_off<LAYOUT>(c.i0), z1 = z_off<LAYOUT>(c.i1);
+                if constexpr (LAYOUT == DIFFUS_PAIRED) { // 4 aligned 8-byte loads: (z0, z0+1) of each column
+                    float2 q00 = *reinterpret_cast<const float2 *>(vol + (c00 + z0));
+                    float2 q01 = *reinterpret_cast<const float2 *>(vol + (c01 + z0));
+                    float2 q10 = *reinterpret_cast<const float2 *>(vol + (c10 + z0));
+                    float2 q11 = *reinterpret_cast<const float2 *>(vol + (c11 + z0));
+                    raw[jj][0] = q00.x; raw[jj][1] = q00.y; raw[jj][2] = q01.x; raw[jj][3] = q01.y;
+                    raw[jj][4] = q10.x; raw[jj][5] = q10.y; raw[jj][6] = q11.x; raw[jj][7] = q11.y;
+                    (void)z1;
+                } else {
 #ifdef DIFFUS_ABLATE_LOADS
                 raw[jj][0] = __uint_as_float(c00 + z0); raw[jj][1] = __uint_as_float(c00 + z1);
                 raw[jj][2] = __uint_as_float(c01 + z0); raw[jj][3] = __uint_as_float(c01 + z1);
@@ -520,6 +550,7 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps
                 raw[jj][4] = vol[c10 + z0]; raw[jj][5] = vol[c10 + z1];
                 raw[jj][6] = vol[c11 + z0]; raw[jj][7] = vol[c11 + z1];
 #endif
+                }
                 ta[jj] = a.t; tb[jj] = b.t; tc[jj] = c.t;
                 if (GRAD) mk[jj] = (a.m != 0.f ? 1u : 0u) | (b.m != 0.f ? 2u : 0u) | (c.m != 0.f ? 4u : 0u);
             }
@@ -1277,7 +1308,7 @@ __global__ void median_bwd_kernel(Args A)
         if (A.gvol) {
             Cell c = cell_of<SAMPLER>(A, ps, k);
             for_each_corner<SAMPLER>(c, zb[q], [&](int a, int b, int cc, float v) {
-                if (v != 0.f) atomicAdd(A.gvol + vox_off<LAYOUT>(A.G, a, b, cc), v);
+                if (v != 0.f) atomicAdd(A.gvol + vox_off<GradLayout<LAYOUT>::value>(A.G, a, b, cc), v);
             });
         }
         if (SAMPLER == DIFFUS_TRILINEAR) {
@@ -1683,6 +1714,27 @@ __global__ void loss_finish_kernel(const float *__restrict__ part, float *__rest
     loss[p] = t;
 }
 
+// canonical -> PAIRED: a block writes 4 x 4 columns x 32 depths (4 KiB contiguous) from 16 canonical
+// rows of 33 floats, through LDS.
+__global__ __launch_bounds__(kBlock) void pair_convert_kernel(const float *__restrict__ in, float *__restrict__ out, Geom G)
+{
+    __shared__ float t[16][34];
+    const int z0 = blockIdx.x * 32;
+    const int by = blockIdx.y, bx = blockIdx.z;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 16 * 33; e += kBlock) {
+        int row = e / 33, zz = e - row * 33;
+        int x = min(bx * 4 + (row >> 2), G.d0 - 1), y = min(by * 4 + (row & 3), G.d1 - 1), z = min(z0 + zz, G.d2 - 1);
+        t[row][zz] = in[((long)x * G.d1 + y) * G.d2 + z];
+    }
+    __syncthreads();
+    const long col0 = ((long)bx * G.nb1 + by) * G.d2 + z0;
+    for (int e = tid; e < 32 * kBrickFloats; e += kBlock) {
+        int zz = e >> 5, off = e & 31;
+        if (z0 + zz < G.d2) out[(col0 + zz) * kBrickFloats + off] = t[off >> 1][zz + (off & 1)];
+    }
+}
+
 // ----------------------------------------------------------------------------
 // host side
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1700,6 +1752,12 @@ size_t bricked_floats(int d0, int d1, int d2)
 {
     Geom G = make_geom(d0, d1, d2);
     return (size_t)((d0 + 3) / 4) * G.nb1 * G.nb2 * kBrickFloats;
+}
+
+size_t paired_floats(int d0, int d1, int d2)
+{
+    Geom G = make_geom(d0, d1, d2);
+    return (size_t)((d0 + 3) / 4) * G.nb1 * d2 * kBrickFloats;
 }
 
 struct Workspace {
@@ -1742,11 +1800,12 @@ int check_common(const float *vol, int d0, int d1, int d2, const void *src, int 
     if ((src_dtype != DIFFUS_F32 && src_dtype != DIFFUS_F64) || (dirs_dtype != DIFFUS_F32 && dirs_dtype != DIFFUS_F64))
         return DIFFUS_EINVAL;
     if (sampler != DIFFUS_NEAREST && sampler != DIFFUS_TRILINEAR) return DIFFUS_EINVAL;
-    if (layout != DIFFUS_CANONICAL && layout != DIFFUS_BRICKED) return DIFFUS_EINVAL;
+    if (layout != DIFFUS_CANONICAL && layout != DIFFUS_BRICKED && layout != DIFFUS_PAIRED) return DIFFUS_EINVAL;
     if (start < 0 || start > S - 1) return DIFFUS_EINVAL;
     if (start > 0 && start > S - 2) return DIFFUS_EINVAL; // reference raises IndexError at :243
     if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24)) return DIFFUS_EUNSUPPORTED; // float(dim-1) must be exact
     if (bricked_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;    // 32-bit element offsets
+    if (layout == DIFFUS_PAIRED && paired_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;
     if (need_scan && S - start > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
     if (start > 0 && (size_t)R * sizeof(float) > 64 * 1024) return DIFFUS_EUNSUPPORTED; // median LDS
     return DIFFUS_OK;
@@ -1769,16 +1828,22 @@ Args make_args(const float *vol, int d0, int d1, int d2, const void *src, int sr
 int last_launch() { return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH; }
 
 // (sampler, layout) -> compile-time constants
+template <int SM, typename F>
+int dispatch_layout(int layout, F &&f)
+{
+    using S_ = std::integral_constant<int, SM>;
+    switch (layout) {
+    case DIFFUS_CANONICAL: return f(S_{}, std::integral_constant<int, DIFFUS_CANONICAL>{});
+    case DIFFUS_BRICKED: return f(S_{}, std::integral_constant<int, DIFFUS_BRICKED>{});
+    default: return f(S_{}, std::integral_constant<int, DIFFUS_PAIRED>{});
+    }
+}
+
 template <typename F>
 int dispatch_sl(int sampler, int layout, F &&f)
 {
-    if (sampler == DIFFUS_NEAREST)
-        return layout == DIFFUS_CANONICAL
-                   ? f(std::integral_constant<int, DIFFUS_NEAREST>{}, std::integral_constant<int, DIFFUS_CANONICAL>{})
-                   : f(std::integral_constant<int, DIFFUS_NEAREST>{}, std::integral_constant<int, DIFFUS_BRICKED>{});
-    return layout == DIFFUS_CANONICAL
-               ? f(std::integral_constant<int, DIFFUS_TRILINEAR>{}, std::integral_constant<int, DIFFUS_CANONICAL>{})
-               : f(std::integral_constant<int, DIFFUS_TRILINEAR>{}, std::integral_constant<int, DIFFUS_BRICKED>{});
+    return sampler == DIFFUS_NEAREST ? dispatch_layout<DIFFUS_NEAREST>(layout, f)
+                                     : dispatch_layout<DIFFUS_TRILINEAR>(layout, f);
 }
 
 int launch_median(const Args &A, int sampler, int layout, hipStream_t st)
@@ -1878,6 +1943,22 @@ size_t diffus_bricked_floats(int d0, int d1, int d2)
     return bricked_floats(d0, d1, d2);
 }
 
+size_t diffus_paired_floats(int d0, int d1, int d2)
+{
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
+    return paired_floats(d0, d1, d2);
+}
+
+int diffus_pair_volume(const float *vol, int d0, int d1, int d2, float *paired, diffus_stream_t stream)
+{
+    if (!vol || !paired || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    dim3 grid((d2 + 31) / 32, G.nb1, (d0 + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
+    hipLaunchKernelGGL(pair_convert_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, vol, paired, G);
+    return last_launch();
+}
+
 int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked, diffus_stream_t stream)
 {
     if (!vol || !bricked || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
@@ -1960,8 +2041,9 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
         const int rgs = (R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
         const unsigned nb = (unsigned)((long)P * rgs * sgs);
         const bool f32 = !A.src_f64 && !A.dir_f64;
-        rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
-            constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+        const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout; // the scatter only sees the gradient
+        rc = dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
+            constexpr int SM = decltype(S_)::value, LY = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
             if (f32)
                 hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
             else

@@ -19,9 +19,10 @@ Differences from the reference, all deliberate:
     (:237-238); the reference crashes on it inside its visualisation (:774);
   * `render_poses` batches P poses in one launch;
   * `layout=` selects the HBM layout the kernels read: "canonical" (the caller's
-    tensor), "bricked" (a cached 4x4x2-brick copy, DESIGN.md §Data layout) or
-    "auto"; a `BrickedVolume` keeps a volume (e.g. a learnable impedance map)
-    permanently bricked so that no conversion happens per step.
+    tensor), "bricked" / "paired" (cached converted copies, DESIGN.md §Data layout)
+    or "auto" (= paired once a volume is used for a large or a second call); a
+    `BrickedVolume` keeps a volume (e.g. a learnable impedance map) permanently
+    bricked so that no conversion happens per step.
 """
 from __future__ import annotations
 
@@ -37,7 +38,7 @@ from . import _lib
 log = logging.getLogger("diffus_amd")
 
 _SAMPLERS = {"nearest": _lib.NEAREST, "prop": _lib.NEAREST, "trilinear": _lib.TRILINEAR}
-_LAYOUTS = ("auto", "canonical", "bricked")
+_LAYOUTS = ("auto", "canonical", "bricked", "paired")
 _workspaces: dict = {}
 _brick_cache: list = []     # [(weakref(source tensor), version, bricked copy)]   (at most 2 entries)
 _brick_seen: list = []      # [(weakref(source tensor), version, calls)]
@@ -112,6 +113,19 @@ def brick_volume(volume: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pair_volume(volume: torch.Tensor) -> torch.Tensor:
+    """canonical (d0,d1,d2) -> flat paired float32 tensor on the GPU (diffus_pair_volume)."""
+    lib = _lib.load()
+    dev = _device_for(volume)
+    v = volume.detach().to(device=dev, dtype=torch.float32).contiguous()
+    d0, d1, d2 = v.shape
+    with torch.cuda.device(dev):
+        out = torch.empty(lib.diffus_paired_floats(d0, d1, d2), dtype=torch.float32, device=dev)
+        rc = lib.diffus_pair_volume(_ptr(v), d0, d1, d2, _ptr(out), _stream(dev))
+    _lib.check(rc, "diffus_pair_volume")
+    return out
+
+
 def unbrick_volume(bricked: torch.Tensor, shape, out: Optional[torch.Tensor] = None, accumulate=False):
     """flat bricked tensor -> canonical (d0,d1,d2) float32 (diffus_unbrick_volume)."""
     lib = _lib.load()
@@ -126,19 +140,21 @@ def unbrick_volume(bricked: torch.Tensor, shape, out: Optional[torch.Tensor] = N
     return out
 
 
-def _bricked_copy(vol: torch.Tensor, src_tensor: torch.Tensor, want: str, samples: int):
-    """Return the cached bricked copy of `vol` if the layout policy asks for one, else None.
+def _converted_copy(vol: torch.Tensor, src_tensor: torch.Tensor, want: str, samples: int):
+    """Return (cached converted copy, layout id) if the layout policy asks for one, else (None, CANONICAL).
 
-    Entries are keyed by the IDENTITY of the caller's tensor (weak reference) and
-    its in-place version counter -- never by address, which the allocator reuses.
+    Entries are keyed by the IDENTITY of the caller's tensor (weak reference), its in-place
+    version counter and the layout -- never by address, which the allocator reuses.
     """
     if want == "canonical":
-        return None
+        return None, _lib.CANONICAL
+    kind = "bricked" if want == "bricked" else "paired"
+    lid = _lib.BRICKED if kind == "bricked" else _lib.PAIRED
     ver = src_tensor._version
     _brick_cache[:] = [e for e in _brick_cache if e[0]() is not None]
-    for ref, v, b in _brick_cache:
-        if ref() is src_tensor and v == ver:
-            return b
+    for ref, v, k, b in _brick_cache:
+        if ref() is src_tensor and v == ver and k == kind:
+            return b, lid
     _brick_seen[:] = [e for e in _brick_seen if e[0]() is not None][-16:]
     calls = 1
     for i, (ref, v, n) in enumerate(_brick_seen):
@@ -149,11 +165,11 @@ def _bricked_copy(vol: torch.Tensor, src_tensor: torch.Tensor, want: str, sample
     else:
         _brick_seen.append((weakref.ref(src_tensor), ver, 1))
     if want == "auto" and samples < _AUTO_BRICK_SAMPLES and calls < 2:
-        return None
-    b = brick_volume(vol)
-    _brick_cache.append((weakref.ref(src_tensor), ver, b))
+        return None, _lib.CANONICAL
+    b = brick_volume(vol) if kind == "bricked" else pair_volume(vol)
+    _brick_cache.append((weakref.ref(src_tensor), ver, kind, b))
     del _brick_cache[:-2]
-    return b
+    return b, lid
 
 
 def resolve_start(start, num_samples: int) -> int:
@@ -202,12 +218,13 @@ class _Problem:
         self.src_dt = _lib.DIFFUS_F64 if sd == torch.float64 else _lib.DIFFUS_F32
         self.dir_dt = _lib.DIFFUS_F64 if dd == torch.float64 else _lib.DIFFUS_F32
         if self.bricked is None:
-            self.bricked = _bricked_copy(self.vol, volume, layout, self.P * self.R * self.N1)
-        self.layout = _lib.BRICKED if self.bricked is not None else _lib.CANONICAL
+            self.bricked, self.layout = _converted_copy(self.vol, volume, layout, self.P * self.R * self.N1)
+        else:
+            self.layout = _lib.BRICKED
 
     def common(self):
         d0, d1, d2 = self.shape
-        v = self.bricked if self.layout == _lib.BRICKED else self.vol
+        v = self.bricked if self.layout != _lib.CANONICAL else self.vol
         return (_ptr(v), d0, d1, d2, self.layout, _ptr(self.src), self.src_dt, _ptr(self.dirs), self.dir_dt,
                 self.P, self.R, self.S, self.start, self.alpha, self.sampler)
 
@@ -246,8 +263,11 @@ class _RenderFn(torch.autograd.Function):
         with torch.cuda.device(pb.dev):
             g = gframe.detach().to(device=pb.dev, dtype=torch.float32).contiguous()
             gvol = None
-            if need_v:      # gradient buffer in the layout the kernels ran in
-                gvol = torch.zeros_like(pb.bricked if pb.layout == _lib.BRICKED else pb.vol)
+            if need_v:      # gradient buffer in the layout that goes with the volume's
+                if pb.layout == _lib.CANONICAL:
+                    gvol = torch.zeros_like(pb.vol)
+                else:
+                    gvol = torch.zeros(lib.diffus_bricked_floats(*pb.shape), dtype=torch.float32, device=pb.dev)
             gsrc = torch.empty((pb.P, 3), dtype=torch.float32, device=pb.dev) if need_s else None
             gdirs = torch.empty((pb.P, pb.R, 3), dtype=torch.float32, device=pb.dev) if need_d else None
             ws = pb.workspace()
@@ -256,7 +276,7 @@ class _RenderFn(torch.autograd.Function):
         _lib.check(rc, "diffus_render_bwd")
         out_v = None
         if need_v:
-            if pb._layout_req != "prebricked" and pb.layout == _lib.BRICKED:
+            if pb._layout_req != "prebricked" and pb.layout != _lib.CANONICAL:
                 gvol = unbrick_volume(gvol, pb.shape)       # back to the caller's (d0,d1,d2)
             out_v = gvol.to(device=vdev, dtype=vdt)
         out_s = gsrc.reshape(sshape).to(device=sdev, dtype=sdt) if need_s else None

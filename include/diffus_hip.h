@@ -60,6 +60,9 @@ extern "C" {
 #define DIFFUS_CANONICAL 0 /* the caller's (d0,d1,d2) row-major tensor */
 #define DIFFUS_BRICKED   1 /* 4x4x2-voxel bricks of 32 floats (one 128-B line), row-major over
                               (ceil(d0/4), ceil(d1/4), ceil(d2/2)); made by diffus_brick_volume */
+#define DIFFUS_PAIRED    2 /* volume only: 4x4 columns x one depth z per 128-B line, each voxel stored as
+                              the pair (v[z], v[min(z+1,d2-1)]); made by diffus_pair_volume; twice the
+                              memory; the gradient that goes with it (gvol) is DIFFUS_BRICKED */
 
 /* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples,
  * at most 16 -> N1 <= 1024 */
@@ -80,12 +83,17 @@ size_t diffus_workspace_bytes(int P, int R, int S, int start);
  * constant dim 2 (src/cone.py:258) -- the worst case for that layout.  The
  * kernels therefore also accept a bricked copy (DIFFUS_BRICKED).  These two calls
  * convert; both are coalesced streaming passes over the volume.
+ *   diffus_paired_floats   number of floats of the paired buffer (about 2*d0*d1*d2)
+ *   diffus_pair_volume     canonical -> paired
  *   diffus_bricked_floats  number of floats of the bricked buffer (>= d0*d1*d2)
  *   diffus_brick_volume    canonical -> bricked (padding voxels are written as 0)
  *   diffus_unbrick_volume  bricked -> canonical; accumulate != 0 adds instead of
  *                          storing (used to fold a bricked gradient into a
  *                          canonical one)
  */
+size_t diffus_paired_floats(int d0, int d1, int d2);
+int diffus_pair_volume(const float *vol, int d0, int d1, int d2, float *paired,
+                       diffus_stream_t stream);
 size_t diffus_bricked_floats(int d0, int d1, int d2);
 int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked,
                         diffus_stream_t stream);
@@ -120,8 +128,9 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
  * compute_echo_traces (:439-457) -> attenuation (:256-259), see SURVEY.md §3.2 /
  * App. A.4, without storing any dense system: given gframe = dL/dframe (P,R,N1) it recomputes the forward
  * per ray and produces any of
- *   gvol   nullable, float32 in the SAME layout as vol ((d0,d1,d2) canonical or
- *          diffus_bricked_floats() bricked), ACCUMULATED with float atomics
+ *   gvol   nullable, float32 in the layout that goes with vol's ((d0,d1,d2) canonical for a
+ *          canonical vol, diffus_bricked_floats() bricked for a bricked or paired vol),
+ *          ACCUMULATED with float atomics
  *          (caller zeroes it; shared by all poses)
  *   gsrc   nullable (P,3) float32, overwritten   (trilinear only, else zeros)
  *   gdirs  nullable (P,R,3) float32, overwritten (trilinear only, else zeros)

@@ -97,7 +97,7 @@ def test_echo_adversarial_growth(da, oracle):
 
 
 # ----------------------------------------------------------------------------- stage 1: sampling
-@pytest.mark.parametrize("layout", ["canonical", "bricked"])
+@pytest.mark.parametrize("layout", ["canonical", "bricked", "paired"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
 def test_trace_rays_vs_oracle(da, oracle, vols, sampler, layout):
     g = load_golden("g5_small_frames")
@@ -128,7 +128,7 @@ def test_trilinear_vs_grid_sample_golden(da):
 
 
 # ----------------------------------------------------------------------------- whole frames vs the reference
-@pytest.mark.parametrize("layout", ["canonical", "bricked"])
+@pytest.mark.parametrize("layout", ["canonical", "bricked", "paired"])
 def test_plot_beam_frame_golden_small(da, oracle, vols, layout):
     g = load_golden("g5_small_frames")
     for t in [str(x) for x in g["tags"]]:
@@ -183,7 +183,7 @@ def test_config2_golden(da, vol256):
 @pytest.mark.parametrize("S,start,R", [(2, 0, 2), (3, 1, 3), (48, 46, 5), (65, 0, 1), (130, 1, 7), (257, 0, 3),
                                        (513, 0, 2), (1024, 0, 3), (1030, 6, 2)])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
-@pytest.mark.parametrize("layout", ["canonical", "bricked"])
+@pytest.mark.parametrize("layout", ["canonical", "bricked", "paired"])
 def test_shapes_and_edges_vs_oracle(da, oracle, vols, S, start, R, sampler, layout):
     src, dirs = pose_ring(64, 3, R)
     vol = vols[64]
@@ -212,7 +212,7 @@ def test_zero_impedance_and_degenerate_volume(da, oracle):
     src = np.array([2.0, 16.0, 16.0], np.float32)
     dirs = np.array([[1.0, 0.0, 0.0], [0.9, 0.1, 0.0]], np.float32)
     for sampler, layout in (("nearest", "canonical"), ("trilinear", "canonical"), ("nearest", "bricked"),
-                            ("trilinear", "bricked")):
+                            ("trilinear", "bricked"), ("nearest", "paired"), ("trilinear", "paired")):
         f = da.render_poses(cuda(vol), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
                             sampler=sampler, layout=layout).cpu().numpy()[0]
         _, _, _, fo = oracle.plot_beam_frame(vol, src, dirs, 30, 1e-3, 0, sampler=sampler)
@@ -221,7 +221,7 @@ def test_zero_impedance_and_degenerate_volume(da, oracle):
         assert np.all(f[0, 12:] == 0)
     flat = phantom(32)[:, :, :1].copy()   # d2 == 1: the paired dim-2 load must not be used
     _, _, _, fo = oracle.plot_beam_frame(flat, src, dirs, 30, 1e-3, 0, sampler="trilinear")
-    for layout in ("canonical", "bricked"):
+    for layout in ("canonical", "bricked", "paired"):
         f = da.render_poses(cuda(flat), torch.from_numpy(src), torch.from_numpy(dirs), 30, 1e-3,
                             sampler="trilinear", layout=layout).cpu().numpy()[0]
         assert maxnorm_rel(f, fo) < 2e-5
@@ -241,7 +241,7 @@ def _autograd_case(vol_np, src, dirs, S, alpha, start, sampler, gseed=0):
         (d.grad.numpy() if d.grad is not None else None)
 
 
-@pytest.mark.parametrize("layout", ["canonical", "bricked"])
+@pytest.mark.parametrize("layout", ["canonical", "bricked", "paired"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
 @pytest.mark.parametrize("S,start", [(48, 0), (48, 7), (150, 0), (300, 12), (700, 0)])
 def test_backward_vs_float64_autograd(da, vols, sampler, S, start, layout):
@@ -336,7 +336,8 @@ def test_full_size_batch_vs_oracle_and_properties(da, oracle, vol256):
     src, dirs = pose_ring(256, P, R)
     vol = cuda(vol256)
     s, d = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
-    for sampler, layout in (("nearest", "bricked"), ("trilinear", "bricked"), ("trilinear", "canonical")):
+    for sampler, layout in (("nearest", "bricked"), ("trilinear", "bricked"), ("trilinear", "canonical"),
+                            ("trilinear", "paired"), ("nearest", "paired")):
         f = da.render_poses(vol, s, d, S, alpha, sampler=sampler, layout=layout)
         assert f.shape == (P, R, S)
         fc = f.cpu().numpy()
@@ -348,7 +349,7 @@ def test_full_size_batch_vs_oracle_and_properties(da, oracle, vol256):
         f2 = da.render_poses(vol, s[5:6], d[5:6], S, alpha, sampler=sampler, layout=layout)
         assert torch.equal(f2[0], f[5])
         assert torch.equal(da.render_poses(vol, s, d, S, alpha, sampler=sampler, layout=layout), f)
-        if layout == "bricked":       # the layout must not change a single bit of the frame
+        if layout != "canonical":     # the layout must not change a single bit of the frame
             assert torch.equal(da.render_poses(vol, s, d, S, alpha, sampler=sampler, layout="canonical"), f)
 
 

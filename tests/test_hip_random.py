@@ -42,7 +42,7 @@ def test_random_forward_vs_oracle(oracle, seed):
     vol, src, dirs, S, start, alpha = _case(seed)
     for sampler in ("nearest", "trilinear"):
         x, y, z, fo = oracle.plot_beam_frame(vol, src, dirs, S, alpha, start, sampler=sampler)
-        for layout in ("canonical", "bricked"):
+        for layout in ("canonical", "bricked", "paired"):
             f, idx = diffus_amd.render_poses(torch.from_numpy(vol).cuda(), torch.from_numpy(src), torch.from_numpy(dirs), S,
                                              alpha, start=start, sampler=sampler, return_indices=True, layout=layout)
             f = f[0].cpu().numpy()
@@ -72,7 +72,7 @@ def test_random_backward_vs_autograd(seed):
         f64 = ar.render(v64, s64, d64, S, alpha, start, sampler)
         up = torch.randn(f64.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
         (f64 * up).sum().backward()
-        for layout in ("canonical", "bricked"):
+        for layout in ("canonical", "bricked", "paired"):
             v = torch.from_numpy(vol).cuda().requires_grad_(True)
             s = torch.from_numpy(src).cuda().requires_grad_(True)
             d = torch.from_numpy(dirs).cuda().requires_grad_(True)
