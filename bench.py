@@ -9,9 +9,9 @@ Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays 
 512 steps.  One *step* = one pass of the hot path over one batch of poses:
   forward frame (diffus_render_fwd)
   -> loss_p = sum(frame_p^2), dL/dframe = 2 frame (diffus_loss_sumsq)
-  -> zero the volume-gradient buffer
+  -> zero the caller's canonical (d0,d1,d2) volume-gradient tensor
   -> backward (diffus_render_bwd: d/d volume, d/d source, d/d directions)
-  -> bricked gradient -> the caller's canonical (d0,d1,d2) tensor
+  -> touched bricks of the gradient scratch -> added into that tensor (diffus_gradbuf_flush)
   -> gather of the per-pose losses over ranks (RCCL, N > 1).
 Workload at N=1 = BASELINE config 3 (32 poses of the config-2 shape on one GPU;
 a single 256x512 frame is only 256 wavefronts, i.e. launch-latency-bound, and is
@@ -61,7 +61,7 @@ def vp(t):
 class HotPath:
     """Pre-allocated buffers + direct C-ABI calls (what a captured training step does)."""
 
-    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="paired"):
+    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="paired", sparse=True):
         self.lib = _lib.load()
         self.vol, self.src, self.dirs = vol, src, dirs
         self.layout = {"canonical": 0, "bricked": 1, "paired": 2}[layout]
@@ -85,9 +85,13 @@ class HotPath:
             else:
                 self.vol_k = torch.empty(self.lib.diffus_paired_floats(d0, d1, d2), dtype=torch.float32, device=dev)
                 _lib.check(self.lib.diffus_pair_volume(vp(vol), d0, d1, d2, vp(self.vol_k), self.stream()), "pair")
-            self.gvol_k = torch.empty(nb, dtype=torch.float32, device=dev) if want_gvol else None
+            # sparse gradient hand-back: the bricked scratch and its touched-brick flags are all-zero
+            # between steps (diffus_gradbuf_flush restores that), only touched bricks are converted
+            self.gvol_k = torch.zeros(nb, dtype=torch.float32, device=dev) if want_gvol else None
+            self.touched = (torch.zeros(self.lib.diffus_brick_count(d0, d1, d2), dtype=torch.int32, device=dev)
+                            if (want_gvol and sparse) else None)
         else:
-            self.vol_k, self.gvol_k = vol, self.gvol
+            self.vol_k, self.gvol_k, self.touched = vol, self.gvol, None
         self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
         self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
@@ -105,9 +109,9 @@ class HotPath:
                                               self.stream()), "diffus_render_fwd")
 
     def bwd(self, stages=_lib.BWD_ALL):
-        _lib.check(self.lib.diffus_render_bwd(*self.common, vp(self.gframe), vp(self.gvol_k), vp(self.gsrc),
-                                              vp(self.gdirs), stages, vp(self.ws), self.ws.numel(), self.stream()),
-                   "diffus_render_bwd")
+        _lib.check(self.lib.diffus_render_bwd(*self.common, vp(self.gframe), vp(self.gvol_k), vp(self.touched),
+                                              vp(self.gsrc), vp(self.gdirs), stages, vp(self.ws), self.ws.numel(),
+                                              self.stream()), "diffus_render_bwd")
 
     def loss_and_grad(self):
         _lib.check(self.lib.diffus_loss_sumsq(vp(self.frame), self.P, self.R * self.N1, vp(self.loss),
@@ -115,12 +119,18 @@ class HotPath:
                    "diffus_loss_sumsq")
 
     def zero_grad(self):
-        if self.gvol_k is not None:
-            self.gvol_k.zero_()
+        """A fresh dense gradient every step: zero the caller's canonical (d0,d1,d2) tensor (sparse
+        hand-back), or the bricked scratch (dense hand-back: the conversion overwrites every voxel)."""
+        if self.gvol is not None:
+            (self.gvol if (self.touched is not None or self.layout == 0) else self.gvol_k).zero_()
 
     def finish_grad(self):
-        """bricked gradient -> the caller's canonical (d0,d1,d2) tensor."""
-        if self.layout != 0 and self.gvol is not None:
+        """touched bricks of the scratch -> added into the canonical gradient; scratch back to all-zero."""
+        if self.layout != 0 and self.gvol is not None and self.touched is not None:
+            # accumulate = 0: the tensor was zeroed this step and every touched voxel is written once
+            _lib.check(self.lib.diffus_gradbuf_flush(vp(self.gvol_k), vp(self.touched), *self.dims, vp(self.gvol), 0,
+                                                     self.stream()), "diffus_gradbuf_flush")
+        elif self.layout != 0 and self.gvol is not None:
             _lib.check(self.lib.diffus_unbrick_volume(vp(self.gvol_k), *self.dims, vp(self.gvol), 0, self.stream()),
                        "diffus_unbrick_volume")
 
@@ -197,6 +207,8 @@ def main():
     ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
     ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
     ap.add_argument("--layout", default="paired", choices=["paired", "bricked", "canonical"])
+    ap.add_argument("--dense-grad", action="store_true",
+                    help="hand the gradient back by a dense conversion instead of the touched-brick flush")
     ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alpha", type=float, default=1e-4)
@@ -231,7 +243,7 @@ def main():
     src = torch.from_numpy(src_all[lo:lo + args.poses]).to(dev).contiguous()
     dirs = torch.from_numpy(dirs_all[lo:lo + args.poses]).to(dev).contiguous()
     hp = HotPath(vol, src, dirs, args.samples, args.alpha, args.sampler, want_gvol=not args.no_gvol,
-                 layout=args.layout)
+                 layout=args.layout, sparse=not args.dense_grad)
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
 
     # --- the step: eager launches, or one captured hipGraph (compute) + the collective ---
@@ -290,7 +302,9 @@ def main():
     k_ms = {"render_fwd_kernel": time_events(hp.fwd, it),
             "render_bwd_kernel": time_events(lambda: hp.bwd(_lib.BWD_SCAN), it)}
     if not args.no_gvol:
-        k_ms["scatter_patch_kernel"] = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), it, pre=hp.zero_grad)
+        k_ms["scatter_patch_kernel"] = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), it,
+                                                   pre=(hp.finish_grad if hp.touched is not None else hp.zero_grad))
+        hp.finish_grad()
     local_rs = args.poses * args.rays * args.samples
     b = BYTES[args.sampler]
     dom = max(k_ms, key=lambda k: k_ms[k]["mean"])
@@ -307,7 +321,7 @@ def main():
 
     # --- single-pose latency (BASELINE config 2): 1 pose, fwd + bwd, eager and graph-replayed ---
     hp1 = HotPath(vol, src[:1].contiguous(), dirs[:1].contiguous(), args.samples, args.alpha, args.sampler,
-                  want_gvol=not args.no_gvol, layout=args.layout)
+                  want_gvol=not args.no_gvol, layout=args.layout, sparse=not args.dense_grad)
     for _ in range(5):
         hp1.step()
     sp = time_events(hp1.step, 20)
@@ -345,7 +359,7 @@ def main():
                              f"+ canonical gradient + per-pose loss gather"),
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": 0, "alpha": args.alpha,
-                "layout": args.layout, "issue": "hipGraph replay" if graph is not None else "eager",
+                "layout": args.layout, "grad_handback": "dense" if args.dense_grad else "sparse (touched bricks)", "issue": "hipGraph replay" if graph is not None else "eager",
                 "parallelism": f"poses sharded x{ngpu}, volume replicated",
             },
             "roofline": {

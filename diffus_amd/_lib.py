@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so
 
 EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
            "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume", "diffus_paired_floats",
-           "diffus_pair_volume",
+           "diffus_pair_volume", "diffus_brick_count", "diffus_gradbuf_flush",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces",
            "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd")
 
@@ -50,7 +50,11 @@ def load():
     lib.diffus_render_fwd.restype = i
     lib.diffus_render_fwd.argtypes = common + [vp, vp, vp, sz, vp]
     lib.diffus_render_bwd.restype = i
-    lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, i, vp, sz, vp]
+    lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, vp, i, vp, sz, vp]
+    lib.diffus_brick_count.restype = sz
+    lib.diffus_brick_count.argtypes = [i, i, i]
+    lib.diffus_gradbuf_flush.restype = i
+    lib.diffus_gradbuf_flush.argtypes = [vp, vp, i, i, i, vp, i, vp]
     lib.diffus_loss_sumsq.restype = i
     lib.diffus_loss_sumsq.argtypes = [vp, i, C.c_long, vp, vp, vp, sz, vp]
     lib.diffus_trace_rays.restype = i

@@ -373,7 +373,8 @@ struct Args {
     long long *idx;
     // backward
     const float *gframe;
-    float *gvol;      // same layout as vol
+    float *gvol;      // layout that goes with vol's (GradLayout)
+    int *gtouched;    // nullable: one flag per gradient brick, set when a launch adds into it (bricked only)
     float *zbar;      // (P,R,N1) d L / d imp per sample, consumed by scatter_patch_kernel
     float *gsrc_part; // (P,R,3) per-ray partials of d/d source
     float *gdirs;
@@ -1137,7 +1138,11 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         for (int q = 0; q < kSamplesPerThread; ++q)
             if (zb[q] != 0.f)
                 for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
-                    if (v != 0.f) atomicAdd(A.gvol + vox_off<LAYOUT>(A.G, i, j, k), v);
+                    if (v != 0.f) {
+                        unsigned g = vox_off<LAYOUT>(A.G, i, j, k);
+                        atomicAdd(A.gvol + g, v);
+                        if (LAYOUT == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
+                    }
                 });
         return;
     }
@@ -1198,7 +1203,10 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     for (int i = 0; i < b0; ++i) {
         for (int m = msub; m < b12; m += mstep) {
             int v = tile[(i * b12 + m) * UNIT + o];
-            if (v != 0) {
+            // a half-wave = one brick (bricked) -- skip the address arithmetic for all-zero bricks
+            bool any = v != 0;
+            if (UNIT != 1) any = (unsigned)(__ballot(v != 0) >> (tid & 32)) != 0u;
+            if (any) {
                 int j = __float2int_rz(((float)m + 0.5f) * rb2); // exact: m < 2^14, b2 <= 2^14
                 int k = m - j * b2;
                 unsigned g;
@@ -1206,7 +1214,10 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
                     g = ((unsigned)(l0 + i) * (unsigned)A.G.d1 + (unsigned)(l1 + j)) * (unsigned)A.G.d2 + (unsigned)(l2 + k);
                 else
                     g = (((unsigned)(l0 + i) * (unsigned)A.G.nb1 + (unsigned)(l1 + j)) * (unsigned)A.G.nb2 + (unsigned)(l2 + k)) * kBrickFloats + (unsigned)o;
-                atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
+                // one plain, idempotent flag store per touched brick; no returning atomic (its latency
+                // would sit on the flush path)
+                if (LAYOUT == DIFFUS_BRICKED && A.gtouched && o == 0) A.gtouched[g >> 5] = 1;
+                if (v != 0) atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
             }
         }
     }
@@ -1308,7 +1319,11 @@ __global__ void median_bwd_kernel(Args A)
         if (A.gvol) {
             Cell c = cell_of<SAMPLER>(A, ps, k);
             for_each_corner<SAMPLER>(c, zb[q], [&](int a, int b, int cc, float v) {
-                if (v != 0.f) atomicAdd(A.gvol + vox_off<GradLayout<LAYOUT>::value>(A.G, a, b, cc), v);
+                if (v != 0.f) {
+                    unsigned g = vox_off<GradLayout<LAYOUT>::value>(A.G, a, b, cc);
+                    atomicAdd(A.gvol + g, v);
+                    if (GradLayout<LAYOUT>::value == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
+                }
             });
         }
         if (SAMPLER == DIFFUS_TRILINEAR) {
@@ -1714,6 +1729,48 @@ __global__ void loss_finish_kernel(const float *__restrict__ part, float *__rest
     loss[p] = t;
 }
 
+// Sparse bricked gradient -> canonical: one wave per 64 bricks reads their "touched" flags; every
+// touched brick is added into (or stored to) the canonical tensor, ZEROED in the bricked buffer and
+// its flag cleared, so the bricked buffer and the flags are all-zero again afterwards.  A fan touches
+// a few thousand of the 524 288 bricks of a 256^3 volume: this replaces a 64 MiB memset plus a
+// 128 MiB dense conversion per step.
+__global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict__ bricked, int *__restrict__ touched,
+                                                               float *__restrict__ out, Geom G, long nbricks,
+                                                               int accumulate)
+{
+    __shared__ int s_list[kWavesPerBlock][kWave];
+    const int wib = threadIdx.x >> 6;
+    const long w = (long)blockIdx.x * kWavesPerBlock + wib;
+    const int lane = threadIdx.x & 63;
+    const long b0 = w * kWave;
+    if (b0 >= nbricks) return;
+    const long mine = b0 + lane;
+    int f = (mine < nbricks) ? touched[mine] : 0;
+    unsigned long long m = __ballot(f != 0);
+    if (m == 0) return; // wave-uniform: nothing touched in these 64 bricks
+    if (f) {
+        touched[mine] = 0;
+        s_list[wib][__builtin_popcountll(m & ((1ull << lane) - 1))] = lane; // compact the touched ids
+    }
+    wave_lds_sync();
+    const int cnt = __builtin_popcountll(m);
+    const int o = lane & 31, half = lane >> 5;
+    // two bricks per step (one per half-wave); iterations are independent so their loads overlap
+#pragma unroll 4
+    for (int i = half; i < cnt; i += 2) {
+        const long brick = b0 + s_list[wib][i];
+        float v = bricked[brick * kBrickFloats + o];
+        bricked[brick * kBrickFloats + o] = 0.f;
+        long bz = brick % G.nb2, t = brick / G.nb2;
+        long by = t % G.nb1, bx = t / G.nb1;
+        int x = (int)bx * 4 + (o >> 3), y = (int)by * 4 + ((o >> 1) & 3), z = (int)bz * 2 + (o & 1);
+        if (x < G.d0 && y < G.d1 && z < G.d2) {
+            long a = ((long)x * G.d1 + y) * G.d2 + z;
+            out[a] = accumulate ? out[a] + v : v;
+        }
+    }
+}
+
 // canonical -> PAIRED: a block writes 4 x 4 columns x 32 depths (4 KiB contiguous) from 16 canonical
 // rows of 33 floats, through LDS.
 __global__ __launch_bounds__(kBlock) void pair_convert_kernel(const float *__restrict__ in, float *__restrict__ out, Geom G)
@@ -1943,6 +2000,25 @@ size_t diffus_bricked_floats(int d0, int d1, int d2)
     return bricked_floats(d0, d1, d2);
 }
 
+size_t diffus_brick_count(int d0, int d1, int d2)
+{
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
+    return bricked_floats(d0, d1, d2) / kBrickFloats;
+}
+
+int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, float *vol, int accumulate,
+                         diffus_stream_t stream)
+{
+    if (!bricked || !touched || !vol || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    const long nbricks = (long)(bricked_floats(d0, d1, d2) / kBrickFloats);
+    const long waves = (nbricks + kWave - 1) / kWave;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(gradbuf_flush_kernel, dim3(nblk), dim3(kBlock), 0, (hipStream_t)stream, bricked, touched, vol, G,
+                       nbricks, accumulate);
+    return last_launch();
+}
+
 size_t diffus_paired_floats(int d0, int d1, int d2)
 {
     if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
@@ -2005,8 +2081,8 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, cons
 
 int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
-                      const float *gframe, float *gvol, float *gsrc, float *gdirs, int stages, void *workspace,
-                      size_t workspace_bytes, diffus_stream_t stream)
+                      const float *gframe, float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
+                      void *workspace, size_t workspace_bytes, diffus_stream_t stream)
 {
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
@@ -2026,6 +2102,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
     Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.gframe = gframe;
     A.gvol = gvol;
+    A.gtouched = (gvol && layout != DIFFUS_CANONICAL) ? gvol_touched : nullptr;
     A.zbar = gvol ? ws.zbar : nullptr;
     A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
     A.gdirs = pose ? gdirs : nullptr;

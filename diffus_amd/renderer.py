@@ -40,6 +40,7 @@ log = logging.getLogger("diffus_amd")
 _SAMPLERS = {"nearest": _lib.NEAREST, "prop": _lib.NEAREST, "trilinear": _lib.TRILINEAR}
 _LAYOUTS = ("auto", "canonical", "bricked", "paired")
 _workspaces: dict = {}
+_gradbufs: dict = {}        # (device, shape) -> (bricked scratch, touched flags); all-zero between uses
 _brick_cache: list = []     # [(weakref(source tensor), version, bricked copy)]   (at most 2 entries)
 _brick_seen: list = []      # [(weakref(source tensor), version, calls)]
 _AUTO_BRICK_SAMPLES = 1 << 18
@@ -84,6 +85,21 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
         ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
         _workspaces[dev] = ws
     return ws
+
+
+def _gradbuf(dev: torch.device, shape):
+    """Persistent sparse-gradient scratch of a device/shape: bricked floats + one flag per brick.
+    Invariant: both all-zero whenever no backward is in flight (diffus_gradbuf_flush restores it)."""
+    key = (dev, tuple(shape), torch.cuda.current_stream(dev).cuda_stream)   # one scratch per stream: no cross-stream races
+    gb = _gradbufs.get(key)
+    if gb is None:
+        lib = _lib.load()
+        gb = (torch.zeros(lib.diffus_bricked_floats(*shape), dtype=torch.float32, device=dev),
+              torch.zeros(lib.diffus_brick_count(*shape), dtype=torch.int32, device=dev))
+        if len(_gradbufs) >= 3:
+            _gradbufs.pop(next(iter(_gradbufs)))
+        _gradbufs[key] = gb
+    return gb
 
 
 def _pose_dtype(t: torch.Tensor) -> torch.dtype:
@@ -262,23 +278,28 @@ class _RenderFn(torch.autograd.Function):
         need_v, need_s, need_d = ctx.needs_input_grad[:3]
         with torch.cuda.device(pb.dev):
             g = gframe.detach().to(device=pb.dev, dtype=torch.float32).contiguous()
-            gvol = None
+            gvol = touched = None
+            sparse = False
             if need_v:      # gradient buffer in the layout that goes with the volume's
                 if pb.layout == _lib.CANONICAL:
                     gvol = torch.zeros_like(pb.vol)
-                else:
+                elif pb._layout_req == "prebricked":
                     gvol = torch.zeros(lib.diffus_bricked_floats(*pb.shape), dtype=torch.float32, device=pb.dev)
+                else:       # sparse: persistent all-zero scratch + touched flags, flushed below
+                    gvol, touched = _gradbuf(pb.dev, pb.shape)
+                    sparse = True
             gsrc = torch.empty((pb.P, 3), dtype=torch.float32, device=pb.dev) if need_s else None
             gdirs = torch.empty((pb.P, pb.R, 3), dtype=torch.float32, device=pb.dev) if need_d else None
             ws = pb.workspace()
-            rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(gsrc), _ptr(gdirs), _lib.BWD_ALL,
-                                       _ptr(ws), ws.numel(), _stream(pb.dev))
-        _lib.check(rc, "diffus_render_bwd")
-        out_v = None
-        if need_v:
-            if pb._layout_req != "prebricked" and pb.layout != _lib.CANONICAL:
-                gvol = unbrick_volume(gvol, pb.shape)       # back to the caller's (d0,d1,d2)
-            out_v = gvol.to(device=vdev, dtype=vdt)
+            rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(touched), _ptr(gsrc), _ptr(gdirs),
+                                       _lib.BWD_ALL, _ptr(ws), ws.numel(), _stream(pb.dev))
+            _lib.check(rc, "diffus_render_bwd")
+            if sparse:      # only the bricks the fans touched travel back to the caller's (d0,d1,d2)
+                dense = torch.zeros(pb.shape, dtype=torch.float32, device=pb.dev)
+                rc = lib.diffus_gradbuf_flush(_ptr(gvol), _ptr(touched), *pb.shape, _ptr(dense), 0, _stream(pb.dev))
+                _lib.check(rc, "diffus_gradbuf_flush")
+                gvol = dense
+        out_v = gvol.to(device=vdev, dtype=vdt) if need_v else None
         out_s = gsrc.reshape(sshape).to(device=sdev, dtype=sdt) if need_s else None
         out_d = None
         if need_d:

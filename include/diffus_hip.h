@@ -91,6 +91,17 @@ size_t diffus_workspace_bytes(int P, int R, int S, int start);
  *                          storing (used to fold a bricked gradient into a
  *                          canonical one)
  */
+/*
+ * Sparse gradient hand-back.  diffus_gradbuf_flush visits only the bricks whose flag is set:
+ * adds (accumulate != 0) or stores them into the canonical (d0,d1,d2) tensor `vol`, zeroes them
+ * in `bricked` and clears the flags -- so a buffer pair that starts all-zero is all-zero again
+ * after the flush, and neither a 64 MiB memset nor a dense conversion is needed per step.
+ * With accumulate == 0 only touched voxels are written: zero `vol` first if it must be dense.
+ */
+size_t diffus_brick_count(int d0, int d1, int d2);
+int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, float *vol,
+                         int accumulate, diffus_stream_t stream);
+
 size_t diffus_paired_floats(int d0, int d1, int d2);
 int diffus_pair_volume(const float *vol, int d0, int d1, int d2, float *paired,
                        diffus_stream_t stream);
@@ -132,6 +143,10 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
  *          canonical vol, diffus_bricked_floats() bricked for a bricked or paired vol),
  *          ACCUMULATED with float atomics
  *          (caller zeroes it; shared by all poses)
+ *   gvol_touched  nullable, only with a bricked gvol: diffus_brick_count() ints; the
+ *          entry of every brick this call adds into is set to 1 (plain stores).
+ *          Together with diffus_gradbuf_flush it makes the gradient SPARSE: keep
+ *          gvol and gvol_touched all-zero between steps, flush after each backward.
  *   gsrc   nullable (P,3) float32, overwritten   (trilinear only, else zeros)
  *   gdirs  nullable (P,R,3) float32, overwritten (trilinear only, else zeros)
  * With start > 0 the median written into column 0 (reference :243-244) routes
@@ -151,7 +166,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout,
                       const void *dirs, int dirs_dtype,
                       int P, int R, int S, int start, float alpha, int sampler,
                       const float *gframe,
-                      float *gvol, float *gsrc, float *gdirs,
+                      float *gvol, int *gvol_touched, float *gsrc, float *gdirs,
                       int stages,
                       void *workspace, size_t workspace_bytes,
                       diffus_stream_t stream);

@@ -67,7 +67,7 @@ def test_argument_validation_without_a_gpu(lib):
     assert fwd(vol=None) == -1
     assert fwd(d0=0) == -1
     assert fwd(sampler=7) == -1
-    assert fwd(layout=2) == -1
+    assert fwd(layout=3) == -1
     assert fwd(sdt=3) == -1
     assert fwd(start=4) == -1            # start > S-1
     assert fwd(start=3) == -1            # start > 0 needs two samples (reference IndexError at :243)
@@ -75,9 +75,11 @@ def test_argument_validation_without_a_gpu(lib):
     assert fwd(d0=1 << 25) == -2
     assert fwd(start=1) == -4            # start > 0 needs the workspace
     assert fwd(frame=None) == -1
-    assert lib.diffus_render_bwd(p, 2, 2, 2, 0, p, 0, p, 0, 1, 1, 4, 0, 0.1, 0, p, p, None, None, 3, None, 0, None) == -4
-    assert lib.diffus_render_bwd(p, 2, 2, 2, 0, p, 0, p, 0, 1, 1, 4, 0, 0.1, 0, p, p, None, None, 0, p, 1 << 20, None) == -1
-    assert lib.diffus_render_bwd(p, 2, 2, 2, 0, p, 0, p, 0, 1, 1, 4, 0, 0.1, 0, p, None, None, None, 3, None, 0, None) == 0
+    assert lib.diffus_render_bwd(p, 2, 2, 2, 0, p, 0, p, 0, 1, 1, 4, 0, 0.1, 0, p, p, None, None, None, 3, None, 0, None) == -4
+    assert lib.diffus_render_bwd(p, 2, 2, 2, 0, p, 0, p, 0, 1, 1, 4, 0, 0.1, 0, p, p, None, None, None, 0, p, 1 << 20, None) == -1
+    assert lib.diffus_render_bwd(p, 2, 2, 2, 0, p, 0, p, 0, 1, 1, 4, 0, 0.1, 0, p, None, None, None, None, 3, None, 0, None) == 0
+    assert lib.diffus_brick_count(256, 256, 256) == 256 ** 3 // 32
+    assert lib.diffus_gradbuf_flush(None, p, 2, 2, 2, p, 1, None) == -1
     assert lib.diffus_echo_traces(None, 1, 4, p, None) == -1
     assert lib.diffus_echo_traces(p, 1, 2000, p, None) == -2
     assert lib.diffus_brick_volume(None, 2, 2, 2, p, None) == -1

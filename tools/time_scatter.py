@@ -15,5 +15,6 @@ for _ in range(3):
     hp.step()
 f = time_events(hp.fwd, 30)["median"]
 b = time_events(lambda: hp.bwd(_lib.BWD_SCAN), 30)["median"]
-s = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), 30, pre=hp.zero_grad)["median"]
-print("%-34s fwd %.1f us  bwd-scan %.1f us  scatter %.1f us" % (os.path.basename(sys.argv[1]), f * 1e3, b * 1e3, s * 1e3))
+s = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), 30, pre=hp.finish_grad)["median"]
+u = time_events(hp.finish_grad, 30, pre=lambda: hp.bwd(_lib.BWD_SCATTER))["median"]
+print("%-34s fwd %.1f us  bwd-scan %.1f us  scatter %.1f us  flush %.1f us" % (os.path.basename(sys.argv[1]), f * 1e3, b * 1e3, s * 1e3, u * 1e3))
