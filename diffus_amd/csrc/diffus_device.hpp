@@ -1,0 +1,718 @@
+// diffus_device.hpp -- gfx950 (MI355X / CDNA4) kernels + C ABI for the DiffUS
+// plot_beam_frame hot path.  See include/diffus_hip.h for the boundary and
+// DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Execution model (CDNA4-first, not a port of the reference's ATen call chain):
+//   * one 64-lane wavefront marches one ray; lane l owns C = ceil(N1/64)
+//     CONSECUTIVE samples n = l*C .. l*C+C-1 of the cropped ray (N1 = S-start);
+//   * the reference's N+1 dense solves (src/renderer.py:367-457) collapse to a
+//     running product of 2x2 transfer matrices: each lane
+//     multiplies its C matrices, the wave does a 6-round Hillis-Steele scan of
+//     2x2 products with cross-lane shuffles, each lane then sweeps its chunk from
+//     its exclusive prefix.  No A matrix, no LU, no global scratch;
+//   * backward recomputes the forward in-kernel and runs the adjoint recursion
+//      as a reverse affine scan over the same lanes;
+//   * memory is touched in an INTERLEAVED lane mapping (consecutive lanes =
+//     consecutive steps) and the scan runs in a CHUNKED one; a per-wave LDS
+//     buffer transposes between them;
+//   * the volume (and its gradient) can live in a BRICKED layout: 4x4x2-voxel
+//     bricks = one 128-B line, so a fan sheet uses whole lines instead of 8 B of
+//     each; the gradient scatter is privatised in LDS tiles per patch of rays;
+//   * a pose's rays are kept on one XCD (blockIdx remap) so neighbouring rays,
+//     which touch the same voxels near the apex, share that XCD's L2.
+// This is gather/accumulate work: HBM/L2-bound, no MFMA anywhere.
+// This header holds every __device__ helper shared by the translation units (render_fwd.hip,
+// render_bwd.hip, scatter.hip, splat.hip); everything is in an anonymous namespace, so each unit
+// gets its own copy and nothing here has external linkage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "diffus_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+// ----------------------------------------------------------------------------
+// 2x2 matrices  [[a b],[c d]]
+struct Mat {
+    float a, b, c, d;
+};
+
+__device__ __forceinline__ Mat mat_identity() { return Mat{1.f, 0.f, 0.f, 1.f}; }
+
+__device__ __forceinline__ Mat mat_mul(const Mat &x, const Mat &y)
+{
+    Mat o;
+    o.a = __builtin_fmaf(x.a, y.a, x.b * y.c);
+    o.b = __builtin_fmaf(x.a, y.b, x.b * y.d);
+    o.c = __builtin_fmaf(x.c, y.a, x.d * y.c);
+    o.d = __builtin_fmaf(x.c, y.b, x.d * y.d);
+    return o;
+}
+
+// x * y^T
+__device__ __forceinline__ Mat mat_mul_bt(const Mat &x, const Mat &y)
+{
+    Mat o;
+    o.a = __builtin_fmaf(x.a, y.a, x.b * y.b);
+    o.b = __builtin_fmaf(x.a, y.c, x.b * y.d);
+    o.c = __builtin_fmaf(x.c, y.a, x.d * y.b);
+    o.d = __builtin_fmaf(x.c, y.c, x.d * y.d);
+    return o;
+}
+
+// x^T * y
+__device__ __forceinline__ Mat mat_mul_at(const Mat &x, const Mat &y)
+{
+    Mat o;
+    o.a = __builtin_fmaf(x.a, y.a, x.c * y.c);
+    o.b = __builtin_fmaf(x.a, y.b, x.c * y.d);
+    o.c = __builtin_fmaf(x.b, y.a, x.d * y.c);
+    o.d = __builtin_fmaf(x.b, y.b, x.d * y.d);
+    return o;
+}
+
+// Transfer matrix of one interface, M(r) = [[1-2r^2, r], [-r, 1]] (SURVEY A.3,
+// from the rows written at reference src/renderer.py:397-405 with :380-382).
+__device__ __forceinline__ Mat mat_of_r(float r) { return Mat{1.f - (2.f * r) * r, r, -r, 1.f}; }
+
+// P * M(r) without forming M
+__device__ __forceinline__ Mat mat_step(const Mat &p, float r)
+{
+    float a = 1.f - (2.f * r) * r;
+    Mat o;
+    o.a = __builtin_fmaf(p.a, a, -(p.b * r));
+    o.b = __builtin_fmaf(p.a, r, p.b);
+    o.c = __builtin_fmaf(p.c, a, -(p.d * r));
+    o.d = __builtin_fmaf(p.c, r, p.d);
+    return o;
+}
+
+__device__ __forceinline__ Mat mat_scale(const Mat &m, int e)
+{
+    return Mat{ldexpf(m.a, e), ldexpf(m.b, e), ldexpf(m.c, e), ldexpf(m.d, e)};
+}
+
+// Rescale by an exact power of two so that max|entry| is in [0.5,1).  Returns ex
+// with  m_out = m_in * 2^-ex  (0 when m is all zero / non finite).
+__device__ __forceinline__ int mat_renorm(Mat &m)
+{
+    float mx = fmaxf(fmaxf(fabsf(m.a), fabsf(m.b)), fmaxf(fabsf(m.c), fabsf(m.d)));
+    // v_frexp_exp_i32_f32 returns 0 for +-0, inf and NaN: no branch needed, ldexp(x, 0) is a no-op
+    int ex = __builtin_amdgcn_frexp_expf(mx);
+    m = mat_scale(m, -ex);
+    return ex;
+}
+
+__device__ __forceinline__ bool finitef(float x) { return fabsf(x) < __builtin_inff(); }
+__device__ __forceinline__ bool mat_finite(const Mat &m) { return finitef(m.a) && finitef(m.b) && finitef(m.c) && finitef(m.d); }
+
+// Wave-wide min/max of an int by the classic DPP ladder (row_shr 1,2,3,4,8, row_bcast 15,31):
+// 7 VALU+DPP steps instead of 6 ds_bpermute round trips.  Result valid in every lane (readlane 63).
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_reduce_minmax(int v)
+{
+#define DIFFUS_DPP_STEP(ctrl, rmask, bmask)                                                   \
+    {                                                                                         \
+        int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, bmask, false);                 \
+        v = IS_MIN ? min(v, o) : max(v, o);                                                   \
+    }
+    DIFFUS_DPP_STEP(0x111, 0xf, 0xf) // row_shr:1
+    DIFFUS_DPP_STEP(0x112, 0xf, 0xf) // row_shr:2
+    DIFFUS_DPP_STEP(0x113, 0xf, 0xf) // row_shr:3
+    DIFFUS_DPP_STEP(0x114, 0xf, 0xe) // row_shr:4
+    DIFFUS_DPP_STEP(0x118, 0xf, 0xc) // row_shr:8
+    DIFFUS_DPP_STEP(0x142, 0xa, 0xf) // row_bcast:15
+    DIFFUS_DPP_STEP(0x143, 0xc, 0xf) // row_bcast:31
+#undef DIFFUS_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ Mat mat_shfl_up(const Mat &m, int off)
+{
+    return Mat{__shfl_up(m.a, off, kWave), __shfl_up(m.b, off, kWave), __shfl_up(m.c, off, kWave),
+               __shfl_up(m.d, off, kWave)};
+}
+__device__ __forceinline__ Mat mat_shfl_down(const Mat &m, int off)
+{
+    return Mat{__shfl_down(m.a, off, kWave), __shfl_down(m.b, off, kWave), __shfl_down(m.c, off, kWave),
+               __shfl_down(m.d, off, kWave)};
+}
+
+// ----------------------------------------------------------------------------
+struct Pose {
+    // source and direction of this wave's ray, kept in both precisions; pmode
+    // says which roundings the reference would perform (diffus_oracle.c orc_point)
+    float sf[3], df[3];
+    double sd[3], dd[3];
+    int pmode; // 0: f32 src, f32 dir; 1: f64 src, f32 dir; 2: f64 dir (src any)
+};
+
+// PM = 0: both inputs are f32 (the common case) -- compile-time: no f64 code, no mode branches.
+// PM = 1: dtypes resolved at run time.
+template <int PM = 1>
+__device__ __forceinline__ void load_pose(Pose &ps, const void *src, int src_f64, const void *dirs, int dir_f64,
+                                          long pose, long ray_lin)
+{
+    if (PM == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ps.sf[c] = ((const float *)src)[pose * 3 + c];
+            ps.df[c] = ((const float *)dirs)[ray_lin * 3 + c];
+        }
+        ps.pmode = 0;
+        return;
+    }
+    for (int c = 0; c < 3; ++c) {
+        if (src_f64) {
+            ps.sd[c] = ((const double *)src)[pose * 3 + c];
+            ps.sf[c] = (float)ps.sd[c];
+        } else {
+            ps.sf[c] = ((const float *)src)[pose * 3 + c];
+            ps.sd[c] = (double)ps.sf[c];
+        }
+        if (dir_f64) {
+            ps.dd[c] = ((const double *)dirs)[ray_lin * 3 + c];
+            ps.df[c] = (float)ps.dd[c];
+        } else {
+            ps.df[c] = ((const float *)dirs)[ray_lin * 3 + c];
+            ps.dd[c] = (double)ps.df[c];
+        }
+    }
+    ps.pmode = dir_f64 ? 2 : (src_f64 ? 1 : 0);
+}
+
+// p_c = source_c + float(k) * dir_c with the reference's rounding sequence
+// (src/renderer.py:119-124, cast to f32 at :751).  No FMA contraction.
+template <int PM = 1>
+__device__ __forceinline__ float ray_point(const Pose &ps, int c, int k)
+{
+    float stepf = (float)k;
+    if (PM == 0 || ps.pmode == 0) {
+        return __fadd_rn(ps.sf[c], __fmul_rn(stepf, ps.df[c]));
+    } else if (ps.pmode == 1) {
+        float t = __fmul_rn(stepf, ps.df[c]);
+        return (float)__dadd_rn(ps.sd[c], (double)t);
+    } else {
+        return (float)__dadd_rn(ps.sd[c], __dmul_rn((double)stepf, ps.dd[c]));
+    }
+}
+
+// round-half-even -> clamp (src/renderer.py:754-756); NaN / beyond-int64 -> 0
+// like x86's float->int64 conversion followed by the clamp.
+__device__ __forceinline__ int nearest_index(float p, int dim)
+{
+    float r = rintf(p);
+    if (!(r > -9.2233720368547758e18f && r < 9.2233720368547758e18f)) return 0;
+    float hi = (float)(dim - 1);
+    r = fminf(fmaxf(r, 0.f), hi);
+    return (int)r;
+}
+
+// ----------------------------------------------------------------------------
+// Volume layouts.
+//   CANONICAL: the caller's (d0,d1,d2) row-major tensor, dim 2 contiguous.
+//   BRICKED:   4x4x2-voxel bricks of 32 floats = one 128-B cache line, bricks in
+//              row-major order over (ceil(d0/4), ceil(d1/4), ceil(d2/2)).  Every
+//              demo fan lies in a plane of constant dim-2 (reference src/cone.py:258):
+//              in the canonical layout each sample then uses 8 bytes of every
+//              128-B line it touches; in a brick the same sheet uses the whole line,
+//              and neighbouring steps/rays land in the same line.
+constexpr int kBrickFloats = 32;
+
+//   PAIRED:    (volume only) 4x4 columns x ONE depth z, each voxel stored as the float2
+//              (v[z], v[min(z+1, d2-1)]): every trilinear column is one aligned 8-byte load whatever
+//              the parity of z, and a fan sheet uses all 128 bytes of each line it touches.  Twice
+//              the memory of the volume; the gradient of a PAIRED volume is BRICKED.
+} // namespace
+namespace diffus { // types that cross translation units need linkage
+struct Geom {
+    int d0, d1, d2;
+    int nb1, nb2; // bricks along dim 1 / dim 2
+};
+} // namespace diffus
+using diffus::Geom;
+namespace {
+
+// layout of the gradient buffer that goes with a volume layout
+template <int LAYOUT>
+struct GradLayout {
+    static constexpr int value = (LAYOUT == DIFFUS_PAIRED) ? DIFFUS_BRICKED : LAYOUT;
+};
+
+// 32-bit element offsets (the host refuses volumes of 2^30 floats or more): 64-bit address
+// arithmetic was 28 % of the forward kernel's instructions.
+template <int LAYOUT>
+__device__ __forceinline__ unsigned vox_off(const Geom &G, int x, int y, int z)
+{
+    if (LAYOUT == DIFFUS_CANONICAL) {
+        return ((unsigned)x * (unsigned)G.d1 + (unsigned)y) * (unsigned)G.d2 + (unsigned)z;
+    } else if (LAYOUT == DIFFUS_PAIRED) { // index of the .x half of the pair at (x,y,z)
+        unsigned col = ((unsigned)(x >> 2) * (unsigned)G.nb1 + (unsigned)(y >> 2)) * (unsigned)G.d2 + (unsigned)z;
+        return col * kBrickFloats + (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
+    } else {
+        unsigned brick = ((unsigned)(x >> 2) * (unsigned)G.nb1 + (unsigned)(y >> 2)) * (unsigned)G.nb2 + (unsigned)(z >> 1);
+        return brick * kBrickFloats + (unsigned)(((x & 3) << 3) | ((y & 3) << 1) | (z & 1));
+    }
+}
+
+struct Axis {
+    int i0, i1;
+    float t, m;
+};
+__device__ __forceinline__ Axis tri_axis(float p, int dim)
+{
+    Axis a;
+    float hi = (float)(dim - 1);
+    a.m = (p > 0.f && p < hi) ? 1.f : 0.f;
+    float pc = p;
+    if (!(pc > 0.f)) pc = 0.f; // also catches NaN
+    if (pc > hi) pc = hi;
+    float f = floorf(pc);
+    a.i0 = (int)f;
+    a.t = pc - f;
+    a.i1 = min(a.i0 + 1, dim - 1);
+    return a;
+}
+
+struct __attribute__((packed, aligned(4))) F2 {
+    float x, y;
+};
+
+// The two dim-2 neighbours of one (x,y) column.  Where they are adjacent in
+// memory they come in ONE 8-byte load: half the vector-memory instructions and
+// L1 tag lookups of the 8-corner gather.
+template <int LAYOUT>
+__device__ __forceinline__ void load_zpair(const float *__restrict__ vol, const Geom &G, int x, int y, const Axis &c,
+                                           float &lo, float &hi)
+{
+    if (LAYOUT == DIFFUS_PAIRED) {
+        float2 v = *reinterpret_cast<const float2 *>(vol + vox_off<LAYOUT>(G, x, y, c.i0));
+        lo = v.x;
+        hi = v.y; // = v[min(z0+1, d2-1)] by construction
+    } else if (LAYOUT == DIFFUS_CANONICAL) {
+        const unsigned row = ((unsigned)x * (unsigned)G.d1 + (unsigned)y) * (unsigned)G.d2;
+        if (G.d2 >= 2) {
+            int b = min(c.i0, G.d2 - 2);
+            F2 v = *reinterpret_cast<const F2 *>(vol + (row + (unsigned)b));
+            lo = (c.i0 == b) ? v.x : v.y;
+            hi = v.y;
+        } else {
+            lo = hi = vol[row];
+        }
+    } else {
+        // the aligned pair (z&~1, z|1) of the brick holding z0 in ONE 8-byte load; when z0 is odd
+        // its upper neighbour lives in the next brick: one more 4-byte load for those lanes only
+        float2 v = *reinterpret_cast<const float2 *>(vol + vox_off<LAYOUT>(G, x, y, c.i0 & ~1));
+        if (!(c.i0 & 1)) {
+            lo = v.x;
+            hi = (c.i1 != c.i0) ? v.y : v.x;
+        } else {
+            lo = v.y;
+            hi = (c.i1 != c.i0) ? vol[vox_off<LAYOUT>(G, x, y, c.i1)] : v.y;
+        }
+    }
+}
+
+struct TriSample {
+    float v;          // interpolated impedance
+    float g0, g1, g2; // d v / d p (border rule applied)
+};
+
+// Trilinear sample at p; lerp order dim 2, dim 1, dim 0, each a + t*(b-a) --
+// the exact sequence of oracle/diffus_oracle.c orc_sample_trilinear.
+template <int LAYOUT, bool GRAD>
+__device__ __forceinline__ TriSample tri_sample(const float *__restrict__ vol, const Geom &G, float p0, float p1,
+                                                float p2)
+{
+    Axis a = tri_axis(p0, G.d0), b = tri_axis(p1, G.d1), c = tri_axis(p2, G.d2);
+    float v000, v001, v010, v011, v100, v101, v110, v111;
+    load_zpair<LAYOUT>(vol, G, a.i0, b.i0, c, v000, v001);
+    load_zpair<LAYOUT>(vol, G, a.i0, b.i1, c, v010, v011);
+    load_zpair<LAYOUT>(vol, G, a.i1, b.i0, c, v100, v101);
+    load_zpair<LAYOUT>(vol, G, a.i1, b.i1, c, v110, v111);
+    float e00 = v001 - v000, e01 = v011 - v010, e10 = v101 - v100, e11 = v111 - v110;
+    float c00 = __fadd_rn(v000, __fmul_rn(c.t, e00)), c01 = __fadd_rn(v010, __fmul_rn(c.t, e01));
+    float c10 = __fadd_rn(v100, __fmul_rn(c.t, e10)), c11 = __fadd_rn(v110, __fmul_rn(c.t, e11));
+    float f0 = c01 - c00, f1 = c11 - c10;
+    float q0 = __fadd_rn(c00, __fmul_rn(b.t, f0)), q1 = __fadd_rn(c10, __fmul_rn(b.t, f1));
+    float g = q1 - q0;
+    TriSample s;
+    s.v = __fadd_rn(q0, __fmul_rn(a.t, g));
+    if (GRAD) {
+        float h0 = __fadd_rn(e00, __fmul_rn(b.t, e01 - e00));
+        float h1 = __fadd_rn(e10, __fmul_rn(b.t, e11 - e10));
+        s.g0 = g * a.m;
+        s.g1 = __fadd_rn(f0, __fmul_rn(a.t, f1 - f0)) * b.m;
+        s.g2 = __fadd_rn(h0, __fmul_rn(a.t, h1 - h0)) * c.m;
+    } else {
+        s.g0 = s.g1 = s.g2 = 0.f;
+    }
+    return s;
+}
+
+// reflection coefficient (reference src/renderer.py:33): IEEE f32 sub, add, div -- used by the
+// stage-wise kernels, whose outputs are compared bit for bit with the oracle
+__device__ __forceinline__ float reflect(float z1, float z2) { return __fdiv_rn(z2 - z1, z1 + z2); }
+
+// Hot-kernel arithmetic.  The fused kernels are VALU-bound (PMC: VALU busy 57 %, ~4 cycles per
+// instruction), and an IEEE f32 division is ~12 instructions, ocml expf ~20.  v_rcp_f32 / v_exp_f32
+// are accurate to ~1 ulp, far inside the 1e-5 frame tolerance; 0/0 stays NaN, x/0 stays +-inf.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float reflect_fast(float z1, float z2) { return fast_div(z2 - z1, z1 + z2); }
+
+// ----------------------------------------------------------------------------
+} // namespace
+namespace diffus {
+struct Args {
+    const float *vol;
+    Geom G;
+    const void *src;
+    const void *dirs;
+    int src_f64, dir_f64;
+    int P, R, S, start, N1;
+    float neg_alpha;
+    // forward
+    float *frame;
+    long long *idx;
+    // backward
+    const float *gframe;
+    float *gvol;      // layout that goes with vol's (GradLayout)
+    int *gtouched;    // nullable: one flag per gradient brick, set when a launch adds into it (bricked only)
+    float *zbar;      // (P,R,N1) d L / d imp per sample, consumed by scatter_patch_kernel
+    float *gsrc_part; // (P,R,3) per-ray partials of d/d source
+    float *gdirs;
+    // start>0 coupling
+    float *med;  // (P) median of r[:,start] over rays
+    int *who;    // (P) ray that supplied it
+    float *gmed; // (P) accumulated d/d median
+};
+} // namespace diffus
+using diffus::Args;
+namespace {
+
+// Blocks are dealt round-robin over the 8 XCDs (block b -> XCD b%8).  Remap so
+// that consecutive LOGICAL blocks (= consecutive rays of one pose) sit on one
+// XCD and share its L2.  Bijective for any grid size (guide T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
+{
+    unsigned xcd = b & 7u, q = nblk >> 3, rem = nblk & 7u;
+    unsigned base = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    return base + (b >> 3);
+}
+
+// ----------------------------------------------------------------------------
+// Two lane <-> sample mappings of one ray's N1 samples over a wave:
+//   INTERLEAVED  sample n = j*64 + lane   -- consecutive lanes = consecutive steps:
+//                used for everything that touches memory (gathers land in the
+//                same bricks / lines, frame & gradient rows are read and written
+//                as 256-B runs);
+//   CHUNKED      sample n = lane*C + j    -- a lane owns C consecutive samples:
+//                used for the scan (15 serial 2x2 products + 6 shuffle rounds
+//                instead of 8 x 6 shuffle rounds).
+// A per-wave LDS buffer of 64*C floats converts between the two.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int C>
+__device__ __forceinline__ void to_chunked(float *wb, int lane, const float (&in)[C], float (&out)[C])
+{
+#pragma unroll
+    for (int j = 0; j < C; ++j) wb[j * kWave + lane] = in[j];
+    wave_lds_sync();
+    if (C >= 4) {
+        const float4 *q = reinterpret_cast<const float4 *>(wb + lane * C);
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) {
+            float4 v = q[j];
+            out[4 * j] = v.x; out[4 * j + 1] = v.y; out[4 * j + 2] = v.z; out[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) out[j] = wb[lane * C + j];
+    }
+    wave_lds_sync();
+}
+
+template <int C>
+__device__ __forceinline__ void to_interleaved(float *wb, int lane, const float (&in)[C], float (&out)[C])
+{
+    if (C >= 4) {
+        float4 *q = reinterpret_cast<float4 *>(wb + lane * C);
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) q[j] = make_float4(in[4 * j], in[4 * j + 1], in[4 * j + 2], in[4 * j + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) wb[lane * C + j] = in[j];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < C; ++j) out[j] = wb[j * kWave + lane];
+    wave_lds_sync();
+}
+
+// Column / depth parts of a voxel offset: off(x,y,z) = col_off(x,y) + z_off(z).
+template <int LAYOUT>
+__device__ __forceinline__ unsigned col_off(const Geom &G, int x, int y)
+{
+    // v_mul_u32_u24 is full rate, v_mul_lo_u32 quarter rate; every factor here is < 2^24 except the
+    // final row stride, which is applied as a shift (bricked) or one 32-bit multiply (canonical)
+    if (LAYOUT == DIFFUS_CANONICAL)
+        return (__umul24((unsigned)x, (unsigned)G.d1) + (unsigned)y) * (unsigned)G.d2;
+    if (LAYOUT == DIFFUS_PAIRED)
+        return ((__umul24((unsigned)(x >> 2), (unsigned)G.nb1) + (unsigned)(y >> 2)) * (unsigned)G.d2 << 5) +
+               (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
+    return ((__umul24((unsigned)(x >> 2), (unsigned)G.nb1) + (unsigned)(y >> 2)) * (unsigned)G.nb2 << 5) +
+           (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
+}
+template <int LAYOUT>
+__device__ __forceinline__ unsigned z_off(int z)
+{
+    if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)z;
+    if (LAYOUT == DIFFUS_PAIRED) return (unsigned)z << 5;
+    return (unsigned)(z >> 1) * kBrickFloats + (unsigned)(z & 1);
+}
+
+// lerps of one trilinear sample from its 8 corner values (order 000,001,010,011,100,101,110,111 =
+// dim0,dim1,dim2 bits); same operation sequence as oracle/diffus_oracle.c orc_sample_trilinear
+template <bool GRAD>
+__device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a, const Axis &b, const Axis &c)
+{
+    float e00 = v[1] - v[0], e01 = v[3] - v[2], e10 = v[5] - v[4], e11 = v[7] - v[6];
+    float c00 = __fadd_rn(v[0], __fmul_rn(c.t, e00)), c01 = __fadd_rn(v[2], __fmul_rn(c.t, e01));
+    float c10 = __fadd_rn(v[4], __fmul_rn(c.t, e10)), c11 = __fadd_rn(v[6], __fmul_rn(c.t, e11));
+    float f0 = c01 - c00, f1 = c11 - c10;
+    float q0 = __fadd_rn(c00, __fmul_rn(b.t, f0)), q1 = __fadd_rn(c10, __fmul_rn(b.t, f1));
+    float g = q1 - q0;
+    TriSample s;
+    s.v = __fadd_rn(q0, __fmul_rn(a.t, g));
+    if (GRAD) {
+        float h0 = __fadd_rn(e00, __fmul_rn(b.t, e01 - e00));
+        float h1 = __fadd_rn(e10, __fmul_rn(b.t, e11 - e10));
+        s.g0 = g * a.m;
+        s.g1 = __fadd_rn(f0, __fmul_rn(a.t, f1 - f0)) * b.m;
+        s.g2 = __fadd_rn(h0, __fmul_rn(a.t, h1 - h0)) * c.m;
+    } else {
+        s.g0 = s.g1 = s.g2 = 0.f;
+    }
+    return s;
+}
+
+#ifndef DIFFUS_GATHER_GROUP
+#define DIFFUS_GATHER_GROUP 8
+#endif
+// Impedance (and for the trilinear backward its spatial gradient) at the wave's samples,
+// INTERLEAVED mapping.  Written for memory-level parallelism: phase A computes the addresses of
+// up to 8 samples x 8 corners and issues every load with NO branch in between (lanes past the
+// end of the ray re-read the last sample instead of being masked), phase B recomputes the cheap
+// interpolation weights and consumes the values.  The first version (load -> use per corner,
+// behind exec-mask branches) made hipcc emit `s_waitcnt vmcnt(0)` after almost every load:
+// ~50 dependent memory round trips per wave, 43 % of wave time in SQ_WAIT_ANY.
+template <int C, int SAMPLER, int LAYOUT, bool GRAD, int PM>
+__device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps, int lane, float (&z)[C],
+                                                   float (&g0)[C], float (&g1)[C], float (&g2)[C])
+{
+    constexpr int G = (C < DIFFUS_GATHER_GROUP) ? C : DIFFUS_GATHER_GROUP;
+    constexpr int NV = (SAMPLER == DIFFUS_NEAREST) ? 1 : 8;
+    const float *__restrict__ vol = A.vol;
+#pragma unroll
+    for (int gb = 0; gb < C; gb += G) {
+        float raw[G][NV];
+        float ta[G], tb[G], tc[G]; // interpolation weights, kept for phase B
+        unsigned mk[G];            // border-rule bits of the three axes (gradient only)
+        // ---- phase A: addresses + loads
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            int n = min((gb + jj) * kWave + lane, A.N1 - 1);
+            int k = A.start + n;
+            float p0 = ray_point<PM>(ps, 0, k), p1 = ray_point<PM>(ps, 1, k), p2 = ray_point<PM>(ps, 2, k);
+            if constexpr (SAMPLER == DIFFUS_NEAREST) {
+                int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+                raw[jj][0] = vol[col_off<LAYOUT>(A.G, i0, i1) + z_off<LAYOUT>(i2)];
+            } else {
+                Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1), c = tri_axis(p2, A.G.d2);
+                unsigned c00 = col_off<LAYOUT>(A.G, a.i0, b.i0), c01 = col_off<LAYOUT>(A.G, a.i0, b.i1);
+                unsigned c10 = col_off<LAYOUT>(A.G, a.i1, b.i0), c11 = col_off<LAYOUT>(A.G, a.i1, b.i1);
+                unsigned z0 = z_off<LAYOUT>(c.i0), z1 = z_off<LAYOUT>(c.i1);
+                if constexpr (LAYOUT == DIFFUS_PAIRED) { // 4 aligned 8-byte loads: (z0, z0+1) of each column
+                    float2 q00 = *reinterpret_cast<const float2 *>(vol + (c00 + z0));
+                    float2 q01 = *reinterpret_cast<const float2 *>(vol + (c01 + z0));
+                    float2 q10 = *reinterpret_cast<const float2 *>(vol + (c10 + z0));
+                    float2 q11 = *reinterpret_cast<const float2 *>(vol + (c11 + z0));
+                    raw[jj][0] = q00.x; raw[jj][1] = q00.y; raw[jj][2] = q01.x; raw[jj][3] = q01.y;
+                    raw[jj][4] = q10.x; raw[jj][5] = q10.y; raw[jj][6] = q11.x; raw[jj][7] = q11.y;
+                    (void)z1;
+                } else {
+#ifdef DIFFUS_ABLATE_LOADS
+                raw[jj][0] = __uint_as_float(c00 + z0); raw[jj][1] = __uint_as_float(c00 + z1);
+                raw[jj][2] = __uint_as_float(c01 + z0); raw[jj][3] = __uint_as_float(c01 + z1);
+                raw[jj][4] = __uint_as_float(c10 + z0); raw[jj][5] = __uint_as_float(c10 + z1);
+                raw[jj][6] = __uint_as_float(c11 + z0); raw[jj][7] = __uint_as_float(c11 + z1);
+#else
+                raw[jj][0] = vol[c00 + z0]; raw[jj][1] = vol[c00 + z1];
+                raw[jj][2] = vol[c01 + z0]; raw[jj][3] = vol[c01 + z1];
+                raw[jj][4] = vol[c10 + z0]; raw[jj][5] = vol[c10 + z1];
+                raw[jj][6] = vol[c11 + z0]; raw[jj][7] = vol[c11 + z1];
+#endif
+                }
+                ta[jj] = a.t; tb[jj] = b.t; tc[jj] = c.t;
+                if (GRAD) mk[jj] = (a.m != 0.f ? 1u : 0u) | (b.m != 0.f ? 2u : 0u) | (c.m != 0.f ? 4u : 0u);
+            }
+        }
+        // ---- phase B: interpolation
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const int j = gb + jj;
+            const bool live = j * kWave + lane < A.N1;
+            if constexpr (SAMPLER == DIFFUS_NEAREST) {
+                z[j] = live ? raw[jj][0] : 1.f;
+                if (GRAD) g0[j] = g1[j] = g2[j] = 0.f;
+            } else {
+                Axis a, b, c;
+                a.t = ta[jj]; b.t = tb[jj]; c.t = tc[jj];
+                if (GRAD) {
+                    a.m = (mk[jj] & 1u) ? 1.f : 0.f;
+                    b.m = (mk[jj] & 2u) ? 1.f : 0.f;
+                    c.m = (mk[jj] & 4u) ? 1.f : 0.f;
+                }
+#ifdef DIFFUS_ABLATE_LERP
+                TriSample sm;
+                sm.v = raw[jj][0] + raw[jj][1] + raw[jj][2] + raw[jj][3] + raw[jj][4] + raw[jj][5] + raw[jj][6] + raw[jj][7] + a.t + b.t + c.t;
+                sm.g0 = sm.g1 = sm.g2 = 0.f;
+#else
+                TriSample sm = tri_lerp<GRAD>(raw[jj], a, b, c);
+#endif
+                z[j] = live ? sm.v : 1.f;
+                if (GRAD) {
+                    g0[j] = live ? sm.g0 : 0.f;
+                    g1[j] = live ? sm.g1 : 0.f;
+                    g2[j] = live ? sm.g2 : 0.f;
+                }
+            }
+        }
+    }
+}
+
+// r'_{n-1} for the lane's samples (CHUNKED): r[j] couples sample n-1 and n
+// (n = lane*C+j).  r = 0 (identity transfer matrix) for n = 0 and n >= N1; with
+// start > 0 the first kept coefficient is replaced by the per-pose median
+// (reference :243-244).
+template <int C>
+__device__ __forceinline__ void reflect_chunk(const Args &A, int n0, const float (&z)[C], float zprev, float medv,
+                                              float (&r)[C])
+{
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
+        float v = reflect_fast(zp, z[j]);
+        if (n == 1 && A.start > 0) v = medv;
+        r[j] = (n >= 1 && n < A.N1) ? v : 0.f;
+    }
+}
+
+// Echo series of one ray spread over a wave (replaces the N+1
+// dense solves of reference src/renderer.py:367-457).  r[j] is the reflection
+// coefficient entering sample n = lane*C + j (0 where there is none); e[j] gets
+// echo_n = (P_n)01/(P_n)11 with NaN -> 0 (reference :408).
+template <int C, bool FAST = false>
+__device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float (&e)[C])
+{
+    // local product of the chunk, then inclusive scan over lanes (lower lanes on the left)
+    Mat L = mat_identity();
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        L = mat_step(L, r[j]);
+        mat_renorm(L);
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Mat o = mat_shfl_up(L, off);
+        if (lane >= off) {
+            L = mat_mul(o, L);
+            mat_renorm(L);
+        }
+    }
+    Mat Pm = mat_shfl_up(L, 1);
+    if (lane == 0) Pm = mat_identity();
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        Pm = mat_step(Pm, r[j]);
+        mat_renorm(Pm);
+        float v = FAST ? fast_div(Pm.b, Pm.d) : __fdiv_rn(Pm.b, Pm.d);
+        e[j] = (v == v) ? v : 0.f; // nan_to_num(nan=0)
+    }
+}
+
+// ---- patches of the (ray, step) grid: shared by the gradient scatter and the splat winner kernel ----
+#ifndef DIFFUS_PATCH_RAYS
+#define DIFFUS_PATCH_RAYS 16
+#endif
+#ifndef DIFFUS_PATCH_STEPS
+#define DIFFUS_PATCH_STEPS 64
+#endif
+#ifndef DIFFUS_TILE_CAP
+#define DIFFUS_TILE_CAP (12 * 1024)
+#endif
+constexpr int kPatchRays = DIFFUS_PATCH_RAYS;
+constexpr int kPatchSteps = DIFFUS_PATCH_STEPS;
+constexpr int kTileCap = DIFFUS_TILE_CAP; // floats (48 KiB: 3 blocks per CU)
+constexpr int kSamplesPerThread = kPatchRays * kPatchSteps / kBlock; // 4
+
+struct Cell {
+    int i0[3], i1[3];
+    float t[3];
+};
+
+template <int SAMPLER, int PM = 1>
+__device__ __forceinline__ Cell cell_of(const Args &A, const Pose &ps, int k)
+{
+    Cell c;
+    const int dims[3] = {A.G.d0, A.G.d1, A.G.d2};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float p = ray_point<PM>(ps, a, k);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            c.i0[a] = c.i1[a] = nearest_index(p, dims[a]);
+            c.t[a] = 0.f;
+        } else {
+            Axis ax = tri_axis(p, dims[a]);
+            c.i0[a] = ax.i0;
+            c.i1[a] = ax.i1;
+            c.t[a] = ax.t;
+        }
+    }
+    return c;
+}
+
+template <int SAMPLER, typename F>
+__device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
+{
+    if (SAMPLER == DIFFUS_NEAREST) {
+        f(c.i0[0], c.i0[1], c.i0[2], zb);
+    } else {
+        float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1, wc1 = c.t[2], wc0 = 1.f - wc1;
+        float w00 = zb * wa0 * wb0, w01 = zb * wa0 * wb1, w10 = zb * wa1 * wb0, w11 = zb * wa1 * wb1;
+        f(c.i0[0], c.i0[1], c.i0[2], w00 * wc0);
+        f(c.i0[0], c.i0[1], c.i1[2], w00 * wc1);
+        f(c.i0[0], c.i1[1], c.i0[2], w01 * wc0);
+        f(c.i0[0], c.i1[1], c.i1[2], w01 * wc1);
+        f(c.i1[0], c.i0[1], c.i0[2], w10 * wc0);
+        f(c.i1[0], c.i0[1], c.i1[2], w10 * wc1);
+        f(c.i1[0], c.i1[1], c.i0[2], w11 * wc0);
+        f(c.i1[0], c.i1[1], c.i1[2], w11 * wc1);
+    }
+}
+
+} // namespace

@@ -1,0 +1,188 @@
+// diffus_host.hpp -- host-side helpers shared by the translation units: workspace carving, argument
+// validation, (sampler, layout) -> template dispatch, and the per-pose median kernel that both the
+// forward and the backward launch when start > 0.
+#pragma once
+#include "diffus_device.hpp"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// host side
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Geom make_geom(int d0, int d1, int d2)
+{
+    Geom G;
+    G.d0 = d0; G.d1 = d1; G.d2 = d2;
+    G.nb1 = (d1 + 3) / 4;
+    G.nb2 = (d2 + 1) / 2;
+    return G;
+}
+
+size_t bricked_floats(int d0, int d1, int d2)
+{
+    Geom G = make_geom(d0, d1, d2);
+    return (size_t)((d0 + 3) / 4) * G.nb1 * G.nb2 * kBrickFloats;
+}
+
+size_t paired_floats(int d0, int d1, int d2)
+{
+    Geom G = make_geom(d0, d1, d2);
+    return (size_t)((d0 + 3) / 4) * G.nb1 * d2 * kBrickFloats;
+}
+
+struct Workspace {
+    float *med;
+    int *who;
+    float *gmed;
+    float *gsrc_part;
+    float *zbar;
+    size_t bytes;
+};
+
+Workspace carve(void *base, int P, int R, int N1)
+{
+    Workspace ws;
+    char *p = (char *)base;
+    size_t o = 0;
+    ws.med = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
+    ws.who = (int *)(p + o);   o += align256(sizeof(int) * (size_t)P);
+    ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
+    ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
+    ws.zbar = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * (N1 > 0 ? N1 : 0));
+    ws.bytes = o;
+    return ws;
+}
+
+int chunk_for(int N1)
+{
+    int c = (N1 + kWave - 1) / kWave;
+    if (c <= 2) return 2;
+    if (c <= 4) return 4;
+    if (c <= 8) return 8;
+    return 16;
+}
+
+int check_common(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+                 int dirs_dtype, int P, int R, int S, int start, int sampler, int layout, bool need_scan)
+{
+    if (!vol || !src || !dirs) return DIFFUS_EINVAL;
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0 || P <= 0 || R <= 0 || S <= 0) return DIFFUS_EINVAL;
+    if ((src_dtype != DIFFUS_F32 && src_dtype != DIFFUS_F64) || (dirs_dtype != DIFFUS_F32 && dirs_dtype != DIFFUS_F64))
+        return DIFFUS_EINVAL;
+    if (sampler != DIFFUS_NEAREST && sampler != DIFFUS_TRILINEAR) return DIFFUS_EINVAL;
+    if (layout != DIFFUS_CANONICAL && layout != DIFFUS_BRICKED && layout != DIFFUS_PAIRED) return DIFFUS_EINVAL;
+    if (start < 0 || start > S - 1) return DIFFUS_EINVAL;
+    if (start > 0 && start > S - 2) return DIFFUS_EINVAL; // reference raises IndexError at :243
+    if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24)) return DIFFUS_EUNSUPPORTED; // float(dim-1) must be exact
+    if (bricked_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;    // 32-bit element offsets
+    if (layout == DIFFUS_PAIRED && paired_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;
+    if (need_scan && S - start > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
+    if (start > 0 && (size_t)R * sizeof(float) > 64 * 1024) return DIFFUS_EUNSUPPORTED; // median LDS
+    return DIFFUS_OK;
+}
+
+Args make_args(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+               int dirs_dtype, int P, int R, int S, int start, float alpha, const Workspace &ws)
+{
+    Args A{};
+    A.vol = vol;
+    A.G = make_geom(d0, d1, d2);
+    A.src = src; A.dirs = dirs;
+    A.src_f64 = src_dtype == DIFFUS_F64; A.dir_f64 = dirs_dtype == DIFFUS_F64;
+    A.P = P; A.R = R; A.S = S; A.start = start; A.N1 = S - start;
+    A.neg_alpha = -alpha;
+    A.med = ws.med; A.who = ws.who; A.gmed = ws.gmed;
+    return A;
+}
+
+int last_launch() { return hipGetLastError() == hipSuccess ? DIFFUS_OK : DIFFUS_ELAUNCH; }
+
+// (sampler, layout) -> compile-time constants
+template <int SM, typename F>
+int dispatch_layout(int layout, F &&f)
+{
+    using S_ = std::integral_constant<int, SM>;
+    switch (layout) {
+    case DIFFUS_CANONICAL: return f(S_{}, std::integral_constant<int, DIFFUS_CANONICAL>{});
+    case DIFFUS_BRICKED: return f(S_{}, std::integral_constant<int, DIFFUS_BRICKED>{});
+    default: return f(S_{}, std::integral_constant<int, DIFFUS_PAIRED>{});
+    }
+}
+
+template <typename F>
+int dispatch_sl(int sampler, int layout, F &&f)
+{
+    return sampler == DIFFUS_NEAREST ? dispatch_layout<DIFFUS_NEAREST>(layout, f)
+                                     : dispatch_layout<DIFFUS_TRILINEAR>(layout, f);
+}
+
+// ----------------------------------------------------------------------------
+// start > 0: median over rays of r[:, start] (reference :243), one block per pose.
+// Lower median like torch.median; NaN if any NaN.  Also zeroes gmed[p].
+template <int SAMPLER, int LAYOUT>
+__global__ __launch_bounds__(kBlock) void median_kernel(Args A)
+{
+    extern __shared__ float vals[];
+    __shared__ int s_nan;
+    const int pose = blockIdx.x;
+    if (threadIdx.x == 0) s_nan = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
+        Pose ps;
+        load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, (long)pose * A.R + i);
+        float zz[2];
+        for (int q = 0; q < 2; ++q) {
+            int k = A.start + q;
+            float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+            if (SAMPLER == DIFFUS_NEAREST) {
+                int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+                zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
+            } else {
+                zz[q] = tri_sample<LAYOUT, false>(A.vol, A.G, p0, p1, p2).v;
+            }
+        }
+        float v = reflect(zz[0], zz[1]);
+        vals[i] = v;
+        if (v != v) atomicOr(&s_nan, 1);
+    }
+    __syncthreads();
+    if (s_nan) {
+        if (threadIdx.x == 0) {
+            A.med[pose] = __builtin_nanf("");
+            A.who[pose] = -1;
+            A.gmed[pose] = 0.f;
+        }
+        return;
+    }
+    const int target = (A.R - 1) / 2;
+    for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
+        float v = vals[i];
+        int rank = 0;
+        for (int j = 0; j < A.R; ++j) {
+            float u = vals[j];
+            rank += (u < v) || (u == v && j < i);
+        }
+        if (rank == target) { // exactly one i satisfies this
+            A.med[pose] = v;
+            A.who[pose] = i;
+            A.gmed[pose] = 0.f;
+        }
+    }
+}
+
+int launch_median(const Args &A, int sampler, int layout, hipStream_t st)
+{
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        hipLaunchKernelGGL((median_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(A.P), dim3(kBlock),
+                           sizeof(float) * (size_t)A.R, st, A);
+        return last_launch();
+    });
+}
+
+} // namespace
+
+// defined in scatter.hip (the only cross-unit call): volume-gradient scatter of the backward
+namespace diffus {
+int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st);
+}

@@ -1,0 +1,416 @@
+// render_bwd.hip -- backward kernel (adjoint scan), median backward, d/dsource reduction, and diffus_render_bwd
+#include "diffus_host.hpp"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// BACKWARD.  Notation (indices in cropped coordinates):
+//   T_n = M(r'_{n-1}),  P_n = P_{n-1} T_n,  echo_n = b_n/d_n,  (b_n,d_n) = 2nd column of P_n
+//   gbar_n = gframe_n * att_n;  Gbar_n = (gbar_n/d_n) [[0,1],[0,-echo_n]]
+//   U_{n-1} = (Gbar_n + U_n) T_n^T, U_N = 0;   Tbar_n = P_{n-1}^T (Gbar_n + U_n)
+//   rbar = -4 r Tbar_00 + Tbar_01 - Tbar_10
+// All P are carried rescaled by exact powers of two (P'_n = 2^{e_n} P_n); with
+// W_n = 2^{e_n-e_{n-1}} (Gbar'_n + U'_n):  Tbar_n = P'_{n-1}^T W_n,  U'_{n-1} = W_n T_n^T.
+// The chunk of one lane is an affine map U_in -> U_out; lanes are combined with a
+// reverse Hillis-Steele scan of affine maps (A, B, beta):  X -> A + X (B 2^beta)^T.
+#ifndef DIFFUS_BWD_MIN_WAVES
+#define DIFFUS_BWD_MIN_WAVES 1
+#endif
+template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM>
+__global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) void render_bwd_kernel(Args A)
+{
+    __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
+    constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 48 more registers
+    const int wib = threadIdx.x >> 6;
+    const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
+    if (w >= (long)A.P * A.R) return;
+    const int lane = threadIdx.x & 63;
+    const long pose = w / A.R;
+    const int n0 = lane * C;
+    float *wb = lds[wib];
+
+    Pose ps;
+    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+
+    float zi[C], gi0[C], gi1[C], gi2[C], z[C], r[C], gb[C];
+    gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD, PM>(A, ps, lane, zi, gi0, gi1, gi2);
+    to_chunked<C>(wb, lane, zi, z);
+    {
+        // upstream gradient row, read as 256-B runs, attenuation folded in
+        const float *gin = A.gframe + w * A.N1;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = j * kWave + lane;
+            zi[j] = (n < A.N1) ? gin[n] * fast_exp(__fmul_rn(A.neg_alpha, (float)n)) : 0.f;
+        }
+        to_chunked<C>(wb, lane, zi, gb);
+    }
+    const float zprev = __shfl_up(z[C - 1], 1, kWave);
+    const float medv = (A.start > 0) ? A.med[pose] : 0.f;
+    reflect_chunk<C>(A, n0, z, zprev, medv, r);
+
+    // ---- forward recompute with exponent tracking ----
+    Mat L = mat_identity();
+    int lam = 0; // L' = L * 2^lam
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        L = mat_step(L, r[j]);
+        lam -= mat_renorm(L);
+    }
+    const Mat Lloc = L;   // normalised local product T_first..T_last
+    const int lamloc = lam;
+    int iota = lam;       // inclusive prefix exponent
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Mat o = mat_shfl_up(L, off);
+        int oe = __shfl_up(iota, off, kWave);
+        if (lane >= off) {
+            L = mat_mul(o, L);
+            iota = oe + iota - mat_renorm(L);
+        }
+    }
+    Mat Pm = mat_shfl_up(L, 1);
+    int eps = __shfl_up(iota, 1, kWave); // exponent of the exclusive prefix
+    if (lane == 0) {
+        Pm = mat_identity();
+        eps = 0;
+    }
+
+    Mat Pin[C];  // P'_{n-1} as used by this lane
+    int ex[C];   // renorm exponent of step n
+    float gu[C]; // gbar_n / d'_n
+    float rho[C];
+    int esum = 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        Pin[j] = Pm;
+        Pm = mat_step(Pm, r[j]);
+        ex[j] = mat_renorm(Pm);
+        esum += ex[j];
+        float rd = __builtin_amdgcn_rcpf(Pm.d);
+        float e = Pm.b * rd;
+        float g = (e == e) ? gb[j] : 0.f; // echoes zeroed by nan_to_num are constants
+        float q = g * rd;
+        gu[j] = (g != 0.f) ? q : 0.f;
+        rho[j] = (e == e) ? e : 0.f;
+        // past a non-finite reflection coefficient every echo is the constant 0
+        if (!finitef(r[j]) || !mat_finite(Pin[j]) || !finitef(gu[j]) || !finitef(rho[j])) gu[j] = 0.f;
+    }
+
+    // exponent of this lane's last P' and the hop to the next lane's exclusive prefix
+    const int elast = eps - esum;
+    int eps_next = __shfl_down(eps, 1, kWave);
+    const int delta = (lane == kWave - 1) ? 0 : (eps_next - elast);
+
+    // ---- lane-local affine map: A-part = sweep from U = 0 ----
+    auto sweep = [&](Mat U, float *rbar) {
+#pragma unroll
+        for (int j = C - 1; j >= 0; --j) {
+            Mat W;
+            W.a = U.a;
+            W.b = U.b + gu[j];
+            W.c = U.c;
+            W.d = U.d - gu[j] * rho[j];
+            W = mat_scale(W, -ex[j]);
+            if (rbar) {
+                Mat Tb = mat_mul_at(Pin[j], W);
+                rbar[j] = __builtin_fmaf(-4.f * r[j], Tb.a, Tb.b - Tb.c);
+            }
+            float rr = finitef(r[j]) ? r[j] : 0.f; // non-finite step: cut the chain (U is zero there anyway)
+            U = mat_mul_bt(W, mat_of_r(rr));
+        }
+        return U;
+    };
+    Mat Aacc = sweep(Mat{0.f, 0.f, 0.f, 0.f}, nullptr);
+    Mat Bn = Lloc;                    // normalised linear part
+    int beta = delta - esum - lamloc; // B = Bn * 2^beta
+    if (!mat_finite(Bn)) Bn = Mat{0.f, 0.f, 0.f, 0.f}; // a non-finite chunk passes nothing
+
+    // ---- reverse inclusive scan of affine maps: G_l = F_l o F_{l+1} o ... o F_63 ----
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Mat oA = mat_shfl_down(Aacc, off);
+        Mat oB = mat_shfl_down(Bn, off);
+        int ob = __shfl_down(beta, off, kWave);
+        if (lane + off < kWave) {
+            Mat t = mat_scale(mat_mul_bt(oA, Bn), beta);
+            Aacc.a += t.a; Aacc.b += t.b; Aacc.c += t.c; Aacc.d += t.d;
+            Bn = mat_mul(Bn, oB);
+            beta = beta + ob + mat_renorm(Bn); // B = Bn * 2^beta: a rescale of Bn by 2^-ex adds ex
+        }
+    }
+    Mat Uin = mat_shfl_down(Aacc, 1);
+    if (lane == kWave - 1) Uin = Mat{0.f, 0.f, 0.f, 0.f};
+    Uin = mat_scale(Uin, delta);
+
+    float rbar[C];
+    sweep(Uin, rbar);
+
+    // ---- rbar -> zbar (d r / d Z of reference :33) ----
+    float zbar[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) zbar[j] = 0.f;
+    float carry = 0.f, gmed_lane = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        bool live = (n >= 1 && n < A.N1);
+        float rb = live ? rbar[j] : 0.f;
+        if (!finitef(rb)) rb = 0.f; // drop non-finite
+        if (n == 1 && A.start > 0) {
+            gmed_lane = rb;
+            rb = 0.f;
+        }
+        float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
+        float s = zp + z[j];
+        float inv = __builtin_amdgcn_rcpf(s);
+        float dz = 2.f * zp * inv * inv;     // d r / d Z_n
+        float dzp = -2.f * z[j] * inv * inv; // d r / d Z_{n-1}
+        float c1 = rb * dz, c0 = rb * dzp;
+        if (!finitef(c1)) c1 = 0.f;
+        if (!finitef(c0)) c0 = 0.f;
+        zbar[j] += c1;
+        if (j == 0)
+            carry = c0;
+        else
+            zbar[j == 0 ? 0 : j - 1] += c0;
+    }
+    float cin = __shfl_down(carry, 1, kWave);
+    if (lane != kWave - 1) zbar[C - 1] += cin;
+    if (gmed_lane != 0.f) atomicAdd(&A.gmed[pose], gmed_lane);
+
+    // ---- back to INTERLEAVED: hand zbar to the scatter kernel, reduce the pose gradient ----
+    // The volume scatter is a separate launch (scatter_patch_kernel): its thread <-> sample
+    // mapping is chosen for LDS privatisation, not for the scan.
+    to_interleaved<C>(wb, lane, zbar, zi);
+    if (A.zbar) {
+        float *zo = A.zbar + w * A.N1;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = j * kWave + lane;
+            if (n < A.N1) zo[n] = zi[j];
+        }
+    }
+    if (GPOSE) {
+        float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = j * kWave + lane;
+            float zb = zi[j];
+            if (n < A.N1 && zb != 0.f) {
+                int k = A.start + n;
+                float q0, q1, q2;
+                if (KEEP_GRAD) {
+                    q0 = gi0[j]; q1 = gi1[j]; q2 = gi2[j];
+                } else {
+                    TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point<PM>(ps, 0, k), ray_point<PM>(ps, 1, k),
+                                                           ray_point<PM>(ps, 2, k));
+                    q0 = s.g0; q1 = s.g1; q2 = s.g2;
+                }
+                float kf = (float)k;
+                float a0 = zb * q0, a1 = zb * q1, a2 = zb * q2;
+                gs0 += a0; gs1 += a1; gs2 += a2;
+                gd0 = __builtin_fmaf(kf, a0, gd0);
+                gd1 = __builtin_fmaf(kf, a1, gd1);
+                gd2 = __builtin_fmaf(kf, a2, gd2);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            gs0 += __shfl_xor(gs0, off, kWave);
+            gs1 += __shfl_xor(gs1, off, kWave);
+            gs2 += __shfl_xor(gs2, off, kWave);
+            gd0 += __shfl_xor(gd0, off, kWave);
+            gd1 += __shfl_xor(gd1, off, kWave);
+            gd2 += __shfl_xor(gd2, off, kWave);
+        }
+        if (lane == 0) {
+            if (A.gsrc_part) {
+                A.gsrc_part[w * 3 + 0] = gs0;
+                A.gsrc_part[w * 3 + 1] = gs1;
+                A.gsrc_part[w * 3 + 2] = gs2;
+            }
+            if (A.gdirs) {
+                A.gdirs[w * 3 + 0] = gd0;
+                A.gdirs[w * 3 + 1] = gd1;
+                A.gdirs[w * 3 + 2] = gd2;
+            }
+        }
+    }
+}
+
+// start > 0, backward: route gmed[p] to the ray that supplied the median
+// (torch.median's backward).  One thread per pose; runs after render_bwd_kernel.
+template <int SAMPLER, int LAYOUT>
+__global__ void median_bwd_kernel(Args A)
+{
+    const int pose = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pose >= A.P) return;
+    const int i = A.who[pose];
+    const float gm = A.gmed[pose];
+    if (i < 0 || gm == 0.f || !finitef(gm)) return;
+    const long w = (long)pose * A.R + i;
+    Pose ps;
+    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    float zz[2], g0[2], g1[2], g2[2];
+    for (int q = 0; q < 2; ++q) {
+        int k = A.start + q;
+        float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+            zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
+            g0[q] = g1[q] = g2[q] = 0.f;
+        } else {
+            TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, p0, p1, p2);
+            zz[q] = s.v; g0[q] = s.g0; g1[q] = s.g1; g2[q] = s.g2;
+        }
+    }
+    float s = zz[0] + zz[1];
+    float inv = __fdiv_rn(1.f, s);
+    float zb[2] = {gm * (-2.f * zz[1] * inv * inv), gm * (2.f * zz[0] * inv * inv)};
+    for (int q = 0; q < 2; ++q) {
+        if (!finitef(zb[q]) || zb[q] == 0.f) continue;
+        int k = A.start + q;
+        if (A.gvol) {
+            Cell c = cell_of<SAMPLER>(A, ps, k);
+            for_each_corner<SAMPLER>(c, zb[q], [&](int a, int b, int cc, float v) {
+                if (v != 0.f) {
+                    unsigned g = vox_off<GradLayout<LAYOUT>::value>(A.G, a, b, cc);
+                    atomicAdd(A.gvol + g, v);
+                    if (GradLayout<LAYOUT>::value == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
+                }
+            });
+        }
+        if (SAMPLER == DIFFUS_TRILINEAR) {
+            float kf = (float)k;
+            if (A.gsrc_part) {
+                A.gsrc_part[w * 3 + 0] += zb[q] * g0[q];
+                A.gsrc_part[w * 3 + 1] += zb[q] * g1[q];
+                A.gsrc_part[w * 3 + 2] += zb[q] * g2[q];
+            }
+            if (A.gdirs) {
+                A.gdirs[w * 3 + 0] += kf * zb[q] * g0[q];
+                A.gdirs[w * 3 + 1] += kf * zb[q] * g1[q];
+                A.gdirs[w * 3 + 2] += kf * zb[q] * g2[q];
+            }
+        }
+    }
+}
+
+// gsrc[p,:] = sum over rays of gsrc_part[p,:,:], fixed order => deterministic.
+__global__ __launch_bounds__(kBlock) void reduce_gsrc_kernel(const float *__restrict__ part, float *__restrict__ gsrc,
+                                                             int R)
+{
+    __shared__ float sm[3][kBlock];
+    const int pose = blockIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < R; i += kBlock) {
+        const float *q = part + ((long)pose * R + i) * 3;
+        a0 += q[0]; a1 += q[1]; a2 += q[2];
+    }
+    sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+            sm[2][threadIdx.x] += sm[2][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) gsrc[pose * 3 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+template <int SM, int LY, bool GPOSE, int PM>
+int launch_bwd_p(const Args &A, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(A.N1)) {
+    case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: // 16 samples per lane need ~300 registers: one wave per block so the whole 512-entry file is available
+        hipLaunchKernelGGL((render_bwd_kernel<16, SM, LY, GPOSE, 1, PM>), dim3((unsigned)waves), dim3(kWave), 0, st, A);
+        break;
+    }
+    return last_launch();
+}
+
+template <int SM, int LY, bool GPOSE>
+int launch_bwd_t(const Args &A, hipStream_t st)
+{
+    return (!A.src_f64 && !A.dir_f64) ? launch_bwd_p<SM, LY, GPOSE, 0>(A, st) : launch_bwd_p<SM, LY, GPOSE, 1>(A, st);
+}
+
+int launch_bwd(const Args &A, int sampler, int layout, bool pose, hipStream_t st)
+{
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+        if constexpr (SM == DIFFUS_NEAREST) {
+            return launch_bwd_t<SM, LY, false>(A, st);
+        } else {
+            return pose ? launch_bwd_t<SM, LY, true>(A, st) : launch_bwd_t<SM, LY, false>(A, st);
+        }
+    });
+}
+
+} // namespace
+
+extern "C" {
+
+int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                      const float *gframe, float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
+                      void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
+    if (rc) return rc;
+    if (!gframe) return DIFFUS_EINVAL;
+    if (stages < 1 || stages > DIFFUS_BWD_ALL) return DIFFUS_EINVAL;
+    if (!gvol && !gsrc && !gdirs) return DIFFUS_OK;
+    const bool do_scan = stages & DIFFUS_BWD_SCAN, do_scatter = stages & DIFFUS_BWD_SCATTER;
+    Workspace ws = carve(workspace, P, R, S - start);
+    if (!workspace || workspace_bytes < ws.bytes) return DIFFUS_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool pose = sampler == DIFFUS_TRILINEAR && (gsrc || gdirs);
+    if (sampler == DIFFUS_NEAREST && do_scan) { // integer indices: no pose gradient (reference :754-758)
+        if (gsrc && hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)P * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
+        if (gdirs && hipMemsetAsync(gdirs, 0, sizeof(float) * (size_t)P * R * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
+    }
+    if (sampler == DIFFUS_NEAREST && !gvol) return DIFFUS_OK;
+    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
+    A.gframe = gframe;
+    A.gvol = gvol;
+    A.gtouched = (gvol && layout != DIFFUS_CANONICAL) ? gvol_touched : nullptr;
+    A.zbar = gvol ? ws.zbar : nullptr;
+    A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
+    A.gdirs = pose ? gdirs : nullptr;
+    if (do_scan) {
+        if (start > 0) { // recompute the median (and zero gmed)
+            rc = launch_median(A, sampler, layout, st);
+            if (rc) return rc;
+        }
+        rc = launch_bwd(A, sampler, layout, pose, st);
+        if (rc) return rc;
+    }
+    if (gvol && do_scatter) {
+        rc = diffus::launch_scatter(A, sampler, layout, st);
+        if (rc) return rc;
+    }
+    if (start > 0 && do_scan) {
+        const unsigned nb = (unsigned)((P + 63) / 64);
+        rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+            hipLaunchKernelGGL((median_bwd_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nb), dim3(64), 0, st, A);
+            return last_launch();
+        });
+        if (rc) return rc;
+    }
+    if (pose && gsrc && do_scan) {
+        hipLaunchKernelGGL(reduce_gsrc_kernel, dim3(P), dim3(kBlock), 0, st, ws.gsrc_part, gsrc, R);
+        if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
+    }
+    return DIFFUS_OK;
+}
+
+} // extern "C"

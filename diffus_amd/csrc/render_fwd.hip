@@ -1,0 +1,256 @@
+// render_fwd.hip -- forward kernel (plot_beam_frame), the stage-wise kernels, and their C-ABI entry points
+#include "diffus_host.hpp"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// FORWARD  (replaces reference src/renderer.py:201-275 with artifacts=False)
+#ifndef DIFFUS_FWD_MIN_WAVES
+#define DIFFUS_FWD_MIN_WAVES 1
+#endif
+template <int C, int SAMPLER, int LAYOUT, int WPB, int PM>
+__global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) void render_fwd_kernel(Args A)
+{
+    __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
+    const int wib = threadIdx.x >> 6;
+    const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
+    if (w >= (long)A.P * A.R) return; // wave-uniform; no block-level barrier below
+    const int lane = threadIdx.x & 63;
+    const long pose = w / A.R;
+    const int n0 = lane * C;
+    float *wb = lds[wib];
+
+    Pose ps;
+    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+
+    float zi[C], z[C], r[C], e[C], u0[C], u1[C], u2[C];
+#ifdef DIFFUS_ABLATE_GATHER
+#pragma unroll
+    for (int j = 0; j < C; ++j) zi[j] = ps.sf[0] + (float)(j * kWave + lane) * ps.df[1];
+#else
+    gather_interleaved<C, SAMPLER, LAYOUT, false, PM>(A, ps, lane, zi, u0, u1, u2);
+#endif
+#ifdef DIFFUS_ABLATE_TRANSPOSE
+#pragma unroll
+    for (int j = 0; j < C; ++j) z[j] = zi[j];
+#else
+    to_chunked<C>(wb, lane, zi, z);
+#endif
+    float zprev = __shfl_up(z[C - 1], 1, kWave);
+    float medv = (A.start > 0) ? A.med[pose] : 0.f;
+    reflect_chunk<C>(A, n0, z, zprev, medv, r);
+#ifdef DIFFUS_ABLATE_SCAN
+#pragma unroll
+    for (int j = 0; j < C; ++j) e[j] = r[j];
+#else
+    echo_chunk<C, true>(r, lane, e);
+#endif
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        // attenuation, reference :256-259: f32(-alpha) * f32(n), exp, multiply
+        float att = fast_exp(__fmul_rn(A.neg_alpha, (float)(n0 + j)));
+        e[j] = __fmul_rn(e[j], att);
+    }
+#ifdef DIFFUS_ABLATE_TRANSPOSE
+#pragma unroll
+    for (int j = 0; j < C; ++j) zi[j] = e[j];
+#else
+    to_interleaved<C>(wb, lane, e, zi);
+#endif
+    float *out = A.frame + w * A.N1;
+#ifdef DIFFUS_ABLATE_STORE
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) acc += zi[j];
+    if (acc == 123.456f) out[lane] = acc;
+#else
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = j * kWave + lane;
+        if (n < A.N1) out[n] = zi[j];
+    }
+#endif
+
+    if (A.idx) {
+        const long plane = (long)A.P * A.R * A.N1;
+        long long *ix = A.idx + w * A.N1;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = j * kWave + lane;
+            if (n < A.N1) {
+                int k = A.start + n;
+                ix[n] = nearest_index(ray_point<PM>(ps, 0, k), A.G.d0);
+                ix[plane + n] = nearest_index(ray_point<PM>(ps, 1, k), A.G.d1);
+                ix[2 * plane + n] = nearest_index(ray_point<PM>(ps, 2, k), A.G.d2);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Standalone stages (rows a3-a6 and a7-a9 of SURVEY §8a), exposed so that each
+// can be checked against the reference's golden vectors in isolation.
+
+// trace_ray + custom_nearest_sampler + compute_reflection_coeff
+// (reference src/renderer.py:90-180, :741-759, :27-33, :65-68): one thread per sample.
+template <int SAMPLER, int LAYOUT>
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(Args A, float *__restrict__ imp, float *__restrict__ refl,
+                                                            long long *__restrict__ idx)
+{
+    const long total = (long)A.P * A.R * A.S;
+    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long)gridDim.x * kBlock) {
+        const long w = t / A.S;
+        const int k = (int)(t - w * A.S);
+        Pose ps;
+        load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, w / A.R, w);
+        float zz[2];
+        const int nq = (refl && k + 1 < A.S) ? 2 : 1;
+        for (int q = 0; q < nq; ++q) {
+            float p0 = ray_point(ps, 0, k + q), p1 = ray_point(ps, 1, k + q), p2 = ray_point(ps, 2, k + q);
+            int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+            if (q == 0 && idx) {
+                idx[t] = i0;
+                idx[total + t] = i1;
+                idx[2 * total + t] = i2;
+            }
+            if (SAMPLER == DIFFUS_NEAREST)
+                zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
+            else
+                zz[q] = tri_sample<LAYOUT, false>(A.vol, A.G, p0, p1, p2).v;
+        }
+        if (imp) imp[t] = zz[0];
+        if (refl && k + 1 < A.S) refl[w * (A.S - 1) + k] = reflect(zz[0], zz[1]);
+    }
+}
+
+// compute_echo_traces (reference src/renderer.py:439-457): r (B,N) -> echo (B,N+1),
+// one wave per row.
+template <int C>
+__global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__restrict__ rin, float *__restrict__ echo,
+                                                             int B, int N)
+{
+    const long w = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int n0 = lane * C;
+    float r[C], e[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        r[j] = (n >= 1 && n <= N) ? rin[w * N + n - 1] : 0.f;
+    }
+    echo_chunk<C>(r, lane, e);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        int n = n0 + j;
+        if (n <= N) echo[w * (N + 1) + n] = e[j];
+    }
+}
+
+template <int SM, int LY, int PM>
+int launch_fwd_t(const Args &A, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(A.N1)) {
+    case 2: hipLaunchKernelGGL((render_fwd_kernel<2, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 4: hipLaunchKernelGGL((render_fwd_kernel<4, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: hipLaunchKernelGGL((render_fwd_kernel<8, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: hipLaunchKernelGGL((render_fwd_kernel<16, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    }
+    return last_launch();
+}
+
+int launch_fwd(const Args &A, int sampler, int layout, hipStream_t st)
+{
+    const bool f32 = !A.src_f64 && !A.dir_f64;
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+        return f32 ? launch_fwd_t<SM, LY, 0>(A, st) : launch_fwd_t<SM, LY, 1>(A, st);
+    });
+}
+
+
+} // namespace
+
+extern "C" {
+
+int diffus_abi_version(void) { return DIFFUS_ABI_VERSION; }
+
+const char *diffus_strerror(int code)
+{
+    switch (code) {
+    case DIFFUS_OK: return "ok";
+    case DIFFUS_EINVAL: return "invalid argument";
+    case DIFFUS_EUNSUPPORTED: return "unsupported shape (S - start > 1024, a volume edge > 2^24, or too many rays for start > 0)";
+    case DIFFUS_ELAUNCH: return "HIP launch failure";
+    case DIFFUS_EWORKSPACE: return "workspace too small (see diffus_workspace_bytes)";
+    default: return "unknown diffus error";
+    }
+}
+
+size_t diffus_workspace_bytes(int P, int R, int S, int start)
+{
+    if (P <= 0 || R <= 0 || S <= 0 || start < 0 || start >= S) return 0;
+    return carve(nullptr, P, R, S - start).bytes;
+}
+
+int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                      float *frame, int64_t *idx, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
+    if (rc) return rc;
+    if (!frame) return DIFFUS_EINVAL;
+    Workspace ws = carve(workspace, P, R, S - start);
+    if (start > 0 && (!workspace || workspace_bytes < ws.bytes)) return DIFFUS_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
+    A.frame = frame;
+    A.idx = (long long *)idx;
+    if (start > 0) {
+        rc = launch_median(A, sampler, layout, st);
+        if (rc) return rc;
+    }
+    return launch_fwd(A, sampler, layout, st);
+}
+
+int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype, int P, int R, int S, int sampler, float *imp, float *refl,
+                      int64_t *idx, diffus_stream_t stream)
+{
+    int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, sampler, layout, false);
+    if (rc) return rc;
+    if (!imp && !refl && !idx) return DIFFUS_OK;
+    Workspace ws = carve(nullptr, P, R, S);
+    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, 0.f, ws);
+    const long total = (long)P * R * S;
+    unsigned nblk = (unsigned)((total + kBlock - 1) / kBlock);
+    if (nblk > 256u * 16u) nblk = 256u * 16u;
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        hipLaunchKernelGGL((trace_rays_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nblk), dim3(kBlock), 0, st,
+                           A, imp, refl, (long long *)idx);
+        return last_launch();
+    });
+}
+
+// ---- scan conversion ----
+
+int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stream_t stream)
+{
+    if (!refl && N > 0) return DIFFUS_EINVAL;
+    if (!echo || B <= 0 || N < 0) return DIFFUS_EINVAL;
+    if (N + 1 > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nblk = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+    switch (chunk_for(N + 1)) {
+    case 2: hipLaunchKernelGGL(echo_traces_kernel<2>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    case 4: hipLaunchKernelGGL(echo_traces_kernel<4>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    case 8: hipLaunchKernelGGL(echo_traces_kernel<8>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    default: hipLaunchKernelGGL(echo_traces_kernel<16>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
+    }
+    return last_launch();
+}
+
+} // extern "C"

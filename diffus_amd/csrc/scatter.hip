@@ -1,0 +1,423 @@
+// scatter.hip -- volume-gradient scatter (LDS-privatised patches), sparse gradient flush, layout conversions
+#include "diffus_host.hpp"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// VOLUME SCATTER.  gvol += sum over samples of zbar * (interpolation weights).
+// Naive per-sample global float atomics run ~10x below even the scattered-atomic
+// rate because every fan hammers the few hundred voxels around its apex
+// (measured: 17.5 ms for 33 M atomics at config 3).  Instead a block takes a PATCH
+// of kPatchRays adjacent rays x kPatchSteps consecutive steps of one pose, whose
+// footprint is a small box of voxels; it accumulates the patch into an LDS tile
+// covering that box (ds_add_f32) and flushes each touched voxel ONCE.  In the
+// bricked layout the tile is a box of whole bricks, so the flush is made of
+// 128-B contiguous atomic runs (the full-rate shape of global_atomic_add_f32).
+// Patches whose box does not fit the tile fall back to direct global atomics.
+#ifdef DIFFUS_STAMP // diagnostic build only (tools/): per-block phase timestamps of the scatter kernel
+__device__ unsigned long long *g_stamps = nullptr;
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(i) ((void)0)
+#endif
+
+// tile units: voxels (canonical) or bricks (bricked)
+template <int LAYOUT>
+__device__ __forceinline__ int tile_unit(int v, int axis)
+{
+    if (LAYOUT == DIFFUS_CANONICAL) return v;
+    return axis == 2 ? (v >> 1) : (v >> 2);
+}
+
+template <int SAMPLER, int LAYOUT, int PM>
+__global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_groups, int step_groups)
+{
+    // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
+    // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
+    // The tile therefore accumulates in 32-bit FIXED POINT with a per-patch power-of-two
+    // scale 2^fx chosen so that even all 1024 samples landing on one voxel cannot
+    // overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel can
+    // receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution,
+    // typically 2^-23..2^-26; integer adds commute, so a tile sum is bitwise reproducible.
+    __shared__ int tile[kTileCap];
+    __shared__ int s_lo[3], s_hi[3], s_max;
+    __shared__ float s_sum[kWavesPerBlock];
+    constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
+
+    // patch -> (pose, ray group, step group); the XCD remap keeps a pose on one XCD
+    const unsigned Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int sg = Lb % step_groups;
+    const int rg = (Lb / step_groups) % ray_groups;
+    const int pose = Lb / (step_groups * ray_groups);
+    const int tid = threadIdx.x;
+    // thread -> ray (tid / 16) and 4 consecutive steps ((tid % 16) * 4 ..)
+    const int ray = rg * kPatchRays + tid / (kPatchSteps / kSamplesPerThread);
+    const int nbase = sg * kPatchSteps + (tid % (kPatchSteps / kSamplesPerThread)) * kSamplesPerThread;
+    const bool ray_ok = ray < A.R;
+    const long w = (long)pose * A.R + (ray_ok ? ray : 0);
+
+    STAMP(0);
+    if (tid < 3) {
+        s_lo[tid] = 0x7fffffff;
+        s_hi[tid] = -1;
+    }
+    if (tid == 3) s_max = 0;
+    Pose ps;
+    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    Cell cells[kSamplesPerThread];
+    float zb[kSamplesPerThread];
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    float zmax = 0.f;
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+        int n = nbase + q;
+        zb[q] = 0.f;
+        if (ray_ok && n < A.N1) zb[q] = A.zbar[w * A.N1 + n];
+        if (!finitef(zb[q])) zb[q] = 0.f;
+        cells[q] = cell_of<SAMPLER, PM>(A, ps, A.start + n);
+        zmax = fmaxf(zmax, fabsf(zb[q]));
+        if (zb[q] != 0.f) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = min(lo[a], tile_unit<LAYOUT>(cells[q].i0[a], a));
+                hi[a] = max(hi[a], tile_unit<LAYOUT>(cells[q].i1[a], a));
+            }
+        }
+    }
+    STAMP(1);
+    // block bounding box: DPP wave reduce, then one LDS atomic per wave
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_reduce_minmax<true>(lo[a]);
+        hi[a] = wave_reduce_minmax<false>(hi[a]);
+    }
+    zmax = __int_as_float(wave_reduce_minmax<false>(__float_as_int(zmax))); // zmax >= 0: bits order like floats
+    float zsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) zsum += fabsf(zb[q]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) zsum += __shfl_xor(zsum, off, kWave);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&s_lo[a], lo[a]);
+            atomicMax(&s_hi[a], hi[a]);
+        }
+        atomicMax(&s_max, __float_as_int(zmax)); // non-negative floats order like their bit patterns
+        s_sum[tid >> 6] = zsum;
+    }
+    __syncthreads();
+    STAMP(2);
+    const int l0 = s_lo[0], l1 = s_lo[1], l2 = s_lo[2];
+    if (s_hi[0] < 0) return; // nothing to add in this patch (block-uniform)
+    const int b0 = s_hi[0] - l0 + 1, b1 = s_hi[1] - l1 + 1, b2 = s_hi[2] - l2 + 1;
+    const long vol_tile = (long)b0 * b1 * b2 * UNIT;
+
+    if (vol_tile > kTileCap) { // block-uniform fallback: direct atomics
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+            if (zb[q] != 0.f)
+                for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
+                    if (v != 0.f) {
+                        unsigned g = vox_off<LAYOUT>(A.G, i, j, k);
+                        atomicAdd(A.gvol + g, v);
+                        if (LAYOUT == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
+                    }
+                });
+        return;
+    }
+    const int nt = (int)vol_tile;
+    // (s_sum total) * 2^fx in [2^28, 2^29): headroom for the rounding of each contribution
+    const float ztot = fmaxf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]), __int_as_float(s_max));
+    const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
+    for (int e = tid; e < nt; e += kBlock) tile[e] = 0;
+    __syncthreads();
+    STAMP(3);
+    // tile index = ex(i) + ey(j) + ez(k): three separable parts, each evaluated for the two
+    // coordinates of its axis only (6 small computations per sample instead of 8 full ones)
+    auto part = [&](int v, int axis) -> int {
+        if (LAYOUT == DIFFUS_CANONICAL)
+            return axis == 0 ? (v - l0) * b1 * b2 : (axis == 1 ? (v - l1) * b2 : (v - l2));
+        return axis == 0 ? (((v >> 2) - l0) * b1 * b2 * kBrickFloats + ((v & 3) << 3))
+                         : (axis == 1 ? (((v >> 2) - l1) * b2 * kBrickFloats + ((v & 3) << 1))
+                                      : (((v >> 1) - l2) * kBrickFloats + (v & 1)));
+    };
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q)
+        if (zb[q] != 0.f) {
+            const Cell &c = cells[q];
+            const float sc = ldexpf(zb[q], fx);
+            if (SAMPLER == DIFFUS_NEAREST) {
+                atomicAdd(&tile[part(c.i0[0], 0) + part(c.i0[1], 1) + part(c.i0[2], 2)], __float2int_rn(sc));
+            } else {
+                const int ex0 = part(c.i0[0], 0), ex1 = part(c.i1[0], 0), ey0 = part(c.i0[1], 1), ey1 = part(c.i1[1], 1),
+                          ez0 = part(c.i0[2], 2), ez1 = part(c.i1[2], 2);
+                const float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1, wc1 = c.t[2], wc0 = 1.f - wc1;
+                const float w00 = sc * wa0 * wb0, w01 = sc * wa0 * wb1, w10 = sc * wa1 * wb0, w11 = sc * wa1 * wb1;
+                // clamped samples (outside the volume: more than half of a typical fan) have zero
+                // weights on half or more of their corners: do not spend an LDS atomic on a zero
+                auto add = [&](int e, float v) {
+                    int q = __float2int_rn(v);
+                    if (q != 0) atomicAdd(&tile[e], q);
+                };
+                add(ex0 + ey0 + ez0, w00 * wc0);
+                add(ex0 + ey0 + ez1, w00 * wc1);
+                add(ex0 + ey1 + ez0, w01 * wc0);
+                add(ex0 + ey1 + ez1, w01 * wc1);
+                add(ex1 + ey0 + ez0, w10 * wc0);
+                add(ex1 + ey0 + ez1, w10 * wc1);
+                add(ex1 + ey1 + ez0, w11 * wc0);
+                add(ex1 + ey1 + ez1, w11 * wc1);
+            }
+        }
+    __syncthreads();
+    STAMP(4);
+    // Flush every touched entry once.  No integer division per entry (the first version's
+    // e -> (i,j,k) by three divisions was 80 us of VALU at config 3): walk (i, m = j*b2+k)
+    // and split m with one exact float-reciprocal division by the tiny b2.
+    const int b12 = b1 * b2;
+    const float rb2 = __frcp_rn((float)b2);
+    constexpr int LPU = (UNIT == 1) ? 1 : UNIT;          // lanes per tile unit
+    const int o = (UNIT == 1) ? 0 : (tid & (LPU - 1));   // float inside the brick
+    const int msub = tid / LPU, mstep = kBlock / LPU;
+    for (int i = 0; i < b0; ++i) {
+        for (int m = msub; m < b12; m += mstep) {
+            int v = tile[(i * b12 + m) * UNIT + o];
+            // a half-wave = one brick (bricked) -- skip the address arithmetic for all-zero bricks
+            bool any = v != 0;
+            if (UNIT != 1) any = (unsigned)(__ballot(v != 0) >> (tid & 32)) != 0u;
+            if (any) {
+                int j = __float2int_rz(((float)m + 0.5f) * rb2); // exact: m < 2^14, b2 <= 2^14
+                int k = m - j * b2;
+                unsigned g;
+                if (LAYOUT == DIFFUS_CANONICAL)
+                    g = ((unsigned)(l0 + i) * (unsigned)A.G.d1 + (unsigned)(l1 + j)) * (unsigned)A.G.d2 + (unsigned)(l2 + k);
+                else
+                    g = (((unsigned)(l0 + i) * (unsigned)A.G.nb1 + (unsigned)(l1 + j)) * (unsigned)A.G.nb2 + (unsigned)(l2 + k)) * kBrickFloats + (unsigned)o;
+                // one plain, idempotent flag store per touched brick; no returning atomic (its latency
+                // would sit on the flush path)
+                if (LAYOUT == DIFFUS_BRICKED && A.gtouched && o == 0) A.gtouched[g >> 5] = 1;
+                if (v != 0) atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
+            }
+        }
+    }
+    STAMP(5);
+#ifdef DIFFUS_STAMP
+    if (threadIdx.x == 0 && g_stamps) {
+        g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)nt;
+        g_stamps[(size_t)blockIdx.x * 8 + 7] = 1;
+    }
+#endif
+}
+
+} // namespace
+
+namespace diffus {
+int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
+{
+    const int rgs = (A.R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
+    const unsigned nb = (unsigned)((long)A.P * rgs * sgs);
+    const bool f32 = !A.src_f64 && !A.dir_f64;
+    const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout; // the scatter only sees the gradient
+    return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
+        constexpr int SM = decltype(S_)::value, LY = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
+        if (f32)
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
+        else
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
+        return last_launch();
+    });
+}
+} // namespace diffus
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// canonical <-> bricked conversion.  A block moves 4 x 4 x 64 voxels (32 bricks,
+// 4 KiB): 16 canonical rows of 256 B on one side, 4 KiB contiguous on the other,
+// through an LDS transpose so that both sides are coalesced.
+constexpr int kConvZ = 64;
+template <bool TO_BRICKED, bool ACCUMULATE>
+__global__ __launch_bounds__(kBlock) void brick_convert_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                               Geom G)
+{
+    __shared__ float t[16][kConvZ + 1];
+    const int bz0 = blockIdx.x * (kConvZ / 2); // first brick along dim 2
+    const int by = blockIdx.y, bx = blockIdx.z;
+    const int tid = threadIdx.x;
+    const long brick0 = ((long)bx * G.nb1 + by) * G.nb2 + bz0;
+    if (TO_BRICKED) {
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int row = e / kConvZ, zz = e - row * kConvZ;
+            int x = bx * 4 + (row >> 2), y = by * 4 + (row & 3), z = bz0 * 2 + zz;
+            t[row][zz] = (x < G.d0 && y < G.d1 && z < G.d2) ? in[((long)x * G.d1 + y) * G.d2 + z] : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int brick = e >> 5, off = e & 31;
+            if (bz0 + brick < G.nb2) out[(brick0 + brick) * kBrickFloats + off] = t[off >> 1][brick * 2 + (off & 1)];
+        }
+    } else {
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int brick = e >> 5, off = e & 31;
+            if (bz0 + brick < G.nb2) t[off >> 1][brick * 2 + (off & 1)] = in[(brick0 + brick) * kBrickFloats + off];
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+            int row = e / kConvZ, zz = e - row * kConvZ;
+            int x = bx * 4 + (row >> 2), y = by * 4 + (row & 3), z = bz0 * 2 + zz;
+            if (x < G.d0 && y < G.d1 && z < G.d2) {
+                long o = ((long)x * G.d1 + y) * G.d2 + z;
+                if (ACCUMULATE)
+                    out[o] += t[row][zz];
+                else
+                    out[o] = t[row][zz];
+            }
+        }
+    }
+}
+
+// Sparse bricked gradient -> canonical: one wave per 64 bricks reads their "touched" flags; every
+// touched brick is added into (or stored to) the canonical tensor, ZEROED in the bricked buffer and
+// its flag cleared, so the bricked buffer and the flags are all-zero again afterwards.  A fan touches
+// a few thousand of the 524 288 bricks of a 256^3 volume: this replaces a 64 MiB memset plus a
+// 128 MiB dense conversion per step.
+__global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict__ bricked, int *__restrict__ touched,
+                                                               float *__restrict__ out, Geom G, long nbricks,
+                                                               int accumulate)
+{
+    __shared__ int s_list[kWavesPerBlock][kWave];
+    const int wib = threadIdx.x >> 6;
+    const long w = (long)blockIdx.x * kWavesPerBlock + wib;
+    const int lane = threadIdx.x & 63;
+    const long b0 = w * kWave;
+    if (b0 >= nbricks) return;
+    const long mine = b0 + lane;
+    int f = (mine < nbricks) ? touched[mine] : 0;
+    unsigned long long m = __ballot(f != 0);
+    if (m == 0) return; // wave-uniform: nothing touched in these 64 bricks
+    if (f) {
+        touched[mine] = 0;
+        s_list[wib][__builtin_popcountll(m & ((1ull << lane) - 1))] = lane; // compact the touched ids
+    }
+    wave_lds_sync();
+    const int cnt = __builtin_popcountll(m);
+    const int o = lane & 31, half = lane >> 5;
+    // two bricks per step (one per half-wave); iterations are independent so their loads overlap
+#pragma unroll 4
+    for (int i = half; i < cnt; i += 2) {
+        const long brick = b0 + s_list[wib][i];
+        float v = bricked[brick * kBrickFloats + o];
+        bricked[brick * kBrickFloats + o] = 0.f;
+        long bz = brick % G.nb2, t = brick / G.nb2;
+        long by = t % G.nb1, bx = t / G.nb1;
+        int x = (int)bx * 4 + (o >> 3), y = (int)by * 4 + ((o >> 1) & 3), z = (int)bz * 2 + (o & 1);
+        if (x < G.d0 && y < G.d1 && z < G.d2) {
+            long a = ((long)x * G.d1 + y) * G.d2 + z;
+            out[a] = accumulate ? out[a] + v : v;
+        }
+    }
+}
+
+// canonical -> PAIRED: a block writes 4 x 4 columns x 32 depths (4 KiB contiguous) from 16 canonical
+// rows of 33 floats, through LDS.
+__global__ __launch_bounds__(kBlock) void pair_convert_kernel(const float *__restrict__ in, float *__restrict__ out, Geom G)
+{
+    __shared__ float t[16][34];
+    const int z0 = blockIdx.x * 32;
+    const int by = blockIdx.y, bx = blockIdx.z;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 16 * 33; e += kBlock) {
+        int row = e / 33, zz = e - row * 33;
+        int x = min(bx * 4 + (row >> 2), G.d0 - 1), y = min(by * 4 + (row & 3), G.d1 - 1), z = min(z0 + zz, G.d2 - 1);
+        t[row][zz] = in[((long)x * G.d1 + y) * G.d2 + z];
+    }
+    __syncthreads();
+    const long col0 = ((long)bx * G.nb1 + by) * G.d2 + z0;
+    for (int e = tid; e < 32 * kBrickFloats; e += kBlock) {
+        int zz = e >> 5, off = e & 31;
+        if (z0 + zz < G.d2) out[(col0 + zz) * kBrickFloats + off] = t[off >> 1][zz + (off & 1)];
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+size_t diffus_bricked_floats(int d0, int d1, int d2)
+{
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
+    return bricked_floats(d0, d1, d2);
+}
+
+size_t diffus_brick_count(int d0, int d1, int d2)
+{
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
+    return bricked_floats(d0, d1, d2) / kBrickFloats;
+}
+
+int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, float *vol, int accumulate,
+                         diffus_stream_t stream)
+{
+    if (!bricked || !touched || !vol || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    const long nbricks = (long)(bricked_floats(d0, d1, d2) / kBrickFloats);
+    const long waves = (nbricks + kWave - 1) / kWave;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(gradbuf_flush_kernel, dim3(nblk), dim3(kBlock), 0, (hipStream_t)stream, bricked, touched, vol, G,
+                       nbricks, accumulate);
+    return last_launch();
+}
+
+size_t diffus_paired_floats(int d0, int d1, int d2)
+{
+    if (d0 <= 0 || d1 <= 0 || d2 <= 0) return 0;
+    return paired_floats(d0, d1, d2);
+}
+
+int diffus_pair_volume(const float *vol, int d0, int d1, int d2, float *paired, diffus_stream_t stream)
+{
+    if (!vol || !paired || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    dim3 grid((d2 + 31) / 32, G.nb1, (d0 + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
+    hipLaunchKernelGGL(pair_convert_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, vol, paired, G);
+    return last_launch();
+}
+
+int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked, diffus_stream_t stream)
+{
+    if (!vol || !bricked || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    dim3 grid((G.nb2 + kConvZ / 2 - 1) / (kConvZ / 2), G.nb1, (d0 + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
+    hipLaunchKernelGGL((brick_convert_kernel<true, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, vol, bricked, G);
+    return last_launch();
+}
+
+int diffus_unbrick_volume(const float *bricked, int d0, int d1, int d2, float *vol, int accumulate,
+                          diffus_stream_t stream)
+{
+    if (!vol || !bricked || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    Geom G = make_geom(d0, d1, d2);
+    dim3 grid((G.nb2 + kConvZ / 2 - 1) / (kConvZ / 2), G.nb1, (d0 + 3) / 4);
+    if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
+    if (accumulate)
+        hipLaunchKernelGGL((brick_convert_kernel<false, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G);
+    else
+        hipLaunchKernelGGL((brick_convert_kernel<false, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G);
+    return last_launch();
+}
+
+#ifdef DIFFUS_STAMP
+int diffus_debug_set_stamps(unsigned long long *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+} // extern "C"

@@ -1,0 +1,349 @@
+// splat.hip -- scan conversion (differentiable_splat) and the benchmark loss, with their C-ABI entry points
+#include "diffus_host.hpp"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// SCAN CONVERSION  (SURVEY §8f row 1): differentiable_splat, reference src/renderer.py:694-737.
+//   image[idx1, idx0] "+=" intensities is an index_put WITHOUT accumulation: of the samples that
+//   round to one pixel the LAST one in flattened order wins, and weight is 1 where any sample
+//   landed (:717-722).  Then both are blurred with a normalised Gaussian (zero padding) and divided
+//   (:725-735); the result is returned transposed (:737).  Autograd hands every sample the gradient
+//   of its pixel, winners and losers alike (index_put's backward is a gather).
+// Pipeline: winner (atomicMax of the sample index) -> compose (image, weight) -> separable blur ->
+// divide + transpose.  Backward: q = gout^T / (blur(weight) + eps) -> blur -> gather per sample.
+constexpr int kSplatTile = 32;
+constexpr int kSplatMaxHalf = 24; // kernel half-width int(6 sigma)|1 >> 1  =>  sigma <= 8
+
+__device__ __forceinline__ int splat_pixel(float c0, float c1, int H, int W)
+{
+    // clamp(round(coord).long(), 0, size-1) with round-half-even (reference :717-718)
+    return nearest_index(c1, H) * W + nearest_index(c0, W);
+}
+
+// winner[pixel] = largest sample index landing on it.  Samples are visited from the LAST to the
+// first and a sample first looks (plain load) whether a later one already owns its pixel: a stale
+// look only costs a redundant atomic, never a wrong answer, and it removes almost all of the
+// same-address atomics around the fan apex (4.2 M contended atomicMax took 1.6 ms without it).
+__global__ __launch_bounds__(kBlock) void splat_winner_kernel(const float *__restrict__ c0, const float *__restrict__ c1,
+                                                              long n, int H, int W, int *winner)
+{
+    const long pz = blockIdx.y;
+    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long)gridDim.x * kBlock) {
+        const long s = n - 1 - t;
+        int *w = &winner[pz * H * W + splat_pixel(c0[pz * n + s], c1[pz * n + s], H, W)];
+        if (__builtin_nontemporal_load(w) < (int)s) atomicMax(w, (int)s);
+    }
+}
+
+// The same, privatised: a block takes a patch of 16 rows x 64 columns of the (rows, cols) sample
+// grid (adjacent rays x consecutive steps: a compact pixel footprint), resolves the winner per
+// pixel in an LDS tile over the patch's pixel bounding box (ds_max_i32), and issues ONE global
+// atomicMax per touched pixel.  Falls back to the direct form when the box does not fit.
+__global__ __launch_bounds__(kBlock) void splat_winner_patch_kernel(const float *__restrict__ c0,
+                                                                    const float *__restrict__ c1, int rows, int cols,
+                                                                    int H, int W, int *winner, int row_groups,
+                                                                    int col_groups)
+{
+    __shared__ int tile[kTileCap];
+    __shared__ int s_lo[2], s_hi[2];
+    const long pz = blockIdx.y, n = (long)rows * cols;
+    const int cg = blockIdx.x % col_groups, rg = blockIdx.x / col_groups;
+    const int tid = threadIdx.x;
+    const int row = rg * kPatchRays + tid / (kPatchSteps / kSamplesPerThread);
+    const int cbase = cg * kPatchSteps + (tid % (kPatchSteps / kSamplesPerThread)) * kSamplesPerThread;
+    if (tid < 2) {
+        s_lo[tid] = 0x7fffffff;
+        s_hi[tid] = -1;
+    }
+    int px[kSamplesPerThread], py[kSamplesPerThread], sid[kSamplesPerThread];
+    int lo0 = 0x7fffffff, lo1 = 0x7fffffff, hi0 = -1, hi1 = -1;
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+        int c = cbase + q;
+        sid[q] = -1;
+        px[q] = py[q] = 0;
+        if (row < rows && c < cols) {
+            long s = (long)row * cols + c;
+            sid[q] = (int)s;
+            px[q] = nearest_index(c0[pz * n + s], W);
+            py[q] = nearest_index(c1[pz * n + s], H);
+            lo0 = min(lo0, px[q]); hi0 = max(hi0, px[q]);
+            lo1 = min(lo1, py[q]); hi1 = max(hi1, py[q]);
+        }
+    }
+    lo0 = wave_reduce_minmax<true>(lo0); hi0 = wave_reduce_minmax<false>(hi0);
+    lo1 = wave_reduce_minmax<true>(lo1); hi1 = wave_reduce_minmax<false>(hi1);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        atomicMin(&s_lo[0], lo0); atomicMax(&s_hi[0], hi0);
+        atomicMin(&s_lo[1], lo1); atomicMax(&s_hi[1], hi1);
+    }
+    __syncthreads();
+    if (s_hi[0] < 0) return;
+    const int l0 = s_lo[0], l1 = s_lo[1], b0 = s_hi[0] - l0 + 1, b1 = s_hi[1] - l1 + 1;
+    int *wz = winner + pz * H * W;
+    if ((long)b0 * b1 > kTileCap) {
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+            if (sid[q] >= 0) {
+                int *w = &wz[py[q] * W + px[q]];
+                if (__builtin_nontemporal_load(w) < sid[q]) atomicMax(w, sid[q]);
+            }
+        return;
+    }
+    const int nt = b0 * b1;
+    for (int e = tid; e < nt; e += kBlock) tile[e] = -1;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q)
+        if (sid[q] >= 0) atomicMax(&tile[(py[q] - l1) * b0 + (px[q] - l0)], sid[q]);
+    __syncthreads();
+    const float rb0 = __frcp_rn((float)b0);
+    for (int e = tid; e < nt; e += kBlock) {
+        int v = tile[e];
+        if (v >= 0) {
+            int y = __float2int_rz(((float)e + 0.5f) * rb0), x = e - y * b0;
+            int *w = &wz[(l1 + y) * W + (l0 + x)];
+            if (__builtin_nontemporal_load(w) < v) atomicMax(w, v);
+        }
+    }
+}
+
+// backward only needs WHERE samples landed (the weight plane): plain stores of 1, no atomics
+__global__ __launch_bounds__(kBlock) void splat_mark_kernel(const float *__restrict__ c0, const float *__restrict__ c1,
+                                                            long n, int H, int W, float *__restrict__ planes)
+{
+    const long pz = blockIdx.y, hw = (long)H * W;
+    for (long s = (long)blockIdx.x * kBlock + threadIdx.x; s < n; s += (long)gridDim.x * kBlock)
+        planes[(pz * 2 + 1) * hw + splat_pixel(c0[pz * n + s], c1[pz * n + s], H, W)] = 1.f;
+}
+
+// planes (P,2,H,W): [0] = image, [1] = weight
+__global__ __launch_bounds__(kBlock) void splat_compose_kernel(const int *__restrict__ winner, const float *__restrict__ val,
+                                                               long n, long hw, float *__restrict__ planes)
+{
+    const long pz = blockIdx.y;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < hw; i += (long)gridDim.x * kBlock) {
+        int wn = winner[pz * hw + i];
+        planes[(pz * 2 + 0) * hw + i] = wn >= 0 ? (val ? val[pz * n + wn] : 0.f) : 0.f;
+        planes[(pz * 2 + 1) * hw + i] = wn >= 0 ? 1.f : 0.f;
+    }
+}
+
+// Separable zero-padded Gaussian blur of `nch` planes of H x W (in -> out), one 32x32 tile per block.
+__global__ __launch_bounds__(kBlock) void blur2d_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W,
+                                                        int half, float sigma)
+{
+    __shared__ float kw[2 * kSplatMaxHalf + 1];
+    __shared__ float src[kSplatTile + 2 * kSplatMaxHalf][kSplatTile + 2 * kSplatMaxHalf + 1];
+    __shared__ float mid[kSplatTile + 2 * kSplatMaxHalf][kSplatTile + 1];
+    const int size = 2 * half + 1, ext = kSplatTile + 2 * half;
+    const long plane = (long)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * kSplatTile, y0 = blockIdx.y * kSplatTile;
+    if ((int)threadIdx.x < size) { // exp(-0.5 (c/sigma)^2) / sum, reference :726-728
+        float c = (float)((int)threadIdx.x - half) / sigma;
+        kw[threadIdx.x] = expf(-0.5f * c * c);
+    }
+    __syncthreads();
+    float ksum = 0.f;
+    for (int i = 0; i < size; ++i) ksum += kw[i];
+    __syncthreads();
+    if ((int)threadIdx.x < size) kw[threadIdx.x] = kw[threadIdx.x] / ksum;
+    for (int e = threadIdx.x; e < ext * ext; e += kBlock) {
+        int r = e / ext, c = e - r * ext;
+        int y = y0 + r - half, x = x0 + c - half;
+        src[r][c] = (y >= 0 && y < H && x >= 0 && x < W) ? in[plane + (long)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ext * kSplatTile; e += kBlock) { // along x
+        int r = e / kSplatTile, c = e - r * kSplatTile;
+        float a = 0.f;
+        for (int t = 0; t < size; ++t) a = __builtin_fmaf(kw[t], src[r][c + t], a);
+        mid[r][c] = a;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kSplatTile * kSplatTile; e += kBlock) { // along y
+        int r = e / kSplatTile, c = e - r * kSplatTile;
+        int y = y0 + r, x = x0 + c;
+        if (y < H && x < W) {
+            float a = 0.f;
+            for (int t = 0; t < size; ++t) a = __builtin_fmaf(kw[t], mid[r + t][c], a);
+            out[plane + (long)y * W + x] = a;
+        }
+    }
+}
+
+// forward: out[p, x, y] = bimg[y, x] / (bw[y, x] + 1e-8)          (the .T of reference :737)
+// backward: q[p, y, x]  = gout[p, x, y] / (bw[y, x] + 1e-8)
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void splat_divide_kernel(const float *__restrict__ blurred, const float *__restrict__ gout,
+                                                              float *__restrict__ out, int H, int W)
+{
+    __shared__ float t[kSplatTile][kSplatTile + 1];
+    const long pz = blockIdx.z, hw = (long)H * W;
+    const int x0 = blockIdx.x * kSplatTile, y0 = blockIdx.y * kSplatTile;
+    const float *bimg = blurred + (pz * 2 + 0) * hw, *bw = blurred + (pz * 2 + 1) * hw;
+    if (!BWD) {
+        for (int e = threadIdx.x; e < kSplatTile * kSplatTile; e += kBlock) {
+            int r = e / kSplatTile, c = e - r * kSplatTile, y = y0 + r, x = x0 + c;
+            t[r][c] = (y < H && x < W) ? bimg[(long)y * W + x] / (bw[(long)y * W + x] + 1e-8f) : 0.f;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kSplatTile * kSplatTile; e += kBlock) {
+            int c = e / kSplatTile, r = e - c * kSplatTile, y = y0 + r, x = x0 + c;
+            if (y < H && x < W) out[pz * hw + (long)x * H + y] = t[r][c];
+        }
+    } else {
+        for (int e = threadIdx.x; e < kSplatTile * kSplatTile; e += kBlock) {
+            int c = e / kSplatTile, r = e - c * kSplatTile, y = y0 + r, x = x0 + c;
+            t[r][c] = (y < H && x < W) ? gout[pz * hw + (long)x * H + y] : 0.f;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kSplatTile * kSplatTile; e += kBlock) {
+            int r = e / kSplatTile, c = e - r * kSplatTile, y = y0 + r, x = x0 + c;
+            if (y < H && x < W) out[pz * hw + (long)y * W + x] = t[r][c] / (bw[(long)y * W + x] + 1e-8f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void splat_gather_kernel(const float *__restrict__ c0, const float *__restrict__ c1,
+                                                              long n, int H, int W, const float *__restrict__ gimg,
+                                                              float *__restrict__ gval)
+{
+    const long pz = blockIdx.y;
+    for (long s = (long)blockIdx.x * kBlock + threadIdx.x; s < n; s += (long)gridDim.x * kBlock)
+        gval[pz * n + s] = gimg[pz * H * W + splat_pixel(c0[pz * n + s], c1[pz * n + s], H, W)];
+}
+
+// ----------------------------------------------------------------------------
+// Energy loss used by the benchmarks and examples: loss[p] = sum(frame[p]^2), gframe = 2 * frame,
+// in one streaming pass.  kLossSplit blocks per pose write partial sums, a second tiny kernel adds
+// them in a fixed order (deterministic; one block per pose alone used only P of the 256 CUs).
+constexpr int kLossSplit = 16;
+__global__ __launch_bounds__(kBlock) void loss_sumsq_kernel(const float *__restrict__ frame, float *__restrict__ part,
+                                                            float *__restrict__ gframe, long n)
+{
+    __shared__ float sm[kWavesPerBlock];
+    const long pz = blockIdx.y;
+    const float *f = frame + pz * n;
+    float *g = gframe ? gframe + pz * n : nullptr;
+    float acc = 0.f;
+    const bool vec = ((n & 3) == 0) && ((((uintptr_t)f) & 15) == 0) && (!g || (((uintptr_t)g) & 15) == 0);
+    if (vec) {
+        const float4 *f4 = reinterpret_cast<const float4 *>(f);
+        float4 *g4 = reinterpret_cast<float4 *>(g);
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n / 4; i += (long)kLossSplit * kBlock) {
+            float4 v = f4[i];
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (g) g4[i] = make_float4(2.f * v.x, 2.f * v.y, 2.f * v.z, 2.f * v.w);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)kLossSplit * kBlock) {
+            float v = f[i];
+            acc += v * v;
+            if (g) g[i] = 2.f * v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[pz * kLossSplit + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ void loss_finish_kernel(const float *__restrict__ part, float *__restrict__ loss, int P)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float t = 0.f;
+    for (int i = 0; i < kLossSplit; ++i) t += part[p * kLossSplit + i];
+    loss[p] = t;
+}
+
+} // namespace
+
+extern "C" {
+
+static int splat_half(float sigma) { return ((int)(6.f * sigma) | 1) / 2; } // size = int(6 sigma) | 1, reference :725
+
+size_t diffus_splat_workspace_bytes(int P, int H, int W)
+{
+    if (P <= 0 || H <= 0 || W <= 0) return 0;
+    return align256(sizeof(int) * (size_t)P * H * W) + 2 * align256(sizeof(float) * (size_t)P * 2 * H * W);
+}
+
+int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, long n, int cols, int H, int W,
+                     float sigma, float *out, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    if (!c0 || !c1 || !val || !out || P <= 0 || n <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f)) return DIFFUS_EINVAL;
+    if (cols < 0 || (cols > 0 && n % cols != 0)) return DIFFUS_EINVAL;
+    if (n > 0x7fffffffL || (long)H * W > 0x3fffffffL) return DIFFUS_EUNSUPPORTED;
+    const int half = splat_half(sigma);
+    if (half > kSplatMaxHalf) return DIFFUS_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < diffus_splat_workspace_bytes(P, H, W)) return DIFFUS_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long hw = (long)H * W;
+    int *winner = (int *)workspace;
+    float *planes = (float *)((char *)workspace + align256(sizeof(int) * (size_t)P * hw));
+    float *blurred = (float *)((char *)planes + align256(sizeof(float) * (size_t)P * 2 * hw));
+    if (hipMemsetAsync(winner, 0xff, sizeof(int) * (size_t)P * hw, st) != hipSuccess) return DIFFUS_ELAUNCH;
+    if (cols >= kPatchSteps / 2 && n / cols >= 2) { // a (rows, cols) grid of samples: privatised patches
+        const int rows = (int)(n / cols);
+        const int rgs = (rows + kPatchRays - 1) / kPatchRays, cgs = (cols + kPatchSteps - 1) / kPatchSteps;
+        hipLaunchKernelGGL(splat_winner_patch_kernel, dim3((unsigned)(rgs * cgs), P), dim3(kBlock), 0, st, c0, c1, rows,
+                           cols, H, W, winner, rgs, cgs);
+    } else {
+        unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(splat_winner_kernel, dim3(nb, P), dim3(kBlock), 0, st, c0, c1, n, H, W, winner);
+    }
+    unsigned pb = (unsigned)((hw + kBlock - 1) / kBlock); if (pb > 4096) pb = 4096;
+    hipLaunchKernelGGL(splat_compose_kernel, dim3(pb, P), dim3(kBlock), 0, st, winner, val, n, hw, planes);
+    dim3 tiles((W + kSplatTile - 1) / kSplatTile, (H + kSplatTile - 1) / kSplatTile, P * 2);
+    hipLaunchKernelGGL(blur2d_kernel, tiles, dim3(kBlock), 0, st, planes, blurred, H, W, half, sigma);
+    tiles.z = P;
+    hipLaunchKernelGGL(splat_divide_kernel<false>, tiles, dim3(kBlock), 0, st, blurred, nullptr, out, H, W);
+    return last_launch();
+}
+
+int diffus_splat_bwd(const float *c0, const float *c1, int P, long n, int H, int W, float sigma, const float *gout,
+                     float *gval, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    if (!c0 || !c1 || !gout || !gval || P <= 0 || n <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f)) return DIFFUS_EINVAL;
+    if (n > 0x7fffffffL || (long)H * W > 0x3fffffffL) return DIFFUS_EUNSUPPORTED;
+    const int half = splat_half(sigma);
+    if (half > kSplatMaxHalf) return DIFFUS_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < diffus_splat_workspace_bytes(P, H, W)) return DIFFUS_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long hw = (long)H * W;
+    int *winner = (int *)workspace;
+    float *planes = (float *)((char *)workspace + align256(sizeof(int) * (size_t)P * hw));
+    float *blurred = (float *)((char *)planes + align256(sizeof(float) * (size_t)P * 2 * hw));
+    // recompute the weight plane and its blur (nothing was saved by the forward)
+    (void)winner;
+    if (hipMemsetAsync(planes, 0, sizeof(float) * (size_t)P * 2 * hw, st) != hipSuccess) return DIFFUS_ELAUNCH;
+    unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(splat_mark_kernel, dim3(nb, P), dim3(kBlock), 0, st, c0, c1, n, H, W, planes);
+    dim3 tiles((W + kSplatTile - 1) / kSplatTile, (H + kSplatTile - 1) / kSplatTile, P * 2);
+    hipLaunchKernelGGL(blur2d_kernel, tiles, dim3(kBlock), 0, st, planes, blurred, H, W, half, sigma);
+    // q = gout^T / (bw + eps) into planes[:, 0]; blur it into blurred[:, 0]; gather per sample
+    tiles.z = P;
+    hipLaunchKernelGGL(splat_divide_kernel<true>, tiles, dim3(kBlock), 0, st, blurred, gout, planes, H, W);
+    // planes is now (P,1,H,W) q; blur plane-wise into `blurred` viewed as (P,H,W)
+    hipLaunchKernelGGL(blur2d_kernel, tiles, dim3(kBlock), 0, st, planes, blurred, H, W, half, sigma);
+    hipLaunchKernelGGL(splat_gather_kernel, dim3(nb, P), dim3(kBlock), 0, st, c0, c1, n, H, W, blurred, gval);
+    return last_launch();
+}
+
+int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe, void *workspace,
+                      size_t workspace_bytes, diffus_stream_t stream)
+{
+    if (!frame || !loss || P <= 0 || n <= 0) return DIFFUS_EINVAL;
+    if (!workspace || workspace_bytes < sizeof(float) * (size_t)P * kLossSplit) return DIFFUS_EWORKSPACE;
+    float *part = (float *)workspace;
+    hipLaunchKernelGGL(loss_sumsq_kernel, dim3(kLossSplit, P), dim3(kBlock), 0, (hipStream_t)stream, frame, part, gframe, n);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, loss, P);
+    return last_launch();
+}
+
+} // extern "C"

@@ -10,7 +10,7 @@ from diffus_amd.phantom import phantom, pose_ring
 lib = _lib.load()
 vol = torch.from_numpy(phantom(256)).cuda()
 src, dirs = pose_ring(256, 32, 256)
-hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), 512, 1e-4, "trilinear")
+hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), 512, 1e-4, "trilinear", sparse=False)
 hp.fwd(); hp.loss_and_grad(); hp.zero_grad(); hp.bwd(_lib.BWD_SCAN)
 nblk = 32 * 16 * 8
 st = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
@@ -35,3 +35,6 @@ if len(nd):
     print("not-done blocks that reached bbox:", e.sum())
 span = s[:, :6][s[:, :6] > 0]
 print("kernel span (cycles, min start..max end): %.0f" % (span.max() - span.min()))
+te = s[done][:, 6]
+for c in (1024, 2048, 3072, 4096, 6144, 8192, 12288):
+    print("tile entries <= %5d: %5.1f %%" % (c, 100.0 * (te <= c).mean()))
