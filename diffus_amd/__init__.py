@@ -7,11 +7,12 @@ from ._lib import DiffusError, LIB_PATH  # noqa: F401
 from .cone import (FanPose, compute_us_apex_and_direction, cone_us_to_mri_world, fan_directions_torch,  # noqa: F401
                    generate_cone_directions, voxel_to_world, world_to_voxel)
 from .renderer import (BrickedVolume, UltrasoundRenderer, brick_volume, compute_echo_traces,  # noqa: F401
+                       compute_gaussian_pulse, gaussian_pulse,
                        pair_volume, render_poses, resolve_start, trace_rays, unbrick_volume)
 
 from .splat import differentiable_splat, rotate_around_apex, splat_frames  # noqa: F401,E402
 
-__all__ = ["FanPose", "compute_us_apex_and_direction", "cone_us_to_mri_world", "voxel_to_world", "world_to_voxel",
+__all__ = ["compute_gaussian_pulse", "gaussian_pulse", "FanPose", "compute_us_apex_and_direction", "cone_us_to_mri_world", "voxel_to_world", "world_to_voxel",
            "differentiable_splat", "rotate_around_apex", "splat_frames", "UltrasoundRenderer", "compute_echo_traces", "render_poses", "trace_rays", "resolve_start",
            "generate_cone_directions", "fan_directions_torch", "DiffusError", "BrickedVolume", "brick_volume",
            "unbrick_volume", "pair_volume"]

@@ -366,6 +366,26 @@ def compute_echo_traces(refLR: torch.Tensor, spacing: float = 1.0, c: float = 1.
     return echo.to(device=refLR.device, dtype=refLR.dtype if refLR.is_floating_point() else torch.float32), delays_us
 
 
+def gaussian_pulse(length: int, sigma: float):
+    """1-D Gaussian pulse, peak 1 (reference src/renderer.py:481-496; NumPy, host side)."""
+    import numpy as np
+    t = np.linspace(-length // 2, length // 2, length)
+    pulse = np.exp(-0.5 * (t / sigma) ** 2)
+    return pulse / pulse.max()
+
+
+def compute_gaussian_pulse(refLR: torch.Tensor, spacing: float = 1.0, c: float = 1.54e3, length: int = 10,
+                           sigma: int = 1, pulse=None) -> torch.Tensor:
+    """Echo traces convolved with a Gaussian pulse (reference src/renderer.py:459-479): the echo
+    series comes from the HIP kernel (diffus_echo_traces), the short conv1d stays in torch."""
+    echo_signals, _ = compute_echo_traces(refLR, spacing, c)
+    if pulse is None:
+        pulse = gaussian_pulse(length=length, sigma=sigma)
+        pulse = torch.tensor(pulse, dtype=echo_signals.dtype, device=echo_signals.device).unsqueeze(0).unsqueeze(0)
+    echo_signals = torch.nn.functional.conv1d(echo_signals.unsqueeze(1), pulse, padding=length // 2)
+    return echo_signals.squeeze(1)
+
+
 class UltrasoundRenderer:
     def __init__(self, num_samples: int, attenuation_coeff: float = 0.5):
         """

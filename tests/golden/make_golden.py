@@ -303,6 +303,17 @@ def main():
         out["nl"] = np.int64(len(lines)); out["na"] = np.int64(3)
         save("g12_pose_helpers", **out)
 
+    # ---- G13: compute_gaussian_pulse / gaussian_pulse (`[DEMO] Modeling Choices` cells 8-12) -----
+    if want("g13"):
+        g4 = np.load(os.path.join(HERE, "g4_random_series.npz"))
+        r = torch.from_numpy(g4["r"][:, :120].copy())
+        out = {"r": r.numpy()}
+        for j, (length, sigma) in enumerate([(10, 1), (20, 4), (7, 2)]):
+            out[f"p{j}"] = np.array([length, sigma])
+            out[f"pulse{j}"] = ref.gaussian_pulse(length, sigma)
+            out[f"out{j}"] = ref.compute_gaussian_pulse(r, length=length, sigma=sigma).numpy()
+        save("g13_gaussian_pulse", **out)
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

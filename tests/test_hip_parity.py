@@ -448,3 +448,47 @@ def test_pose_registration_by_gradient_descent(da):
         losses.append(loss.item())
     assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
     assert torch.linalg.norm(pose.apex.detach() - true.apex.detach()) < 0.6
+
+
+def test_gaussian_pulse_golden(da):
+    g = load_golden("g13_gaussian_pulse")
+    r = cuda(g["r"])
+    for j in range(3):
+        length, sigma = (int(v) for v in g[f"p{j}"])
+        np.testing.assert_array_equal(da.gaussian_pulse(length, sigma), g[f"pulse{j}"])
+        out = da.compute_gaussian_pulse(r, length=length, sigma=sigma)
+        assert out.shape == g[f"out{j}"].shape
+        assert maxnorm_rel(out.cpu().numpy(), g[f"out{j}"]) < 1e-4
+
+
+def test_train_impedance_mlp_through_the_renderer(da):
+    # miniature of `[DEMO] Train MRI to Impedance MLP - GPU` cell 16: a 1->32->32->1 MLP maps MRI intensity to
+    # impedance, frames are rendered through it, and the loss gradient flows HIP backward -> torch autograd -> MLP
+    torch.manual_seed(0)
+    n, R, S = 32, 24, 48
+    mri = torch.from_numpy((phantom(n) / 6.4e6).astype(np.float32)).cuda()
+    src, dirs = pose_ring(n, 4, R)
+    src, dirs = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+
+    def make():
+        return torch.nn.Sequential(torch.nn.Linear(1, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                                   torch.nn.Linear(32, 1)).cuda()
+
+    def frames(model):
+        Z = (model(mri.reshape(-1, 1)).reshape(n, n, n) + 1.5) * 1e6       # impedance volume
+        return da.render_poses(Z, src, dirs, S, 1e-3, sampler="trilinear")
+
+    teacher = make()
+    with torch.no_grad():
+        target = frames(teacher)
+    student = make()
+    opt = torch.optim.Adam(student.parameters(), lr=3e-3)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = ((frames(student) - target) ** 2).mean()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in student.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
