@@ -10,9 +10,10 @@ from .renderer import (BrickedVolume, UltrasoundRenderer, brick_volume, compute_
                        compute_gaussian_pulse, gaussian_pulse,
                        pair_volume, render_poses, resolve_start, trace_rays, unbrick_volume)
 
+from .artifacts import apply_artifacts  # noqa: F401,E402
 from .splat import differentiable_splat, rotate_around_apex, splat_frames  # noqa: F401,E402
 
-__all__ = ["compute_gaussian_pulse", "gaussian_pulse", "FanPose", "compute_us_apex_and_direction", "cone_us_to_mri_world", "voxel_to_world", "world_to_voxel",
+__all__ = ["apply_artifacts", "compute_gaussian_pulse", "gaussian_pulse", "FanPose", "compute_us_apex_and_direction", "cone_us_to_mri_world", "voxel_to_world", "world_to_voxel",
            "differentiable_splat", "rotate_around_apex", "splat_frames", "UltrasoundRenderer", "compute_echo_traces", "render_poses", "trace_rays", "resolve_start",
            "generate_cone_directions", "fan_directions_torch", "DiffusError", "BrickedVolume", "brick_volume",
            "unbrick_volume", "pair_volume"]

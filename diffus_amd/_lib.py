@@ -15,7 +15,8 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
            "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume", "diffus_paired_floats",
            "diffus_pair_volume", "diffus_brick_count", "diffus_gradbuf_flush",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces",
-           "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd")
+           "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd",
+           "diffus_artifacts_workspace_bytes", "diffus_artifacts")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
@@ -77,6 +78,11 @@ def load():
     lib.diffus_splat_fwd.argtypes = [vp, vp, vp, i, C.c_long, i, i, i, f, vp, vp, sz, vp]
     lib.diffus_splat_bwd.restype = i
     lib.diffus_splat_bwd.argtypes = [vp, vp, i, C.c_long, i, i, f, vp, vp, vp, sz, vp]
+    d = C.c_double
+    lib.diffus_artifacts_workspace_bytes.restype = sz
+    lib.diffus_artifacts_workspace_bytes.argtypes = [i, i, i]
+    lib.diffus_artifacts.restype = i
+    lib.diffus_artifacts.argtypes = [vp, i, i, i, d, d, d, d, vp, vp, C.c_uint64, vp, vp, sz, vp]
     if lib.diffus_abi_version() != 1:
         raise DiffusError("libdiffus_hip.so ABI version mismatch")
     _lib = lib

@@ -10,7 +10,9 @@ fallback: without the built library every entry point raises DiffusError.
 
 Differences from the reference, all deliberate:
   * no prints, no matplotlib figure per call (reference :122,179,245,252,:762-801);
-  * `artifacts=True` (NumPy/SciPy speckle chain, :264-273) is out of scope -> NotImplementedError;
+  * `artifacts=True` (speckle arcs, lateral blur, unsharp mask, :264-273) runs on the GPU
+    (diffus_artifacts) and, like the reference, returns float64; keyword-only `seed=` makes the
+    speckle reproducible (the reference uses the unseeded global NumPy RNG);
   * extra keyword-only arguments `sampler=` ("nearest" = reference semantics,
     "trilinear" = differentiable in the pose) and `return_indices=`;
   * gradients work: d frame / d volume for both samplers, d / d source and
@@ -426,7 +428,7 @@ class UltrasoundRenderer:
                         angle: float = 45.0, plot: bool = True, artifacts: bool = False, ax=None, cmap=None,
                         std_radial: float = 0.01, std_local: float = 0.15, max_sigma: float = 4.0,
                         alpha: float = 5, start: float = 0, *, sampler: str = "nearest",
-                        return_indices: bool = True, layout: str = "auto", **kwargs):
+                        return_indices: bool = True, layout: str = "auto", seed=None, **kwargs):
         """Simulate the fan frame of one pose (reference src/renderer.py:201-275).
 
         volume (d0,d1,d2) impedance; source (3,); directions (n_rays,3) unit vectors.
@@ -435,16 +437,17 @@ class UltrasoundRenderer:
         index planes (None when return_indices=False) and the float32 frame, on
         volume.device.
         """
-        if artifacts:
-            raise NotImplementedError("artifacts=True (speckle/lateral blur/sharpen, reference :264-273) is "
-                                      "outside the accelerated path; see DESIGN.md §Out of scope")
         if torch.as_tensor(source).numel() != 3:
             raise ValueError("source must have 3 components")
         res = render_poses(volume, source, directions, self.num_samples, self.attenuation_coeff, start=start,
                            sampler=sampler, return_indices=return_indices, layout=layout)
         dev = volume.device
+        frame = (res[0] if return_indices else res)[0]
+        if artifacts:       # reference :264-273: speckle -> lateral blur -> sharpen (float64 result)
+            from .artifacts import apply_artifacts
+            frame = apply_artifacts(frame, std_radial=std_radial, std_local=std_local, max_sigma=max_sigma,
+                                    alpha=alpha, seed=seed)
         if return_indices:
-            frame, idx = res
-            idx = idx[:, 0].to(dev)
-            return idx[0], idx[1], idx[2], frame[0].to(dev)
-        return None, None, None, res[0].to(dev)
+            idx = res[1][:, 0].to(dev)
+            return idx[0], idx[1], idx[2], frame.to(dev)
+        return None, None, None, frame.to(dev)

@@ -223,6 +223,22 @@ int diffus_splat_bwd(const float *c0, const float *c1, int P, long n,
                      void *workspace, size_t workspace_bytes, diffus_stream_t stream);
 
 /*
+ * B-mode artifact chain: replaces, for P frames (P,R,N) at once, the
+ * artifacts=True branch of plot_beam_frame (reference src/renderer.py:264-273) =
+ * add_speckle_arcs_np (:545-583) -> add_depth_dependent_lateral_blur_np (:585-601) ->
+ * sharpen_np (:535-543), all in float64 like the NumPy/SciPy original.
+ *   radial_noise (P,N), local_noise (P,R,N): nullable float64 multiplicative factors.  When
+ *   NULL they are drawn as N(1, std*(1+depth^p)) from Philox4x32-10 keyed by `seed` (the
+ *   reference uses the unseeded NumPy global RNG and is not reproducible).
+ *   out (P,R,N) float64.
+ */
+size_t diffus_artifacts_workspace_bytes(int P, int R, int N);
+int diffus_artifacts(const float *frame, int P, int R, int N,
+                     double std_radial, double std_local, double max_sigma, double alpha,
+                     const double *radial_noise, const double *local_noise, uint64_t seed,
+                     double *out, void *workspace, size_t workspace_bytes, diffus_stream_t stream);
+
+/*
  * Utility, not a reference function: the energy loss the benchmarks and examples
  * optimise.  loss[p] = sum(frame[p,:]^2) over the n floats of pose p, and (if
  * gframe != NULL) gframe = d loss / d frame = 2 * frame, in one streaming pass.

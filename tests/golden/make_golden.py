@@ -314,6 +314,41 @@ def main():
             out[f"out{j}"] = ref.compute_gaussian_pulse(r, length=length, sigma=sigma).numpy()
         save("g13_gaussian_pulse", **out)
 
+    # ---- G14: artifact chain of plot_beam_frame(artifacts=True) with a SEEDED NumPy RNG ----------
+    if want("g14"):
+        out = {}
+        v = torch.from_numpy(phantom(64))
+        s, d = pose_ring(64, 4, 24)
+        cases = [("a", 0, 60, 0, 0.01, 0.15, 4.0, 5.0), ("b", 1, 64, 6, 0.1, 0.02, 2.0, 1.5), ("c", 2, 40, 0, 0.05, 0.05, 0.5, 3.0)]
+        for tag, p, S, start, std_r, std_l, max_sigma, alpha in cases:
+            x, y, z, f = ref_frame(v, torch.from_numpy(s[p]), torch.from_numpy(d[p]), S, 1e-3, start)
+            f = torch.from_numpy(f)
+            R, N = f.shape
+            np.random.seed(1000 + p)
+            a1 = ref.add_speckle_arcs_np(f.clone(), std_radial=std_r, std_local=std_l)
+            a2 = ref.add_depth_dependent_lateral_blur_np(a1.clone(), max_sigma=max_sigma)
+            a3 = ref.sharpen_np(a2.clone(), alpha=alpha)
+            np.random.seed(1000 + p)          # the same draws, in the same order (:567-574)
+            depth = np.linspace(0.0, 1.0, N)
+            radial = np.random.normal(loc=1.0, scale=std_r * (1.0 + depth ** 2.0), size=N)
+            local = np.random.normal(loc=1.0, scale=(std_l * (1.0 + depth ** 1.5))[None, :], size=(R, N))
+            # and the whole thing through plot_beam_frame itself
+            np.random.seed(1000 + p)
+            rr = ref.UltrasoundRenderer(num_samples=S, attenuation_coeff=1e-3)
+            with quiet():
+                _, _, _, full = rr.plot_beam_frame(volume=v, source=torch.from_numpy(s[p]), directions=torch.from_numpy(d[p]),
+                                                   plot=False, artifacts=True, std_radial=std_r, std_local=std_l,
+                                                   max_sigma=max_sigma, alpha=alpha, start=start)
+            import matplotlib.pyplot as plt
+            plt.close("all")
+            out[f"{tag}_pose"] = np.int64(p); out[f"{tag}_S"] = np.int64(S); out[f"{tag}_start"] = np.int64(start)
+            out[f"{tag}_params"] = np.array([std_r, std_l, max_sigma, alpha])
+            out[f"{tag}_frame"] = f.numpy(); out[f"{tag}_radial"] = radial; out[f"{tag}_local"] = local
+            out[f"{tag}_speckle"] = np.asarray(a1); out[f"{tag}_blur"] = np.asarray(a2); out[f"{tag}_sharp"] = np.asarray(a3)
+            out[f"{tag}_full"] = np.asarray(full); out[f"{tag}_full_dtype"] = np.array(str(full.dtype))
+        out["tags"] = np.array([c[0] for c in cases])
+        save("g14_artifacts", **out)
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

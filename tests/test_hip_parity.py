@@ -201,9 +201,6 @@ def test_too_many_samples_fails_loudly(da, vols):
         da.render_poses(cuda(vols[64]), torch.from_numpy(src), torch.from_numpy(dirs), 1025, 1e-3)
     with pytest.raises(IndexError):
         da.render_poses(cuda(vols[64]), torch.from_numpy(src), torch.from_numpy(dirs), 48, 1e-3, start=47)
-    with pytest.raises(NotImplementedError):
-        da.UltrasoundRenderer(48).plot_beam_frame(cuda(vols[64]), torch.from_numpy(src[0]), torch.from_numpy(dirs[0]),
-                                                  artifacts=True)
 
 
 def test_zero_impedance_and_degenerate_volume(da, oracle):
