@@ -77,12 +77,14 @@ tcc, atom = pmc("TCC_HIT_sum_TCC_MISS_sum"), pmc("TCC_EA0_ATOMIC_sum")
 summary = {"tag": tag, "workload_ray_steps": 32 * 256 * 512, "sampler": "trilinear",
            "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  [FETCH_SIZE x2 on gfx950]",
            "calibration": {}, "kernels": {}}
-if "brick_convert_kernel" in fetch:
+if "pair_convert_kernel" in fetch:
+    summary["calibration"] = {"kernel": "pair_convert_kernel (reads 64 MiB, writes 128 MiB)", "FETCH_SIZE_KiB": fetch["pair_convert_kernel"].get("FETCH_SIZE"), "WRITE_SIZE_KiB": write.get("pair_convert_kernel", {}).get("WRITE_SIZE"), "expected_KiB": [65536, 131072]}
+elif "brick_convert_kernel" in fetch:
     summary["calibration"] = {"kernel": "brick_convert_kernel (reads 64 MiB, writes 64 MiB)",
                               "FETCH_SIZE_KiB": fetch["brick_convert_kernel"].get("FETCH_SIZE"),
                               "WRITE_SIZE_KiB": write.get("brick_convert_kernel", {}).get("WRITE_SIZE"),
                               "expected_KiB": 65536}
-for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "brick_convert_kernel", "loss_sumsq_kernel"):
+for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "gradbuf_flush_kernel", "pair_convert_kernel", "brick_convert_kernel", "loss_sumsq_kernel"):
     if k not in fetch:
         continue
     f, w = fetch[k].get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
