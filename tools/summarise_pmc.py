@@ -76,7 +76,11 @@ fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
 tcc, atom = pmc("TCC_HIT_sum_TCC_MISS_sum"), pmc("TCC_EA0_ATOMIC_sum")
 summary = {"tag": tag, "workload_ray_steps": 32 * 256 * 512, "sampler": "trilinear",
            "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  [FETCH_SIZE x2 on gfx950]",
-           "calibration": {}, "kernels": {}}
+           "calibration": {}, "kernels": {},
+           "note": ("FETCH_SIZE counts 64 B per fabric read request: exactly 1/2 of the bytes for wide coalesced streams "
+                    "(brick_convert_kernel, 256-B rows: 32 781 KiB reported for a 65 536 KiB read), but 0.94 of them for "
+                    "pair_convert_kernel's 132-B rows.  The x2 prescribed for gfx950 is therefore an UPPER bound of the "
+                    "read traffic of the gather kernels; hbm_bytes_per_launch uses it.")}
 if "pair_convert_kernel" in fetch:
     summary["calibration"] = {"kernel": "pair_convert_kernel (reads 64 MiB, writes 128 MiB)", "FETCH_SIZE_KiB": fetch["pair_convert_kernel"].get("FETCH_SIZE"), "WRITE_SIZE_KiB": write.get("pair_convert_kernel", {}).get("WRITE_SIZE"), "expected_KiB": [65536, 131072]}
 elif "brick_convert_kernel" in fetch:
