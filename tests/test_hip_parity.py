@@ -489,3 +489,17 @@ def test_train_impedance_mlp_through_the_renderer(da):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+def test_demo_notebook_call_sequence(da):
+    # `[DEMO] REUBEN DATA 46` cells 11-14 with the import swapped (examples/reuben_like_demo.py)
+    import importlib.util
+    import os as _os
+    spec = importlib.util.spec_from_file_location(
+        "reuben_like_demo", _os.path.join(_os.path.dirname(_os.path.dirname(__file__)), "examples", "reuben_like_demo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    x, y, z, I, img = mod.run(n=128, n_rays=64, d1=30, d2=120, seed=1)
+    assert I.shape == (64, 120 - 18) and I.dtype == torch.float64 and x.dtype == torch.int64
+    assert img.shape == (128, 128) and img.dtype == torch.float32
+    assert torch.isfinite(img).all() and float(img.abs().max()) > 0
