@@ -22,7 +22,8 @@ DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
 BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
-MAX_SAMPLES = 1024
+MAX_SAMPLES = 1024          # cropped samples per launch; longer rays run as chained segments
+MAX_SEGMENTS = 64
 
 _lib = None
 

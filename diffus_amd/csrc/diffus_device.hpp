@@ -378,6 +378,18 @@ struct Args {
     const void *dirs;
     int src_f64, dir_f64;
     int P, R, S, start, N1;
+    // Rays longer than 64*16 samples are processed in SEGMENTS of at most 1024 cropped samples, one
+    // launch per segment, chained through per-ray carries in the workspace: [seg0, seg0+segN) is the
+    // segment of this launch (seg0 = 0, segN = N1 when the ray fits one launch).
+    int seg0, segN;
+    const float *cin;  // nullable (P*R,5): running product P (normalised) + impedance of sample seg0-1
+    float *cout;       // nullable (P*R,5): the same after this segment's last sample
+    const float *cnext; // backward, nullable (P*R,5): carry-in of the NEXT segment (= cout of the carry-only pass)
+    const float *uin;  // backward, nullable (P*R,4): adjoint carry U' entering from the next segment
+    float *uout;       // backward, nullable (P*R,4): adjoint carry leaving towards the previous segment
+    const float *zcin; // backward, nullable (P*R): d L/d imp contribution to this segment's LAST sample
+    float *zcout;      // backward, nullable (P*R): contribution of this segment's first r to sample seg0-1
+    int accum_pose;    // backward: add to (instead of overwrite) the per-ray pose-gradient partials
     float neg_alpha;
     // forward
     float *frame;
@@ -520,7 +532,7 @@ __device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a
 // behind exec-mask branches) made hipcc emit `s_waitcnt vmcnt(0)` after almost every load:
 // ~50 dependent memory round trips per wave, 43 % of wave time in SQ_WAIT_ANY.
 template <int C, int SAMPLER, int LAYOUT, bool GRAD, int PM>
-__device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps, int lane, float (&z)[C],
+__device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int segN, const Pose &ps, int lane, float (&z)[C],
                                                    float (&g0)[C], float (&g1)[C], float (&g2)[C])
 {
     constexpr int G = (C < DIFFUS_GATHER_GROUP) ? C : DIFFUS_GATHER_GROUP;
@@ -534,8 +546,8 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps
         // ---- phase A: addresses + loads
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) {
-            int n = min((gb + jj) * kWave + lane, A.N1 - 1);
-            int k = A.start + n;
+            int n = min((gb + jj) * kWave + lane, segN - 1);
+            int k = A.start + seg0 + n;
             float p0 = ray_point<PM>(ps, 0, k), p1 = ray_point<PM>(ps, 1, k), p2 = ray_point<PM>(ps, 2, k);
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
                 int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
@@ -574,7 +586,7 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) {
             const int j = gb + jj;
-            const bool live = j * kWave + lane < A.N1;
+            const bool live = j * kWave + lane < segN;
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
                 z[j] = live ? raw[jj][0] : 1.f;
                 if (GRAD) g0[j] = g1[j] = g2[j] = 0.f;
@@ -609,16 +621,17 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, const Pose &ps
 // start > 0 the first kept coefficient is replaced by the per-pose median
 // (reference :243-244).
 template <int C>
-__device__ __forceinline__ void reflect_chunk(const Args &A, int n0, const float (&z)[C], float zprev, float medv,
+__device__ __forceinline__ void reflect_chunk(const Args &A, int seg0, int segN, int n0, const float (&z)[C], float zprev, float medv,
                                               float (&r)[C])
 {
+    // n0 = lane*C is the segment-local index of the lane's first sample; the global cropped index is seg0 + n0 + j
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
+        int nl = n0 + j, n = seg0 + nl;
         float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
         float v = reflect_fast(zp, z[j]);
         if (n == 1 && A.start > 0) v = medv;
-        r[j] = (n >= 1 && n < A.N1) ? v : 0.f;
+        r[j] = (n >= 1 && nl < segN) ? v : 0.f;
     }
 }
 
@@ -627,7 +640,8 @@ __device__ __forceinline__ void reflect_chunk(const Args &A, int n0, const float
 // coefficient entering sample n = lane*C + j (0 where there is none); e[j] gets
 // echo_n = (P_n)01/(P_n)11 with NaN -> 0 (reference :408).
 template <int C, bool FAST = false>
-__device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float (&e)[C])
+__device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float (&e)[C], const Mat *carry_in = nullptr,
+                                           int last = -1, Mat *carry_out = nullptr)
 {
     // local product of the chunk, then inclusive scan over lanes (lower lanes on the left)
     Mat L = mat_identity();
@@ -646,12 +660,17 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
     }
     Mat Pm = mat_shfl_up(L, 1);
     if (lane == 0) Pm = mat_identity();
+    if (carry_in) { // segment > 0: everything is preceded by the product of the earlier segments
+        Pm = mat_mul(*carry_in, Pm);
+        mat_renorm(Pm);
+    }
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         Pm = mat_step(Pm, r[j]);
         mat_renorm(Pm);
         float v = FAST ? fast_div(Pm.b, Pm.d) : __fdiv_rn(Pm.b, Pm.d);
         e[j] = (v == v) ? v : 0.f; // nan_to_num(nan=0)
+        if (carry_out && lane * C + j == last) *carry_out = Pm;
     }
 }
 

@@ -37,6 +37,10 @@ struct Workspace {
     float *gmed;
     float *gsrc_part;
     float *zbar;
+    float *carry;  // (nseg-1, P*R, 5) per-segment carry-in of long rays
+    float *ucarry; // (2, P*R, 4) adjoint carry, ping-pong
+    float *zcarry; // (2, P*R)
+    int nseg;      // launches per ray: ceil(N1 / DIFFUS_MAX_SAMPLES)
     size_t bytes;
 };
 
@@ -50,6 +54,13 @@ Workspace carve(void *base, int P, int R, int N1)
     ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
     ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
     ws.zbar = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * (N1 > 0 ? N1 : 0));
+    ws.nseg = N1 > 0 ? (N1 + DIFFUS_MAX_SAMPLES - 1) / DIFFUS_MAX_SAMPLES : 1;
+    ws.carry = ws.ucarry = ws.zcarry = nullptr;
+    if (ws.nseg > 1) {
+        ws.carry = (float *)(p + o);  o += align256(sizeof(float) * (size_t)P * R * 5 * (ws.nseg - 1));
+        ws.ucarry = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 4 * 2);
+        ws.zcarry = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 2);
+    }
     ws.bytes = o;
     return ws;
 }
@@ -77,7 +88,7 @@ int check_common(const float *vol, int d0, int d1, int d2, const void *src, int 
     if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24)) return DIFFUS_EUNSUPPORTED; // float(dim-1) must be exact
     if (bricked_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;    // 32-bit element offsets
     if (layout == DIFFUS_PAIRED && paired_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;
-    if (need_scan && S - start > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
+    if (need_scan && S - start > DIFFUS_MAX_SAMPLES * DIFFUS_MAX_SEGMENTS) return DIFFUS_EUNSUPPORTED;
     if (start > 0 && (size_t)R * sizeof(float) > 64 * 1024) return DIFFUS_EUNSUPPORTED; // median LDS
     return DIFFUS_OK;
 }
@@ -91,6 +102,7 @@ Args make_args(const float *vol, int d0, int d1, int d2, const void *src, int sr
     A.src = src; A.dirs = dirs;
     A.src_f64 = src_dtype == DIFFUS_F64; A.dir_f64 = dirs_dtype == DIFFUS_F64;
     A.P = P; A.R = R; A.S = S; A.start = start; A.N1 = S - start;
+    A.seg0 = 0; A.segN = A.N1; // one launch covers the ray unless the caller loops over segments
     A.neg_alpha = -alpha;
     A.med = ws.med; A.who = ws.who; A.gmed = ws.gmed;
     return A;
@@ -182,7 +194,8 @@ int launch_median(const Args &A, int sampler, int layout, hipStream_t st)
 
 } // namespace
 
-// defined in scatter.hip (the only cross-unit call): volume-gradient scatter of the backward
+// cross-unit calls: the volume-gradient scatter of the backward (scatter.hip) and the forward launch
 namespace diffus {
 int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st);
+int launch_fwd(const Args &A, int sampler, int layout, hipStream_t st); // render_fwd.hip
 }

@@ -16,9 +16,15 @@ namespace {
 #ifndef DIFFUS_BWD_MIN_WAVES
 #define DIFFUS_BWD_MIN_WAVES 1
 #endif
-template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM>
+// SEG = true: one 1024-sample segment of a longer ray (see diffus_render_bwd); only instantiated for C = 16.
+template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM, bool SEG = false>
 __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) void render_bwd_kernel(Args A)
 {
+    const int seg0 = SEG ? A.seg0 : 0, segN = SEG ? A.segN : A.N1;
+    const float *const cin = SEG ? A.cin : nullptr, *const cnext = SEG ? A.cnext : nullptr;
+    const float *const uin = SEG ? A.uin : nullptr, *const zcin = SEG ? A.zcin : nullptr;
+    float *const uout = SEG ? A.uout : nullptr, *const zcout = SEG ? A.zcout : nullptr;
+    const bool accum_pose = SEG && A.accum_pose;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 48 more registers
     const int wib = threadIdx.x >> 6;
@@ -33,21 +39,22 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
     float zi[C], gi0[C], gi1[C], gi2[C], z[C], r[C], gb[C];
-    gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD, PM>(A, ps, lane, zi, gi0, gi1, gi2);
+    gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD, PM>(A, seg0, segN, ps, lane, zi, gi0, gi1, gi2);
     to_chunked<C>(wb, lane, zi, z);
     {
         // upstream gradient row, read as 256-B runs, attenuation folded in
-        const float *gin = A.gframe + w * A.N1;
+        const float *gin = A.gframe + w * A.N1 + seg0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = j * kWave + lane;
-            zi[j] = (n < A.N1) ? gin[n] * fast_exp(__fmul_rn(A.neg_alpha, (float)n)) : 0.f;
+            zi[j] = (n < segN) ? gin[n] * fast_exp(__fmul_rn(A.neg_alpha, (float)(seg0 + n))) : 0.f;
         }
         to_chunked<C>(wb, lane, zi, gb);
     }
-    const float zprev = __shfl_up(z[C - 1], 1, kWave);
+    float zprev = __shfl_up(z[C - 1], 1, kWave);
+    if (cin && lane == 0) zprev = cin[w * 5 + 4]; // last sample of the previous segment
     const float medv = (A.start > 0) ? A.med[pose] : 0.f;
-    reflect_chunk<C>(A, n0, z, zprev, medv, r);
+    reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r);
 
     // ---- forward recompute with exponent tracking ----
     Mat L = mat_identity();
@@ -74,6 +81,10 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     if (lane == 0) {
         Pm = mat_identity();
         eps = 0;
+    }
+    if (cin) { // segment > 0: P'_{seg0-1} of the carry-only forward pass precedes everything (its scale is exponent 0)
+        Pm = mat_mul(Mat{cin[w * 5 + 0], cin[w * 5 + 1], cin[w * 5 + 2], cin[w * 5 + 3]}, Pm);
+        eps -= mat_renorm(Pm);
     }
 
     Mat Pin[C];  // P'_{n-1} as used by this lane
@@ -141,10 +152,34 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     }
     Mat Uin = mat_shfl_down(Aacc, 1);
     if (lane == kWave - 1) Uin = Mat{0.f, 0.f, 0.f, 0.f};
+    if (uin) {
+        // Adjoint entering from the next segment.  It was written relative to the scale of that segment's
+        // carry-in P' (cnext); lane 63's final P' is the same matrix up to a power of two (idle samples
+        // multiply by the identity), so the ratio of their largest entries gives the exact exponent hop.
+        Mat Kn{cnext[w * 5 + 0], cnext[w * 5 + 1], cnext[w * 5 + 2], cnext[w * 5 + 3]};
+        float mk = fmaxf(fmaxf(fabsf(Kn.a), fabsf(Kn.b)), fmaxf(fabsf(Kn.c), fabsf(Kn.d)));
+        float mp = fmaxf(fmaxf(fabsf(Pm.a), fabsf(Pm.b)), fmaxf(fabsf(Pm.c), fabsf(Pm.d)));
+        mp = __shfl(mp, kWave - 1, kWave);
+        float ratio = mk / mp;
+        Mat Uc{uin[w * 4 + 0], uin[w * 4 + 1], uin[w * 4 + 2], uin[w * 4 + 3]};
+        if (finitef(ratio) && ratio > 0.f && mat_finite(Uc))
+            Uc = mat_scale(Uc, (int)rintf(log2f(ratio)));
+        else
+            Uc = Mat{0.f, 0.f, 0.f, 0.f};
+        // U entering lane l = G_{l+1}(Uc) = Aacc_{l+1} + Uc (B_{l+1} 2^beta_{l+1})^T
+        Mat Bs = mat_shfl_down(Bn, 1);
+        int bs = __shfl_down(beta, 1, kWave);
+        Mat t = mat_scale(mat_mul_bt(Uc, Bs), bs);
+        Uin.a += t.a; Uin.b += t.b; Uin.c += t.c; Uin.d += t.d;
+        if (lane == kWave - 1) Uin = Uc;
+    }
     Uin = mat_scale(Uin, delta);
 
     float rbar[C];
-    sweep(Uin, rbar);
+    const Mat Uout = sweep(Uin, rbar);
+    if (uout && lane == 0) { // relative to the scale of this segment's carry-in P'
+        uout[w * 4 + 0] = Uout.a; uout[w * 4 + 1] = Uout.b; uout[w * 4 + 2] = Uout.c; uout[w * 4 + 3] = Uout.d;
+    }
 
     // ---- rbar -> zbar (d r / d Z of reference :33) ----
     float zbar[C];
@@ -153,8 +188,8 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     float carry = 0.f, gmed_lane = 0.f;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
-        bool live = (n >= 1 && n < A.N1);
+        int n = seg0 + n0 + j;
+        bool live = (n >= 1 && n0 + j < segN);
         float rb = live ? rbar[j] : 0.f;
         if (!finitef(rb)) rb = 0.f; // drop non-finite
         if (n == 1 && A.start > 0) {
@@ -175,8 +210,18 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         else
             zbar[j == 0 ? 0 : j - 1] += c0;
     }
-    float cin = __shfl_down(carry, 1, kWave);
-    if (lane != kWave - 1) zbar[C - 1] += cin;
+    const float cnb = __shfl_down(carry, 1, kWave);
+    if (lane != kWave - 1) zbar[C - 1] += cnb;
+    if (zcout && lane == 0) zcout[w] = carry; // belongs to the last sample of the previous segment
+    if (zcin) {
+        const int last = segN - 1;
+        const float zc = zcin[w];
+        if (lane == last / C) {
+#pragma unroll
+            for (int j = 0; j < C; ++j)
+                if (j == last % C) zbar[j] += zc;
+        }
+    }
     if (gmed_lane != 0.f) atomicAdd(&A.gmed[pose], gmed_lane);
 
     // ---- back to INTERLEAVED: hand zbar to the scatter kernel, reduce the pose gradient ----
@@ -184,11 +229,11 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     // mapping is chosen for LDS privatisation, not for the scan.
     to_interleaved<C>(wb, lane, zbar, zi);
     if (A.zbar) {
-        float *zo = A.zbar + w * A.N1;
+        float *zo = A.zbar + w * A.N1 + seg0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = j * kWave + lane;
-            if (n < A.N1) zo[n] = zi[j];
+            if (n < segN) zo[n] = zi[j];
         }
     }
     if (GPOSE) {
@@ -197,8 +242,8 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         for (int j = 0; j < C; ++j) {
             int n = j * kWave + lane;
             float zb = zi[j];
-            if (n < A.N1 && zb != 0.f) {
-                int k = A.start + n;
+            if (n < segN && zb != 0.f) {
+                int k = A.start + seg0 + n;
                 float q0, q1, q2;
                 if (KEEP_GRAD) {
                     q0 = gi0[j]; q1 = gi1[j]; q2 = gi2[j];
@@ -225,6 +270,14 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
             gd2 += __shfl_xor(gd2, off, kWave);
         }
         if (lane == 0) {
+            if (accum_pose) { // later-processed segment of a long ray: add to the partial sums
+                if (A.gsrc_part) {
+                    gs0 += A.gsrc_part[w * 3 + 0]; gs1 += A.gsrc_part[w * 3 + 1]; gs2 += A.gsrc_part[w * 3 + 2];
+                }
+                if (A.gdirs) {
+                    gd0 += A.gdirs[w * 3 + 0]; gd1 += A.gdirs[w * 3 + 1]; gd2 += A.gdirs[w * 3 + 2];
+                }
+            }
             if (A.gsrc_part) {
                 A.gsrc_part[w * 3 + 0] = gs0;
                 A.gsrc_part[w * 3 + 1] = gs1;
@@ -326,6 +379,10 @@ int launch_bwd_p(const Args &A, hipStream_t st)
 {
     const long waves = (long)A.P * A.R;
     const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (A.N1 > DIFFUS_MAX_SAMPLES) { // a segment of a long ray
+        hipLaunchKernelGGL((render_bwd_kernel<16, SM, LY, GPOSE, 1, PM, true>), dim3((unsigned)waves), dim3(kWave), 0, st, A);
+        return last_launch();
+    }
     switch (chunk_for(A.N1)) {
     case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
     case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
@@ -391,8 +448,39 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
             rc = launch_median(A, sampler, layout, st);
             if (rc) return rc;
         }
-        rc = launch_bwd(A, sampler, layout, pose, st);
-        if (rc) return rc;
+        if (ws.nseg == 1) {
+            rc = launch_bwd(A, sampler, layout, pose, st);
+            if (rc) return rc;
+        } else {
+            // Long rays.  Pass 1 runs the forward kernel segment by segment to leave every segment's carry-in
+            // (P' and the last impedance sample) in the workspace; pass 2 runs the adjoint scan from the last
+            // segment to the first, chained through U' and the boundary term of zbar.
+            const size_t wr = (size_t)P * R;
+            for (int s = 0; s + 1 < ws.nseg; ++s) {
+                Args F = A;
+                F.frame = nullptr; F.idx = nullptr;
+                F.seg0 = s * DIFFUS_MAX_SAMPLES; F.segN = DIFFUS_MAX_SAMPLES;
+                F.cin = s ? ws.carry + (size_t)(s - 1) * wr * 5 : nullptr;
+                F.cout = ws.carry + (size_t)s * wr * 5;
+                rc = diffus::launch_fwd(F, sampler, layout, st);
+                if (rc) return rc;
+            }
+            for (int s = ws.nseg - 1; s >= 0; --s) {
+                Args B = A;
+                const bool last = s == ws.nseg - 1;
+                B.seg0 = s * DIFFUS_MAX_SAMPLES;
+                B.segN = last ? A.N1 - B.seg0 : DIFFUS_MAX_SAMPLES;
+                B.cin = s ? ws.carry + (size_t)(s - 1) * wr * 5 : nullptr;
+                B.cnext = last ? nullptr : ws.carry + (size_t)s * wr * 5;
+                B.uin = last ? nullptr : ws.ucarry + (size_t)((s + 1) & 1) * wr * 4;
+                B.uout = s ? ws.ucarry + (size_t)(s & 1) * wr * 4 : nullptr;
+                B.zcin = last ? nullptr : ws.zcarry + (size_t)((s + 1) & 1) * wr;
+                B.zcout = s ? ws.zcarry + (size_t)(s & 1) * wr : nullptr;
+                B.accum_pose = !last;
+                rc = launch_bwd(B, sampler, layout, pose, st);
+                if (rc) return rc;
+            }
+        }
     }
     if (gvol && do_scatter) {
         rc = diffus::launch_scatter(A, sampler, layout, st);

@@ -8,9 +8,14 @@ namespace {
 #ifndef DIFFUS_FWD_MIN_WAVES
 #define DIFFUS_FWD_MIN_WAVES 1
 #endif
-template <int C, int SAMPLER, int LAYOUT, int WPB, int PM>
+// SEG = true: the launch covers one 1024-sample segment of a longer ray (carries in the workspace); only
+// instantiated for C = 16.  SEG = false compiles every carry path away.
+template <int C, int SAMPLER, int LAYOUT, int WPB, int PM, bool SEG = false>
 __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) void render_fwd_kernel(Args A)
 {
+    const int seg0 = SEG ? A.seg0 : 0, segN = SEG ? A.segN : A.N1;
+    const float *const cin = SEG ? A.cin : nullptr;
+    float *const cout = SEG ? A.cout : nullptr;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     const int wib = threadIdx.x >> 6;
     const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
@@ -28,7 +33,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #pragma unroll
     for (int j = 0; j < C; ++j) zi[j] = ps.sf[0] + (float)(j * kWave + lane) * ps.df[1];
 #else
-    gather_interleaved<C, SAMPLER, LAYOUT, false, PM>(A, ps, lane, zi, u0, u1, u2);
+    gather_interleaved<C, SAMPLER, LAYOUT, false, PM>(A, seg0, segN, ps, lane, zi, u0, u1, u2);
 #endif
 #ifdef DIFFUS_ABLATE_TRANSPOSE
 #pragma unroll
@@ -37,18 +42,34 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
     to_chunked<C>(wb, lane, zi, z);
 #endif
     float zprev = __shfl_up(z[C - 1], 1, kWave);
+    Mat K = mat_identity(), Klast = mat_identity();
+    if (cin) { // carry of the earlier segments: running product and the sample just before this segment
+        K = Mat{cin[w * 5 + 0], cin[w * 5 + 1], cin[w * 5 + 2], cin[w * 5 + 3]};
+        if (lane == 0) zprev = cin[w * 5 + 4];
+    }
     float medv = (A.start > 0) ? A.med[pose] : 0.f;
-    reflect_chunk<C>(A, n0, z, zprev, medv, r);
+    reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r);
 #ifdef DIFFUS_ABLATE_SCAN
 #pragma unroll
     for (int j = 0; j < C; ++j) e[j] = r[j];
 #else
-    echo_chunk<C, true>(r, lane, e);
+    echo_chunk<C, true>(r, lane, e, cin ? &K : nullptr, segN - 1, cout ? &Klast : nullptr);
 #endif
+    if (cout) { // hand the running product and the last impedance sample to the next segment
+        const int last = segN - 1;
+        if (lane == last / C) {
+            float zl = z[0];
+#pragma unroll
+            for (int j = 1; j < C; ++j) zl = (j == last % C) ? z[j] : zl;
+            cout[w * 5 + 0] = Klast.a; cout[w * 5 + 1] = Klast.b; cout[w * 5 + 2] = Klast.c; cout[w * 5 + 3] = Klast.d;
+            cout[w * 5 + 4] = zl;
+        }
+    }
+    if (SEG && !A.frame) return; // carry-only pass (first half of a segmented backward)
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         // attenuation, reference :256-259: f32(-alpha) * f32(n), exp, multiply
-        float att = fast_exp(__fmul_rn(A.neg_alpha, (float)(n0 + j)));
+        float att = fast_exp(__fmul_rn(A.neg_alpha, (float)(seg0 + n0 + j)));
         e[j] = __fmul_rn(e[j], att);
     }
 #ifdef DIFFUS_ABLATE_TRANSPOSE
@@ -57,7 +78,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #else
     to_interleaved<C>(wb, lane, e, zi);
 #endif
-    float *out = A.frame + w * A.N1;
+    float *out = A.frame + w * A.N1 + seg0;
 #ifdef DIFFUS_ABLATE_STORE
     float acc = 0.f;
 #pragma unroll
@@ -67,18 +88,18 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         int n = j * kWave + lane;
-        if (n < A.N1) out[n] = zi[j];
+        if (n < segN) out[n] = zi[j];
     }
 #endif
 
     if (A.idx) {
         const long plane = (long)A.P * A.R * A.N1;
-        long long *ix = A.idx + w * A.N1;
+        long long *ix = A.idx + w * A.N1 + seg0;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = j * kWave + lane;
-            if (n < A.N1) {
-                int k = A.start + n;
+            if (n < segN) {
+                int k = A.start + seg0 + n;
                 ix[n] = nearest_index(ray_point<PM>(ps, 0, k), A.G.d0);
                 ix[plane + n] = nearest_index(ray_point<PM>(ps, 1, k), A.G.d1);
                 ix[2 * plane + n] = nearest_index(ray_point<PM>(ps, 2, k), A.G.d2);
@@ -132,18 +153,25 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
     const long w = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (w >= B) return;
     const int lane = threadIdx.x & 63;
-    const int n0 = lane * C;
-    float r[C], e[C];
+    // rows longer than 64*C samples: the wave walks them in pieces, the running product stays in registers
+    Mat K = mat_identity();
+    for (int base = 0; base <= N; base += kWave * C) {
+        const int n0 = base + lane * C;
+        float r[C], e[C];
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
-        r[j] = (n >= 1 && n <= N) ? rin[w * N + n - 1] : 0.f;
-    }
-    echo_chunk<C>(r, lane, e);
+        for (int j = 0; j < C; ++j) {
+            int n = n0 + j;
+            r[j] = (n >= 1 && n <= N) ? rin[w * N + n - 1] : 0.f;
+        }
+        Mat Kl = K;
+        echo_chunk<C>(r, lane, e, base ? &K : nullptr, kWave * C - 1, &Kl);
+        K = Mat{__shfl(Kl.a, kWave - 1, kWave), __shfl(Kl.b, kWave - 1, kWave), __shfl(Kl.c, kWave - 1, kWave),
+                __shfl(Kl.d, kWave - 1, kWave)};
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        int n = n0 + j;
-        if (n <= N) echo[w * (N + 1) + n] = e[j];
+        for (int j = 0; j < C; ++j) {
+            int n = n0 + j;
+            if (n <= N) echo[w * (N + 1) + n] = e[j];
+        }
     }
 }
 
@@ -161,17 +189,28 @@ int launch_fwd_t(const Args &A, hipStream_t st)
     return last_launch();
 }
 
-int launch_fwd(const Args &A, int sampler, int layout, hipStream_t st)
+template <int SM, int LY, int PM>
+int launch_fwd_seg(const Args &A, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((render_fwd_kernel<16, SM, LY, kWavesPerBlock, PM, true>), dim3(nblk), dim3(kBlock), 0, st, A);
+    return last_launch();
+}
+
+} // namespace
+
+// one launch of the forward kernel over the segment [A.seg0, A.seg0 + A.segN); also used by the backward of
+// long rays (render_bwd.hip) as its carry-only pass
+int diffus::launch_fwd(const Args &A, int sampler, int layout, hipStream_t st)
 {
     const bool f32 = !A.src_f64 && !A.dir_f64;
     return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
         constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+        if (A.N1 > DIFFUS_MAX_SAMPLES) return f32 ? launch_fwd_seg<SM, LY, 0>(A, st) : launch_fwd_seg<SM, LY, 1>(A, st);
         return f32 ? launch_fwd_t<SM, LY, 0>(A, st) : launch_fwd_t<SM, LY, 1>(A, st);
     });
 }
-
-
-} // namespace
 
 extern "C" {
 
@@ -182,7 +221,7 @@ const char *diffus_strerror(int code)
     switch (code) {
     case DIFFUS_OK: return "ok";
     case DIFFUS_EINVAL: return "invalid argument";
-    case DIFFUS_EUNSUPPORTED: return "unsupported shape (S - start > 1024, a volume edge > 2^24, or too many rays for start > 0)";
+    case DIFFUS_EUNSUPPORTED: return "unsupported shape (S - start > 65536, a volume edge > 2^24, or too many rays for start > 0)";
     case DIFFUS_ELAUNCH: return "HIP launch failure";
     case DIFFUS_EWORKSPACE: return "workspace too small (see diffus_workspace_bytes)";
     default: return "unknown diffus error";
@@ -203,7 +242,7 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, cons
     if (rc) return rc;
     if (!frame) return DIFFUS_EINVAL;
     Workspace ws = carve(workspace, P, R, S - start);
-    if (start > 0 && (!workspace || workspace_bytes < ws.bytes)) return DIFFUS_EWORKSPACE;
+    if ((start > 0 || ws.nseg > 1) && (!workspace || workspace_bytes < ws.bytes)) return DIFFUS_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.frame = frame;
@@ -212,7 +251,17 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, cons
         rc = launch_median(A, sampler, layout, st);
         if (rc) return rc;
     }
-    return launch_fwd(A, sampler, layout, st);
+    // rays longer than one launch covers: segments of DIFFUS_MAX_SAMPLES chained through the running product
+    const size_t wr = (size_t)P * R;
+    for (int s = 0; s < ws.nseg; ++s) {
+        A.seg0 = s * DIFFUS_MAX_SAMPLES;
+        A.segN = (s == ws.nseg - 1) ? A.N1 - A.seg0 : DIFFUS_MAX_SAMPLES;
+        A.cin = s ? ws.carry + (size_t)(s - 1) * wr * 5 : nullptr;
+        A.cout = (s + 1 < ws.nseg) ? ws.carry + (size_t)s * wr * 5 : nullptr;
+        rc = diffus::launch_fwd(A, sampler, layout, st);
+        if (rc) return rc;
+    }
+    return DIFFUS_OK;
 }
 
 int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
@@ -241,7 +290,6 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stre
 {
     if (!refl && N > 0) return DIFFUS_EINVAL;
     if (!echo || B <= 0 || N < 0) return DIFFUS_EINVAL;
-    if (N + 1 > DIFFUS_MAX_SAMPLES) return DIFFUS_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const unsigned nblk = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
     switch (chunk_for(N + 1)) {

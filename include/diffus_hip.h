@@ -40,7 +40,7 @@ extern "C" {
 /* error codes */
 #define DIFFUS_OK            0
 #define DIFFUS_EINVAL      (-1) /* bad argument (null pointer, non-positive size, bad enum) */
-#define DIFFUS_EUNSUPPORTED (-2) /* shape outside what the kernels cover (S - start > DIFFUS_MAX_SAMPLES) */
+#define DIFFUS_EUNSUPPORTED (-2) /* shape outside what the kernels cover (S - start > MAX_SAMPLES * MAX_SEGMENTS, ...) */
 #define DIFFUS_ELAUNCH     (-3) /* HIP reported a launch error (hipGetLastError) */
 #define DIFFUS_EWORKSPACE  (-4) /* workspace too small, see diffus_workspace_bytes */
 
@@ -64,9 +64,12 @@ extern "C" {
                               the pair (v[z], v[min(z+1,d2-1)]); made by diffus_pair_volume; twice the
                               memory; the gradient that goes with it (gvol) is DIFFUS_BRICKED */
 
-/* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples,
- * at most 16 -> N1 <= 1024 */
+/* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples, at most 16, so one launch
+ * covers 1024 cropped samples.  Longer rays (N1 = S - start up to MAX_SAMPLES * MAX_SEGMENTS) are processed
+ * as segments of 1024 samples, one launch each, chained through per-ray carries in the workspace (the running
+ * transfer-matrix product forward, the adjoint matrix backward). */
 #define DIFFUS_MAX_SAMPLES 1024
+#define DIFFUS_MAX_SEGMENTS 64
 
 typedef void *diffus_stream_t;
 
@@ -191,7 +194,7 @@ int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout,
  * Stage 2 alone: replaces compute_echo_traces' first return value (reference
  * src/renderer.py:439-457, i.e. propagate_full_rays_batched :412-436 and
  * prop_single_ray :367-410): refl (B,N) -> echo (B,N+1), echo[:,0] = 0.
- * N + 1 <= DIFFUS_MAX_SAMPLES.
+ * Any N: rows longer than 1024 samples are walked in pieces by the same wave.
  */
 int diffus_echo_traces(const float *refl, int B, int N, float *echo,
                        diffus_stream_t stream);

@@ -71,7 +71,8 @@ def test_argument_validation_without_a_gpu(lib):
     assert fwd(sdt=3) == -1
     assert fwd(start=4) == -1            # start > S-1
     assert fwd(start=3) == -1            # start > 0 needs two samples (reference IndexError at :243)
-    assert fwd(S=2000) == -2             # S - start > DIFFUS_MAX_SAMPLES
+    assert fwd(S=70000) == -2            # S - start > DIFFUS_MAX_SAMPLES * DIFFUS_MAX_SEGMENTS
+    assert fwd(S=2000) == -4             # long rays need the workspace for their carries
     assert fwd(d0=1 << 25) == -2
     assert fwd(start=1) == -4            # start > 0 needs the workspace
     assert fwd(frame=None) == -1
@@ -81,7 +82,6 @@ def test_argument_validation_without_a_gpu(lib):
     assert lib.diffus_brick_count(256, 256, 256) == 256 ** 3 // 32
     assert lib.diffus_gradbuf_flush(None, p, 2, 2, 2, p, 1, None) == -1
     assert lib.diffus_echo_traces(None, 1, 4, p, None) == -1
-    assert lib.diffus_echo_traces(p, 1, 2000, p, None) == -2
     assert lib.diffus_brick_volume(None, 2, 2, 2, p, None) == -1
     assert lib.diffus_loss_sumsq(p, 0, 4, p, None, p, 1024, None) == -1
     assert lib.diffus_loss_sumsq(p, 1, 4, p, None, None, 0, None) == -4
