@@ -16,7 +16,9 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
            "diffus_pair_volume", "diffus_brick_count", "diffus_gradbuf_flush",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces",
            "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd",
-           "diffus_artifacts_workspace_bytes", "diffus_artifacts")
+           "diffus_artifacts_workspace_bytes", "diffus_artifacts",
+           "diffus_mlp_fwd", "diffus_mlp_workspace_bytes", "diffus_mlp_bwd", "diffus_brain_mask_workspace_bytes",
+           "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
@@ -84,6 +86,20 @@ def load():
     lib.diffus_artifacts_workspace_bytes.argtypes = [i, i, i]
     lib.diffus_artifacts.restype = i
     lib.diffus_artifacts.argtypes = [vp, i, i, i, d, d, d, d, vp, vp, C.c_uint64, vp, vp, sz, vp]
+    lib.diffus_mlp_fwd.restype = i
+    lib.diffus_mlp_fwd.argtypes = [vp, vp, sz, vp, f, f, f, f, vp, vp]
+    lib.diffus_mlp_workspace_bytes.restype = sz
+    lib.diffus_mlp_workspace_bytes.argtypes = []
+    lib.diffus_mlp_bwd.restype = i
+    lib.diffus_mlp_bwd.argtypes = [vp, vp, sz, vp, f, f, f, vp, vp, vp, vp, sz, vp]
+    lib.diffus_brain_mask_workspace_bytes.restype = sz
+    lib.diffus_brain_mask_workspace_bytes.argtypes = [i, i, i]
+    lib.diffus_brain_mask.restype = i
+    lib.diffus_brain_mask.argtypes = [vp, i, i, i, f, i, vp, vp, sz, vp]
+    lib.diffus_masked_stats_workspace_bytes.restype = sz
+    lib.diffus_masked_stats_workspace_bytes.argtypes = []
+    lib.diffus_masked_stats.restype = i
+    lib.diffus_masked_stats.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     if lib.diffus_abi_version() != 1:
         raise DiffusError("libdiffus_hip.so ABI version mismatch")
     _lib = lib

@@ -250,6 +250,53 @@ int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gfr
                       void *workspace, size_t workspace_bytes /* >= 64 * P bytes */,
                       diffus_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * MRI -> acoustic impedance, the producer of `vol` in the training loops.
+ *
+ * The MLP is ImpedanceEstimator (reference src/impedance.py:6-17): Linear(1,32) ReLU Linear(32,32) ReLU
+ * Linear(32,1).  `params` = the 1153 floats of its state_dict in order: model.0.weight (32), model.0.bias (32),
+ * model.2.weight (32x32, [out][in]), model.2.bias (32), model.4.weight (32), model.4.bias (1).
+ */
+#define DIFFUS_MLP_HIDDEN 32
+#define DIFFUS_MLP_PARAMS 1153
+
+/*
+ * y[i] = (mask == NULL || mask[i]) ? out_scale * mlp((x[i] - in_shift) / in_div) : fill        i < n
+ * Replaces ImpedanceEstimator.forward (:16-17; in_shift 0, in_div 1, out_scale 1, mask NULL) and, with the
+ * z-score constants, the 1e6 scale and fill = 400, the body of compute_impedance_volume (:45-53) in one pass;
+ * the hidden layer runs on the f32 matrix cores, activations stay in registers.
+ */
+int diffus_mlp_fwd(const float *x, const unsigned char *mask, size_t n, const float *params,
+                   float in_shift, float in_div, float out_scale, float fill, float *y,
+                   diffus_stream_t stream);
+
+/*
+ * Backward of the above for upstream gy (n floats): gparams (1153 floats, overwritten) = d/dparams of
+ * sum(y * gy); gx (nullable, n floats) = d/dx.  Deterministic (fixed-order reductions).
+ */
+size_t diffus_mlp_workspace_bytes(void);
+int diffus_mlp_bwd(const float *x, const unsigned char *mask, size_t n, const float *params,
+                   float in_shift, float in_div, float out_scale, const float *gy,
+                   float *gparams, float *gx, void *workspace, size_t workspace_bytes,
+                   diffus_stream_t stream);
+
+/*
+ * create_brain_mask (reference src/utils.py:12-21): mask = vol > threshold, then `iterations` binary dilations
+ * and `iterations` binary erosions with SciPy's default structure (6-neighbourhood) and border value 0.
+ * mask: d0*d1*d2 bytes of 0/1.
+ */
+size_t diffus_brain_mask_workspace_bytes(int d0, int d1, int d2);
+int diffus_brain_mask(const float *vol, int d0, int d1, int d2, float threshold, int iterations,
+                      unsigned char *mask, void *workspace, size_t workspace_bytes, diffus_stream_t stream);
+
+/*
+ * The statistics of zscore_normalize (reference src/utils.py:34-36) over the voxels with mask[i] != 0 (all when
+ * mask == NULL): out[0] = mean, out[1] = unbiased standard deviation, out[2] = count (device doubles).
+ */
+size_t diffus_masked_stats_workspace_bytes(void);
+int diffus_masked_stats(const float *vol, const unsigned char *mask, size_t n, double *out,
+                        void *workspace, size_t workspace_bytes, diffus_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

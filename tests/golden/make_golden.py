@@ -349,6 +349,51 @@ def main():
         out["tags"] = np.array([c[0] for c in cases])
         save("g14_artifacts", **out)
 
+    # ---- G15: impedance MLP (src/impedance.py:6-17) and compute_impedance_volume (:38-53) ----------
+    if want("g15"):
+        import importlib
+        imp = importlib.import_module("src.impedance")
+        utl = importlib.import_module("src.utils")
+        out = {}
+        torch.manual_seed(77)
+        m = imp.ImpedanceEstimator(1)
+        with torch.no_grad():           # a trained net has biases / weights of both signs and sizes
+            for q in m.parameters():
+                q.mul_(1.7)
+            m.model[4].bias.add_(1.5)
+        for k, v_ in m.state_dict().items():
+            out["sd_" + k] = v_.numpy().copy()
+        g = torch.Generator().manual_seed(5)
+        x = (torch.randn(3001, 1, generator=g) * 1.5)
+        up = torch.randn(3001, 1, generator=g)
+        with torch.enable_grad():
+            xr = x.clone().requires_grad_(True)
+            y = m(xr)
+            (y * up).sum().backward()
+        out["x"] = x.numpy(); out["up"] = up.numpy(); out["y"] = y.detach().numpy(); out["gx"] = xr.grad.numpy()
+        for k, q in m.named_parameters():
+            out["g_" + k] = q.grad.numpy().copy()
+        # a synthetic "MRI": bright head on dark noisy air, with holes and specks the open/close cleans up
+        n0, n1, n2 = 40, 36, 33
+        u0 = (np.arange(n0) / (n0 - 1) - 0.5)[:, None, None]; u1 = (np.arange(n1) / (n1 - 1) - 0.5)[None, :, None]
+        u2 = (np.arange(n2) / (n2 - 1) - 0.5)[None, None, :]
+        rng = np.random.default_rng(15)
+        mri = rng.uniform(0, 30, size=(n0, n1, n2))
+        head = (u0 / 0.42) ** 2 + (u1 / 0.40) ** 2 + (u2 / 0.55) ** 2 <= 1.0     # touches the dim-2 border
+        mri[head] = 300 + 200 * np.sin(9 * u0 + 5 * u1 + 7 * u2)[head] + rng.normal(0, 20, size=int(head.sum()))
+        mri[rng.uniform(size=mri.shape) < 0.02] = 5.0         # holes inside, filled by the dilation
+        mri[rng.uniform(size=mri.shape) < 0.01] = 500.0       # specks outside, removed by the erosion
+        mri = mri.astype(np.float32)
+        for thr in (50, 120.5):
+            mask = utl.create_brain_mask(mri, thr)
+            vn = utl.zscore_normalize(torch.from_numpy(mri), mask)
+            Z = imp.ImpedanceEstimator.compute_impedance_volume(torch.from_numpy(mri), m, thr)
+            tag = "t%d" % int(thr)
+            out[tag + "_thr"] = np.float64(thr); out[tag + "_mask"] = mask.numpy(); out[tag + "_vnorm"] = vn.numpy()
+            out[tag + "_Z"] = Z.numpy()
+        out["mri"] = mri
+        save("g15_impedance", **out)
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

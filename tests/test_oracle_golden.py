@@ -196,3 +196,22 @@ def test_g10_config2_forward(oracle):
     p = int(g["pose"])
     _, _, _, f = oracle.plot_beam_frame(vol, s[p], d[p], 512, 1e-4, 0)
     assert maxnorm_rel(f, g["frame"]) < 1e-4
+
+
+def test_g15_impedance_mlp_and_volume():
+    """the MLP, the brain mask (SciPy morphology), z-scoring and compute_impedance_volume."""
+    from oracle import impedance as oi
+    g = load_golden("g15_impedance")
+    params = oi.pack({k[3:]: g[k] for k in g.files if k.startswith("sd_")})
+    y = oi.mlp_forward(g["x"], params)
+    assert maxnorm_rel(y, g["y"]) < 2e-6
+    gp, gx = oi.mlp_backward(g["x"], params, g["up"])
+    gref = oi.pack({k[2:]: g[k] for k in g.files if k.startswith("g_")})
+    assert maxnorm_rel(gp, gref) < 2e-5
+    assert maxnorm_rel(gx, g["gx"]) < 2e-6
+    for tag in ("t50", "t120"):
+        Z, mask = oi.compute_impedance_volume(g["mri"], params, float(g[tag + "_thr"]))
+        assert np.array_equal(mask, g[tag + "_mask"])                      # the morphology is bit-exact
+        assert maxnorm_rel(oi.zscore_normalize(g["mri"], mask), g[tag + "_vnorm"]) < 1e-6
+        assert maxnorm_rel(Z, g[tag + "_Z"]) < 1e-5
+        assert np.all(Z[~mask] == 400.0)
