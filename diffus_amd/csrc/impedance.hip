@@ -25,8 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kH = DIFFUS_MLP_HIDDEN;           // 32
 constexpr int kNP = DIFFUS_MLP_PARAMS;          // 1153
 constexpr int oW1 = 0, oB1 = 32, oW2 = 64, oB2 = 64 + 1024, oW3 = oB2 + 32, oB3 = oW3 + 32;
-constexpr int kMlpFwdBlocks = 1024;             // persistent grids: forward 4 waves per SIMD (127 registers),
-constexpr int kMlpBwdBlocks = 256;              // backward 1 wave per SIMD (its accumulators fill the register file)
+constexpr int kMlpMaxBlocks = 2048;             // bound of the persistent grids (sizes the backward's workspace)
 
 __device__ __forceinline__ int hidx(int i, int h) { return 8 * (i >> 2) + 4 * h + (i & 3); }
 
@@ -45,7 +44,7 @@ struct MlpArgs {
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 // y = mask ? out_scale * mlp((x - shift) / div) : fill.   One wave = 64 consecutive voxels = two tiles per trip.
-__global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(MlpArgs A)
+__global__ __launch_bounds__(kBlock, 4) void mlp_fwd_kernel(MlpArgs A)
 {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const float *P = A.params;
@@ -62,21 +61,23 @@ __global__ __launch_bounds__(kBlock) void mlp_fwd_kernel(MlpArgs A)
     const float b3 = P[oB3];
     const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock, wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const size_t ngroups = (A.n + 63) / 64;
-    // software prefetch: the next trip's voxels are in flight while this trip's 32 MFMAs run
-    auto fetch = [&](size_t g, float &xv, bool &in, bool &live) {
-        const size_t i0 = g * 64 + lane;
-        in = g < ngroups && i0 < A.n;
-        live = in && (!A.mask || A.mask[i0]);
-        xv = live ? A.x[i0] : A.shift;
+    // software prefetch: the next trip's voxels are in flight while this trip's 32 MFMAs run.  Branch-free loads
+    // (index clamped, mask and x fetched together): a load behind a branch on another load serialises two round trips.
+    const bool has_mask = A.mask != nullptr;
+    auto fetch = [&](size_t g, float &xv, unsigned &mk) {
+        size_t i0 = g * 64 + lane;
+        i0 = i0 < A.n ? i0 : A.n - 1;
+        xv = A.x[i0];
+        mk = has_mask ? A.mask[i0] : 1u;
     };
     float xn;
-    bool inn, liven;
-    fetch(wave, xn, inn, liven);
+    unsigned mkn;
+    fetch(wave, xn, mkn);
     for (size_t g = wave; g < ngroups; g += nwaves) {
         const size_t i0 = g * 64 + lane;
-        float xv = xn;
-        const bool in = inn, live = liven;
-        fetch(g + nwaves, xn, inn, liven);
+        const bool in = i0 < A.n, live = in && mkn;
+        float xv = live ? xn : A.shift;
+        fetch(g + nwaves, xn, mkn);
         if (__ballot(live) == 0) { // all air: nothing to evaluate (most of a head volume)
             if (in) A.y[i0] = A.fill;
             continue;
@@ -133,25 +134,38 @@ __global__ __launch_bounds__(kBlock) void mlp_bwd_kernel(MlpArgs A)
 
     const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock, wave = (size_t)blockIdx.x * kWavesPerBlock + wib;
     const size_t ntiles = (A.n + 31) / 32;
+    // One wave per SIMD (the accumulators fill the register file), so nothing hides a load but the wave itself:
+    // the next tile's x / gy / mask are fetched (branch-free, index clamped) before this tile's 64 MFMAs start.
+    const bool has_mask = A.mask != nullptr;
+    auto fetch = [&](size_t t, float &xv, float &gv, unsigned &mk) {
+        size_t i = t * 32 + r;
+        i = i < A.n ? i : A.n - 1;
+        xv = A.x[i];
+        gv = A.gy[i];
+        mk = has_mask ? A.mask[i] : 1u;
+    };
+    float xnx, gnx;
+    unsigned mnx;
+    fetch(wave, xnx, gnx, mnx);
     for (size_t t = wave; t < ntiles; t += nwaves) {
         const size_t base = t * 32;
         // lane = voxel view
         const size_t il = base + r;
-        const bool livel = il < A.n && (!A.mask || A.mask[il]);
-        const float gyl = livel ? A.gy[il] * A.out_scale : 0.f;
+        const bool livel = il < A.n && mnx;
+        const float gyl = livel ? gnx * A.out_scale : 0.f;
+        const float xraw = livel ? xnx : A.shift;
+        fetch(t + nwaves, xnx, gnx, mnx);
         if (__ballot(gyl != 0.f) == 0) { // nothing flows back through this tile
             if (A.gx && h == 0 && il < A.n) A.gx[il] = 0.f;
             continue;
         }
-        const float xl = __fdiv_rn((livel ? A.x[il] : A.shift) - A.shift, A.div);
-        // (register, half) = voxel view of the same 32 voxels
+        const float xl = __fdiv_rn(xraw - A.shift, A.div);
+        // (register, half) = voxel view of the same 32 voxels: lane idx(i,h) holds that voxel
         float xq[16], gq[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const size_t iq = base + hidx(i, h);
-            const bool lq = iq < A.n && (!A.mask || A.mask[iq]);
-            gq[i] = lq ? A.gy[iq] * A.out_scale : 0.f;
-            xq[i] = __fdiv_rn((lq ? A.x[iq] : A.shift) - A.shift, A.div);
+            xq[i] = __shfl(xl, hidx(i, h), kWave);
+            gq[i] = __shfl(gyl, hidx(i, h), kWave);
         }
         // forward, both orientations
         float hb[16];
@@ -298,6 +312,19 @@ __global__ void stats_finish_kernel(const double *__restrict__ part, int nblk, d
     out[2] = c;
 }
 
+// Persistent grids are sized to what is resident at once (blocks per CU from the occupancy query x CUs): a grid
+// larger than that runs in rounds and the last round leaves most of the chip idle.
+template <typename K>
+unsigned resident_blocks(K kernel)
+{
+    int dev = 0, cus = 256, per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    long nb = (long)cus * per_cu;
+    return (unsigned)(nb < kMlpMaxBlocks ? nb : kMlpMaxBlocks);
+}
+
 unsigned grid_for(size_t n)
 {
     size_t nb = (n + kBlock - 1) / kBlock;
@@ -317,13 +344,14 @@ int diffus_mlp_fwd(const float *x, const unsigned char *mask, size_t n, const fl
     A.x = x; A.mask = mask; A.n = n; A.params = params;
     A.shift = in_shift; A.div = in_div; A.out_scale = out_scale; A.fill = fill; A.y = y;
     const size_t ngroups = (n + 63) / 64;
-    const unsigned nblk = (unsigned)((ngroups + kWavesPerBlock - 1) / kWavesPerBlock < kMlpFwdBlocks
-                                         ? (ngroups + kWavesPerBlock - 1) / kWavesPerBlock : kMlpFwdBlocks);
+    static const unsigned resident = resident_blocks(mlp_fwd_kernel);
+    const size_t want = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned nblk = (unsigned)(want < resident ? want : resident);
     hipLaunchKernelGGL(mlp_fwd_kernel, dim3(nblk), dim3(kBlock), 0, (hipStream_t)stream, A);
     return last_launch();
 }
 
-size_t diffus_mlp_workspace_bytes(void) { return align256(sizeof(float) * (size_t)kMlpBwdBlocks * kNP); }
+size_t diffus_mlp_workspace_bytes(void) { return align256(sizeof(float) * (size_t)kMlpMaxBlocks * kNP); }
 
 int diffus_mlp_bwd(const float *x, const unsigned char *mask, size_t n, const float *params, float in_shift, float in_div,
                    float out_scale, const float *gy, float *gparams, float *gx, void *workspace, size_t workspace_bytes,
@@ -337,8 +365,9 @@ int diffus_mlp_bwd(const float *x, const unsigned char *mask, size_t n, const fl
     A.shift = in_shift; A.div = in_div; A.out_scale = out_scale;
     A.gy = gy; A.gx = gx; A.partial = (float *)workspace;
     const size_t ntiles = (n + 31) / 32;
-    const unsigned nblk = (unsigned)((ntiles + kWavesPerBlock - 1) / kWavesPerBlock < kMlpBwdBlocks
-                                         ? (ntiles + kWavesPerBlock - 1) / kWavesPerBlock : kMlpBwdBlocks);
+    static const unsigned resident = resident_blocks(mlp_bwd_kernel);
+    const size_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned nblk = (unsigned)(want < resident ? want : resident);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nblk), dim3(kBlock), 0, st, A);
     if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
