@@ -405,6 +405,32 @@ def test_full_size_backward_properties(da, vol256):
     assert all(torch.all(x == 0) for x in g0)
 
 
+def test_config5_shape_512_volume_vs_oracle_and_backward(da, oracle):
+    """BASELINE config 5: a 512^3 volume, 512 rays x 1024 steps (one launch covers exactly 1024 samples), fwd + bwd."""
+    n, P, R, S, alpha = 512, 2, 512, 1024, 1e-4
+    v = phantom(n, variant=3)
+    src, dirs = pose_ring(n, 8, R)
+    src, dirs = src[[1, 6]], dirs[[1, 6]]
+    vol = cuda(v).requires_grad_(True)
+    s = torch.from_numpy(src).cuda().requires_grad_(True)
+    d = torch.from_numpy(dirs).cuda().requires_grad_(True)
+    f = da.render_poses(vol, s, d, S, alpha, sampler="trilinear")
+    fc = f.detach().cpu().numpy()
+    assert fc.shape == (P, R, S) and np.all(np.isfinite(fc))
+    for p in range(P):
+        _, _, _, fo = oracle.plot_beam_frame(v, src[p], dirs[p], S, alpha, 0, sampler="trilinear")
+        assert maxnorm_rel(fc[p], fo) < 2e-5, p
+    fn = da.render_poses(vol.detach(), s.detach(), d.detach(), S, alpha, sampler="nearest")
+    _, _, _, fo = oracle.plot_beam_frame(v, src[0], dirs[0], S, alpha, 0, sampler="nearest")
+    assert maxnorm_rel(fn[0].cpu().numpy(), fo) < 2e-5
+    del fn
+    g1 = torch.autograd.grad(f, (vol, s, d), grad_outputs=2 * f.detach(), retain_graph=True)
+    g2 = torch.autograd.grad(f, (vol, s, d), grad_outputs=-4 * f.detach())
+    for a, b in zip(g1, g2):                            # linear in the upstream gradient, at full size
+        assert torch.all(torch.isfinite(a)) and float(a.abs().max()) > 0
+        assert maxnorm_rel((-2 * a).cpu().numpy(), b.cpu().numpy()) < 1e-4
+
+
 # ----------------------------------------------------------------------------- bricked layout
 @pytest.mark.parametrize("shape", [(4, 4, 2), (5, 7, 3), (64, 64, 64), (33, 70, 129), (1, 1, 1), (3, 2, 131)])
 def test_brick_roundtrip(da, shape):
