@@ -9,9 +9,11 @@ Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays 
 512 steps.  One *step* = one pass of the hot path over one batch of poses:
   forward frame (diffus_render_fwd)
   -> loss_p = sum(frame_p^2), dL/dframe = 2 frame (diffus_loss_sumsq)
-  -> zero the caller's canonical (d0,d1,d2) volume-gradient tensor
   -> backward (diffus_render_bwd: d/d volume, d/d source, d/d directions)
-  -> touched bricks of the gradient scratch -> added into that tensor (diffus_gradbuf_flush)
+  -> touched bricks of the gradient scratch -> the caller's canonical (d0,d1,d2) volume-gradient tensor
+     (diffus_gradbuf_flush, mode PERSISTENT: the tensor is kept across steps and bricks the previous step
+     wrote but this one does not are cleared, so after every step it IS that step's dense gradient -- the
+     64 MiB memset per step this replaces is still available as --memset-grad)
   -> gather of the per-pose losses over ranks (RCCL, N > 1).
 Workload at N=1 = BASELINE config 3 (32 poses of the config-2 shape on one GPU;
 a single 256x512 frame is only 256 wavefronts, i.e. launch-latency-bound, and is
@@ -61,7 +63,8 @@ def vp(t):
 class HotPath:
     """Pre-allocated buffers + direct C-ABI calls (what a captured training step does)."""
 
-    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="paired", sparse=True):
+    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="paired", sparse=True,
+                 persistent=True):
         self.lib = _lib.load()
         self.vol, self.src, self.dirs = vol, src, dirs
         self.layout = {"canonical": 0, "bricked": 1, "paired": 2}[layout]
@@ -74,7 +77,11 @@ class HotPath:
         self.gframe = torch.empty_like(self.frame)
         d0, d1, d2 = vol.shape
         self.dims = (d0, d1, d2)
-        self.gvol = torch.empty_like(vol) if want_gvol else None       # canonical gradient, what the caller gets
+        # canonical gradient, what the caller gets.  persistent: the tensor is kept across steps and
+        # diffus_gradbuf_flush(PERSISTENT) clears what the previous step left where this step adds nothing, so it
+        # always equals this step's dense gradient without a 64 MiB memset per step.
+        self.persistent = persistent and sparse and want_gvol and self.layout != 0
+        self.gvol = torch.zeros_like(vol) if want_gvol else None
         if self.layout != 0:
             # HBM-resident converted copy of the (constant) volume, made once outside the timed region;
             # the bricked gradient scratch is zeroed, filled and converted back EVERY step.
@@ -95,7 +102,7 @@ class HotPath:
         self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
         self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
-        self.loss_ws = torch.empty(max(64 * self.P, 256), dtype=torch.uint8, device=dev)
+        self.loss_ws = torch.zeros(max(128 * self.P, 256), dtype=torch.uint8, device=dev)   # arrival counters: zero once
         nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, S, start), 256)
         self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         self.common = (vp(self.vol_k), d0, d1, d2, self.layout, vp(src), 0, vp(dirs), 0, self.P, self.R, S, start,
@@ -121,15 +128,15 @@ class HotPath:
     def zero_grad(self):
         """A fresh dense gradient every step: zero the caller's canonical (d0,d1,d2) tensor (sparse
         hand-back), or the bricked scratch (dense hand-back: the conversion overwrites every voxel)."""
-        if self.gvol is not None:
+        if self.gvol is not None and not self.persistent:
             (self.gvol if (self.touched is not None or self.layout == 0) else self.gvol_k).zero_()
 
     def finish_grad(self):
         """touched bricks of the scratch -> added into the canonical gradient; scratch back to all-zero."""
         if self.layout != 0 and self.gvol is not None and self.touched is not None:
             # accumulate = 0: the tensor was zeroed this step and every touched voxel is written once
-            _lib.check(self.lib.diffus_gradbuf_flush(vp(self.gvol_k), vp(self.touched), *self.dims, vp(self.gvol), 0,
-                                                     self.stream()), "diffus_gradbuf_flush")
+            _lib.check(self.lib.diffus_gradbuf_flush(vp(self.gvol_k), vp(self.touched), *self.dims, vp(self.gvol),
+                                                     2 if self.persistent else 0, self.stream()), "diffus_gradbuf_flush")
         elif self.layout != 0 and self.gvol is not None:
             _lib.check(self.lib.diffus_unbrick_volume(vp(self.gvol_k), *self.dims, vp(self.gvol), 0, self.stream()),
                        "diffus_unbrick_volume")
@@ -207,6 +214,9 @@ def main():
     ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
     ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
     ap.add_argument("--layout", default="paired", choices=["paired", "bricked", "canonical"])
+    ap.add_argument("--memset-grad", action="store_true",
+                    help="zero the whole canonical gradient tensor every step instead of keeping it persistent "
+                         "(diffus_gradbuf_flush mode STORE instead of PERSISTENT)")
     ap.add_argument("--dense-grad", action="store_true",
                     help="hand the gradient back by a dense conversion instead of the touched-brick flush")
     ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
@@ -243,7 +253,7 @@ def main():
     src = torch.from_numpy(src_all[lo:lo + args.poses]).to(dev).contiguous()
     dirs = torch.from_numpy(dirs_all[lo:lo + args.poses]).to(dev).contiguous()
     hp = HotPath(vol, src, dirs, args.samples, args.alpha, args.sampler, want_gvol=not args.no_gvol,
-                 layout=args.layout, sparse=not args.dense_grad)
+                 layout=args.layout, sparse=not args.dense_grad, persistent=not args.memset_grad)
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
 
     # --- the step: eager launches, or one captured hipGraph (compute) + the collective ---
@@ -321,7 +331,8 @@ def main():
 
     # --- single-pose latency (BASELINE config 2): 1 pose, fwd + bwd, eager and graph-replayed ---
     hp1 = HotPath(vol, src[:1].contiguous(), dirs[:1].contiguous(), args.samples, args.alpha, args.sampler,
-                  want_gvol=not args.no_gvol, layout=args.layout, sparse=not args.dense_grad)
+                  want_gvol=not args.no_gvol, layout=args.layout, sparse=not args.dense_grad,
+                  persistent=not args.memset_grad)
     for _ in range(5):
         hp1.step()
     sp = time_events(hp1.step, 20)
@@ -359,7 +370,7 @@ def main():
                              f"+ canonical gradient + per-pose loss gather"),
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": 0, "alpha": args.alpha,
-                "layout": args.layout, "grad_handback": "dense" if args.dense_grad else "sparse (touched bricks)", "issue": "hipGraph replay" if graph is not None else "eager",
+                "layout": args.layout, "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": "hipGraph replay" if graph is not None else "eager",
                 "parallelism": f"poses sharded x{ngpu}, volume replicated",
             },
             "roofline": {

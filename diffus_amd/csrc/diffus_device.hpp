@@ -389,6 +389,7 @@ struct Args {
     float *uout;       // backward, nullable (P*R,4): adjoint carry leaving towards the previous segment
     const float *zcin; // backward, nullable (P*R): d L/d imp contribution to this segment's LAST sample
     float *zcout;      // backward, nullable (P*R): contribution of this segment's first r to sample seg0-1
+    float *gsrc_out;   // scatter launch only, nullable (P,3): its P extra blocks sum gsrc_part over rays into it
     int accum_pose;    // backward: add to (instead of overwrite) the per-ray pose-gradient partials
     float neg_alpha;
     // forward
@@ -418,6 +419,29 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     unsigned xcd = b & 7u, q = nblk >> 3, rem = nblk & 7u;
     unsigned base = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
     return base + (b >> 3);
+}
+
+// gsrc[pose,:] = sum over rays of part[pose,:,:] in a fixed order (deterministic): one block of kBlock threads,
+// sm = 3*kBlock floats of LDS.  Used by reduce_gsrc_kernel and by the tail blocks of the scatter launch.
+__device__ __forceinline__ void reduce_gsrc_block(const float *__restrict__ part, float *__restrict__ gsrc, int R, int pose,
+                                                  float *sm)
+{
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < R; i += kBlock) {
+        const float *q = part + ((long)pose * R + i) * 3;
+        a0 += q[0]; a1 += q[1]; a2 += q[2];
+    }
+    sm[threadIdx.x] = a0; sm[kBlock + threadIdx.x] = a1; sm[2 * kBlock + threadIdx.x] = a2;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sm[threadIdx.x] += sm[threadIdx.x + s];
+            sm[kBlock + threadIdx.x] += sm[kBlock + threadIdx.x + s];
+            sm[2 * kBlock + threadIdx.x] += sm[2 * kBlock + threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) gsrc[pose * 3 + threadIdx.x] = sm[threadIdx.x * kBlock];
 }
 
 // ----------------------------------------------------------------------------

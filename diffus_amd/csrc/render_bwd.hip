@@ -354,24 +354,8 @@ __global__ void median_bwd_kernel(Args A)
 __global__ __launch_bounds__(kBlock) void reduce_gsrc_kernel(const float *__restrict__ part, float *__restrict__ gsrc,
                                                              int R)
 {
-    __shared__ float sm[3][kBlock];
-    const int pose = blockIdx.x;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int i = threadIdx.x; i < R; i += kBlock) {
-        const float *q = part + ((long)pose * R + i) * 3;
-        a0 += q[0]; a1 += q[1]; a2 += q[2];
-    }
-    sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = a2;
-    __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
-            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
-            sm[2][threadIdx.x] += sm[2][threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) gsrc[pose * 3 + threadIdx.x] = sm[threadIdx.x][0];
+    __shared__ float sm[3 * kBlock];
+    reduce_gsrc_block(part, gsrc, R, blockIdx.x, sm);
 }
 
 template <int SM, int LY, bool GPOSE, int PM>
@@ -482,7 +466,11 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
             }
         }
     }
+    // with start == 0 nothing touches the d/dsource partials after the scan, so their per-pose sum rides along
+    // as P extra blocks of the scatter launch instead of a launch of its own
+    const bool fold_gsrc = pose && gsrc && do_scan && gvol && do_scatter && start == 0;
     if (gvol && do_scatter) {
+        A.gsrc_out = fold_gsrc ? gsrc : nullptr;
         rc = diffus::launch_scatter(A, sampler, layout, st);
         if (rc) return rc;
     }
@@ -494,7 +482,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
         });
         if (rc) return rc;
     }
-    if (pose && gsrc && do_scan) {
+    if (pose && gsrc && do_scan && !fold_gsrc) {
         hipLaunchKernelGGL(reduce_gsrc_kernel, dim3(P), dim3(kBlock), 0, st, ws.gsrc_part, gsrc, R);
         if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
     }

@@ -33,7 +33,7 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
 }
 
 template <int SAMPLER, int LAYOUT, int PM>
-__global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_groups, int step_groups)
+__global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
 {
     // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
     // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
@@ -47,8 +47,12 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     __shared__ float s_sum[kWavesPerBlock];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
 
+    if (blockIdx.x >= npatch) { // tail blocks of the launch: d/dsource[pose] = fixed-order sum of the per-ray partials
+        reduce_gsrc_block(A.gsrc_part, A.gsrc_out, A.R, (int)(blockIdx.x - npatch), reinterpret_cast<float *>(tile));
+        return;
+    }
     // patch -> (pose, ray group, step group); the XCD remap keeps a pose on one XCD
-    const unsigned Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned Lb = xcd_remap(blockIdx.x, npatch);
     const int sg = Lb % step_groups;
     const int rg = (Lb / step_groups) % ray_groups;
     const int pose = Lb / (step_groups * ray_groups);
@@ -220,15 +224,16 @@ namespace diffus {
 int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
 {
     const int rgs = (A.R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
-    const unsigned nb = (unsigned)((long)A.P * rgs * sgs);
+    const unsigned np = (unsigned)((long)A.P * rgs * sgs);
+    const unsigned nb = np + (A.gsrc_out ? (unsigned)A.P : 0u);
     const bool f32 = !A.src_f64 && !A.dir_f64;
     const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout; // the scatter only sees the gradient
     return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
         constexpr int SM = decltype(S_)::value, LY = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
         if (f32)
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs, np);
         else
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs, np);
         return last_launch();
     });
 }
@@ -286,9 +291,13 @@ __global__ __launch_bounds__(kBlock) void brick_convert_kernel(const float *__re
 // its flag cleared, so the bricked buffer and the flags are all-zero again afterwards.  A fan touches
 // a few thousand of the 524 288 bricks of a 256^3 volume: this replaces a 64 MiB memset plus a
 // 128 MiB dense conversion per step.
+// mode DIFFUS_FLUSH_PERSISTENT: `out` is a gradient tensor the caller keeps across steps and only this call writes.
+// A brick stored this step gets flag 2 ("out holds last step's values, scratch is zero"); if the next step does not
+// touch it again (the scatter overwrites the flag with 1) its voxels are zeroed in `out` and the flag cleared.  `out`
+// therefore always equals the dense gradient of the latest step without ever being memset.
 __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict__ bricked, int *__restrict__ touched,
                                                                float *__restrict__ out, Geom G, long nbricks,
-                                                               int accumulate)
+                                                               int mode)
 {
     __shared__ int s_list[kWavesPerBlock][kWave];
     const int wib = threadIdx.x >> 6;
@@ -301,8 +310,9 @@ __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict
     unsigned long long m = __ballot(f != 0);
     if (m == 0) return; // wave-uniform: nothing touched in these 64 bricks
     if (f) {
-        touched[mine] = 0;
-        s_list[wib][__builtin_popcountll(m & ((1ull << lane) - 1))] = lane; // compact the touched ids
+        touched[mine] = (mode == DIFFUS_FLUSH_PERSISTENT && f == 1) ? 2 : 0;
+        // compact the touched ids; bit 6 marks a stale brick (nothing new, clear what the last step left)
+        s_list[wib][__builtin_popcountll(m & ((1ull << lane) - 1))] = lane | (f == 2 ? 64 : 0);
     }
     wave_lds_sync();
     const int cnt = __builtin_popcountll(m);
@@ -310,15 +320,19 @@ __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict
     // two bricks per step (one per half-wave); iterations are independent so their loads overlap
 #pragma unroll 4
     for (int i = half; i < cnt; i += 2) {
-        const long brick = b0 + s_list[wib][i];
-        float v = bricked[brick * kBrickFloats + o];
-        bricked[brick * kBrickFloats + o] = 0.f;
+        const int e = s_list[wib][i];
+        const long brick = b0 + (e & 63);
+        float v = 0.f;
+        if (!(e & 64)) { // wave-half-uniform
+            v = bricked[brick * kBrickFloats + o];
+            bricked[brick * kBrickFloats + o] = 0.f;
+        }
         long bz = brick % G.nb2, t = brick / G.nb2;
         long by = t % G.nb1, bx = t / G.nb1;
         int x = (int)bx * 4 + (o >> 3), y = (int)by * 4 + ((o >> 1) & 3), z = (int)bz * 2 + (o & 1);
         if (x < G.d0 && y < G.d1 && z < G.d2) {
             long a = ((long)x * G.d1 + y) * G.d2 + z;
-            out[a] = accumulate ? out[a] + v : v;
+            out[a] = (mode == DIFFUS_FLUSH_ACCUMULATE) ? out[a] + v : v;
         }
     }
 }
@@ -364,6 +378,7 @@ int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, f
                          diffus_stream_t stream)
 {
     if (!bricked || !touched || !vol || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    if (accumulate < DIFFUS_FLUSH_STORE || accumulate > DIFFUS_FLUSH_PERSISTENT) return DIFFUS_EINVAL;
     Geom G = make_geom(d0, d1, d2);
     const long nbricks = (long)(bricked_floats(d0, d1, d2) / kBrickFloats);
     const long waves = (nbricks + kWave - 1) / kWave;

@@ -218,11 +218,15 @@ __global__ __launch_bounds__(kBlock) void splat_gather_kernel(const float *__res
 
 // ----------------------------------------------------------------------------
 // Energy loss used by the benchmarks and examples: loss[p] = sum(frame[p]^2), gframe = 2 * frame,
-// in one streaming pass.  kLossSplit blocks per pose write partial sums, a second tiny kernel adds
+// in one streaming pass.  kLossSplit blocks per pose write partial sums, the last of them to arrive adds
 // them in a fixed order (deterministic; one block per pose alone used only P of the 256 CUs).
 constexpr int kLossSplit = 16;
-__global__ __launch_bounds__(kBlock) void loss_sumsq_kernel(const float *__restrict__ frame, float *__restrict__ part,
-                                                            float *__restrict__ gframe, long n)
+// The kLossSplit partial sums of a pose are handed to whichever of its blocks arrives last, which adds them in a
+// fixed order (deterministic) -- no second launch.  The hand-off is 4 bytes per block, so it uses write-through
+// (sc1) stores and loads around one relaxed agent-scope counter instead of fences (a release fence would write
+// back the XCD's whole L2, freshly dirtied by gframe).  The counter returns to 0 for the next call.
+__global__ __launch_bounds__(kBlock) void loss_sumsq_kernel(const float *__restrict__ frame, float *part, int *cnt,
+                                                            float *__restrict__ loss, float *__restrict__ gframe, long n)
 {
     __shared__ float sm[kWavesPerBlock];
     const long pz = blockIdx.y;
@@ -249,16 +253,19 @@ __global__ __launch_bounds__(kBlock) void loss_sumsq_kernel(const float *__restr
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[pz * kLossSplit + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-}
-
-__global__ void loss_finish_kernel(const float *__restrict__ part, float *__restrict__ loss, int P)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    float t = 0.f;
-    for (int i = 0; i < kLossSplit; ++i) t += part[p * kLossSplit + i];
-    loss[p] = t;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(part + pz * kLossSplit + blockIdx.x, (sm[0] + sm[1]) + (sm[2] + sm[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial has left this CU before the counter moves
+        const int prev = __hip_atomic_fetch_add(cnt + pz, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == kLossSplit - 1) { // every other block of this pose has published its partial
+            float t = 0.f;
+            for (int i = 0; i < kLossSplit; ++i)
+                t += __hip_atomic_load(part + pz * kLossSplit + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loss[pz] = t;
+            __hip_atomic_store(cnt + pz, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 } // namespace
@@ -339,10 +346,11 @@ int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gfr
                       size_t workspace_bytes, diffus_stream_t stream)
 {
     if (!frame || !loss || P <= 0 || n <= 0) return DIFFUS_EINVAL;
-    if (!workspace || workspace_bytes < sizeof(float) * (size_t)P * kLossSplit) return DIFFUS_EWORKSPACE;
-    float *part = (float *)workspace;
-    hipLaunchKernelGGL(loss_sumsq_kernel, dim3(kLossSplit, P), dim3(kBlock), 0, (hipStream_t)stream, frame, part, gframe, n);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, loss, P);
+    if (!workspace || workspace_bytes < (size_t)128 * P) return DIFFUS_EWORKSPACE;
+    int *cnt = (int *)workspace;                      // P arrival counters (zero between calls), then the partials
+    float *part = (float *)((char *)workspace + (size_t)64 * P);
+    hipLaunchKernelGGL(loss_sumsq_kernel, dim3(kLossSplit, P), dim3(kBlock), 0, (hipStream_t)stream, frame, part, cnt, loss,
+                       gframe, n);
     return last_launch();
 }
 

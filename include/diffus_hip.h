@@ -96,14 +96,21 @@ size_t diffus_workspace_bytes(int P, int R, int S, int start);
  */
 /*
  * Sparse gradient hand-back.  diffus_gradbuf_flush visits only the bricks whose flag is set:
- * adds (accumulate != 0) or stores them into the canonical (d0,d1,d2) tensor `vol`, zeroes them
+ * adds (mode ACCUMULATE) or stores them into the canonical (d0,d1,d2) tensor `vol`, zeroes them
  * in `bricked` and clears the flags -- so a buffer pair that starts all-zero is all-zero again
  * after the flush, and neither a 64 MiB memset nor a dense conversion is needed per step.
- * With accumulate == 0 only touched voxels are written: zero `vol` first if it must be dense.
+ * With mode STORE only touched voxels are written: zero `vol` first if it must be dense.
+ * Mode PERSISTENT is for a gradient tensor the caller keeps across steps (all-zero before the first one,
+ * written by nothing but this call, always with the same `touched` array): bricks stored by the previous
+ * call and not touched since are zeroed in `vol`, so `vol` always equals the dense gradient of the latest
+ * step and is never memset.  (`touched` then holds 2 for the bricks `vol` currently has values in.)
  */
+#define DIFFUS_FLUSH_STORE      0
+#define DIFFUS_FLUSH_ACCUMULATE 1
+#define DIFFUS_FLUSH_PERSISTENT 2
 size_t diffus_brick_count(int d0, int d1, int d2);
 int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, float *vol,
-                         int accumulate, diffus_stream_t stream);
+                         int mode, diffus_stream_t stream);
 
 size_t diffus_paired_floats(int d0, int d1, int d2);
 int diffus_pair_volume(const float *vol, int d0, int d1, int d2, float *paired,
@@ -244,10 +251,12 @@ int diffus_artifacts(const float *frame, int P, int R, int N,
 /*
  * Utility, not a reference function: the energy loss the benchmarks and examples
  * optimise.  loss[p] = sum(frame[p,:]^2) over the n floats of pose p, and (if
- * gframe != NULL) gframe = d loss / d frame = 2 * frame, in one streaming pass.
+ * gframe != NULL) gframe = d loss / d frame = 2 * frame, in one streaming pass, one launch.
+ * The workspace (>= 128 * P bytes) holds arrival counters: zero-fill it once before its first use; every
+ * call leaves it zero-filled where it matters.  Deterministic (fixed-order sum of 16 partials per pose).
  */
 int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe,
-                      void *workspace, size_t workspace_bytes /* >= 64 * P bytes */,
+                      void *workspace, size_t workspace_bytes /* >= 128 * P bytes, zeroed once */,
                       diffus_stream_t stream);
 
 /* ------------------------------------------------------------------------

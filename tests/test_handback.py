@@ -1,0 +1,108 @@
+"""Gradient hand-back and loss utility on the GPU: diffus_gradbuf_flush in its three modes (the PERSISTENT mode
+must leave exactly the dense gradient of the latest step in a tensor that is never memset) and diffus_loss_sumsq
+(one launch, last-arriving block adds the partials: deterministic, counters back to zero)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from diffus_amd.phantom import phantom, pose_ring
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hot():
+    import bench
+    return bench
+
+
+def vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
+def test_persistent_flush_equals_fresh_dense_gradient_every_step(hot, sampler):
+    n, R, S = 64, 24, 90
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, 12, R)
+    groups = [[0, 1, 2], [5, 6], [2, 9, 10, 11], [3], [0, 1, 2], [7, 8]]      # fans move: bricks appear and disappear
+    ref = None
+    per = None
+    for step, g in enumerate(groups * 2):
+        s = torch.from_numpy(src[g]).cuda().contiguous()
+        d = torch.from_numpy(dirs[g]).cuda().contiguous()
+        hp_ref = hot.HotPath(vol, s, d, S, 2e-3, sampler, persistent=False)
+        hp_ref.step()
+        hp = hot.HotPath(vol, s, d, S, 2e-3, sampler, persistent=True)
+        if per is not None:                    # carry the persistent tensor, scratch and flags across steps
+            hp.gvol, hp.gvol_k, hp.touched = per
+        assert hp.persistent
+        hp.step()
+        per = (hp.gvol, hp.gvol_k, hp.touched)
+        torch.cuda.synchronize()
+        # the same voxels are non-zero, nothing of earlier steps is left; values agree up to the order of the float atomics
+        assert torch.equal(hp.gvol != 0, hp_ref.gvol != 0), (step, g)
+        assert float((hp.gvol - hp_ref.gvol).abs().max()) <= 1e-5 * float(hp_ref.gvol.abs().max()), (step, g)
+        assert float(hp.gvol.abs().max()) > 0
+        assert torch.all(hp.gvol_k == 0)                              # the scratch is all-zero again
+        fl = hp.touched.cpu().numpy()
+        assert set(np.unique(fl)) <= {0, 2}
+        assert torch.equal(hp.gsrc, hp_ref.gsrc) and torch.equal(hp.gdirs, hp_ref.gdirs)
+        if ref is None:
+            ref = hp_ref.gvol.clone()
+    # a STORE flush on top of a persistent pair still works (stale bricks are cleared, flags return to 0)
+    hp.zero_grad = lambda: None
+    hp.persistent = False
+    hp.step()
+    torch.cuda.synchronize()
+    assert torch.equal(hp.gvol != 0, hp_ref.gvol != 0) and torch.all(hp.touched == 0)
+    assert float((hp.gvol - hp_ref.gvol).abs().max()) <= 1e-5 * float(hp_ref.gvol.abs().max())
+
+
+def test_flush_modes_direct():
+    from diffus_amd import _lib
+    lib = _lib.load()
+    d = (9, 10, 7)
+    nb = lib.diffus_brick_count(*d)
+    nf = lib.diffus_bricked_floats(*d)
+    g = torch.Generator().manual_seed(0)
+    bricked = torch.zeros(nf, device="cuda")
+    touched = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    vol = torch.full(d, 5.0, device="cuda")
+    dense = torch.randn(d, generator=g).cuda()
+    assert lib.diffus_brick_volume(vp(dense), *d, vp(bricked), None) == 0
+    touched[::3] = 1
+    assert lib.diffus_gradbuf_flush(vp(bricked), vp(touched), *d, vp(vol), 7, None) == -1      # unknown mode
+    assert lib.diffus_gradbuf_flush(vp(bricked), vp(touched), *d, vp(vol), 1, None) == 0       # accumulate
+    torch.cuda.synchronize()
+    changed = vol != 5.0
+    assert torch.allclose(vol[changed], dense[changed] + 5.0) and 0 < int(changed.sum()) < vol.numel()
+    assert torch.all(touched == 0)
+
+
+@pytest.mark.parametrize("P,n", [(1, 4), (3, 1000), (32, 256 * 512), (5, 131073)])
+def test_loss_sumsq_single_launch(P, n):
+    from diffus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(P + n)
+    frame = torch.randn(P, n, generator=g).cuda()
+    loss = torch.full((P,), -1.0, device="cuda")
+    gframe = torch.empty_like(frame)
+    ws = torch.zeros(max(128 * P, 256), dtype=torch.uint8, device="cuda")
+    busy = torch.randn(1 << 22, device="cuda")
+    outs = []
+    for it in range(6):                          # repeated calls: the arrival counters must come back to zero
+        if it % 2:
+            busy.mul_(1.0001)                     # uneven load beside it
+        loss.fill_(-1.0)
+        assert lib.diffus_loss_sumsq(vp(frame), P, n, vp(loss), vp(gframe), vp(ws), ws.numel(), None) == 0
+        torch.cuda.synchronize()
+        outs.append(loss.clone())
+    ref = (frame.double() ** 2).sum(1)
+    assert torch.allclose(outs[0].double(), ref, rtol=2e-6)
+    assert all(torch.equal(o, outs[0]) for o in outs)            # deterministic
+    assert torch.equal(gframe, 2 * frame)
+    assert torch.all(ws[:4 * P].view(torch.int32) == 0)
+    assert lib.diffus_loss_sumsq(vp(frame), P, n, vp(loss), None, vp(ws), 64 * P, None) == -4
