@@ -88,3 +88,50 @@ def test_random_backward_vs_autograd(seed):
             if sampler == "trilinear":
                 assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 5e-3, (seed, layout)
                 assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 5e-3, (seed, layout)
+
+
+def _long_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    dims = tuple(int(v) for v in rng.integers(20, 49, size=3))
+    vol = (1.5e6 + 2e5 * rng.standard_normal(dims)).astype(np.float32)
+    if seed % 3 == 1:
+        vol[rng.random(dims) < 0.1] = 6.4e6
+    R = int(rng.integers(1, 5))
+    S = int(rng.choice([1025, 1026, 1100, 2047, 2048, 2049, 2600]))
+    start = int(rng.integers(1, 40)) if seed % 2 else 0
+    centre = np.array(dims) / 2
+    src = centre + rng.normal(0, 0.25, 3) * np.array(dims)
+    dirs = rng.normal(0, 1, (R, 3))
+    dirs *= rng.uniform(0.01, 0.05, (R, 1)) / np.linalg.norm(dirs, axis=1, keepdims=True)   # short steps: stay inside
+    dt = np.float64 if seed % 4 == 2 else np.float32
+    return vol, src.astype(dt), dirs.astype(np.float32 if seed % 4 != 3 else np.float64), S, start, float(10 ** rng.uniform(-4, -3))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_long_rays_forward_and_backward(oracle, seed):
+    """S - start > 1024 (segmented launches) with random shapes, crops, dtypes; every layout and sampler."""
+    import diffus_amd
+    from oracle import autograd_ref as ar
+    vol, src, dirs, S, start, alpha = _long_case(seed)
+    for sampler in ("nearest", "trilinear"):
+        x, y, z, fo = oracle.plot_beam_frame(vol, src, dirs, S, alpha, start, sampler=sampler)
+        v64 = torch.from_numpy(vol).double().requires_grad_(True)
+        s64 = torch.from_numpy(src).double().requires_grad_(True)
+        d64 = torch.from_numpy(dirs).double().requires_grad_(True)
+        f64 = ar.render(v64, s64, d64, S, alpha, start, sampler)
+        up = torch.randn(f64.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+        (f64 * up).sum().backward()
+        for layout in ("canonical", "bricked", "paired"):
+            v = torch.from_numpy(vol).cuda().requires_grad_(True)
+            s = torch.from_numpy(src).cuda().requires_grad_(True)
+            d = torch.from_numpy(dirs).cuda().requires_grad_(True)
+            f, idx = diffus_amd.render_poses(v, s, d, S, alpha, start=start, sampler=sampler, return_indices=True, layout=layout)
+            np.testing.assert_array_equal(idx[0, 0].cpu().numpy(), x)
+            np.testing.assert_array_equal(idx[2, 0].cpu().numpy(), z)
+            assert maxnorm_rel(f[0].detach().cpu().numpy(), fo) < 5e-5, (seed, sampler, layout)
+            (f[0] * up.float().cuda()).sum().backward()
+            ref = v64.grad.numpy()
+            assert maxnorm_rel(v.grad.cpu().numpy(), ref) < 2e-3, (seed, sampler, layout)
+            if sampler == "trilinear":
+                assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 5e-3, (seed, layout)
+                assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 5e-3, (seed, layout)
