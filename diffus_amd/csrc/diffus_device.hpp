@@ -634,6 +634,11 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int 
                     g0[j] = live ? sm.g0 : 0.f;
                     g1[j] = live ? sm.g1 : 0.f;
                     g2[j] = live ? sm.g2 : 0.f;
+                    // Materialise the three gradient components HERE.  Left alone, LLVM sinks these lerps down to
+                    // their only use (the pose-gradient sum at the end of the backward) and keeps the 8 corner values
+                    // and 3 weights of every sample alive across the whole scan instead: 15 registers per sample, not 3
+                    // (render_bwd_kernel<8,...,GPOSE>: 237 VGPRs, 2 waves per SIMD).
+                    asm volatile("" : "+v"(g0[j]), "+v"(g1[j]), "+v"(g2[j]));
                 }
             }
         }
