@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     // overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel can
     // receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution,
     // typically 2^-23..2^-26; integer adds commute, so a tile sum is bitwise reproducible.
-    __shared__ int tile[kTileCap];
+    __shared__ __attribute__((aligned(16))) int tile[kTileCap];
     __shared__ int s_lo[3], s_hi[3], s_max;
     __shared__ float s_sum[kWavesPerBlock];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
@@ -76,10 +76,22 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
     float zmax = 0.f;
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
+    for (int q = 0; q < kSamplesPerThread; ++q) { // issue the loads first ...
         int n = nbase + q;
         zb[q] = 0.f;
         if (ray_ok && n < A.N1) zb[q] = A.zbar[w * A.N1 + n];
+    }
+    // ... and clear the WHOLE tile while they are in flight (12 ds_write_b128 per thread, ~400 cycles per block):
+    // clearing just the bounding box afterwards was a phase of its own with its own barrier (10 % of the block's time)
+    {
+        int4 *t4 = reinterpret_cast<int4 *>(tile);
+#pragma unroll
+        for (int e = 0; e < kTileCap / 4 / kBlock; ++e) t4[e * kBlock + tid] = make_int4(0, 0, 0, 0);
+        static_assert(kTileCap % (4 * kBlock) == 0, "tile clear assumes whole int4 passes");
+    }
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+        int n = nbase + q;
         if (!finitef(zb[q])) zb[q] = 0.f;
         cells[q] = cell_of<SAMPLER, PM>(A, ps, A.start + n);
         zmax = fmaxf(zmax, fabsf(zb[q]));
@@ -138,8 +150,6 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     // (s_sum total) * 2^fx in [2^28, 2^29): headroom for the rounding of each contribution
     const float ztot = fmaxf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]), __int_as_float(s_max));
     const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
-    for (int e = tid; e < nt; e += kBlock) tile[e] = 0;
-    __syncthreads();
     STAMP(3);
     // tile index = ex(i) + ey(j) + ez(k): three separable parts, each evaluated for the two
     // coordinates of its axis only (6 small computations per sample instead of 8 full ones)
@@ -181,22 +191,33 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     __syncthreads();
     STAMP(4);
     // Flush every touched entry once.  No integer division per entry (the first version's
-    // e -> (i,j,k) by three divisions was 80 us of VALU at config 3): walk (i, m = j*b2+k)
-    // and split m with one exact float-reciprocal division by the tiny b2.
-    const int b12 = b1 * b2;
-    const float rb2 = __frcp_rn((float)b2);
+    // e -> (i,j,k) by three divisions was 80 us of VALU at config 3): the flat unit index is split
+    // with two exact float-reciprocal divisions, and only for units that hold something.
+    const int b12 = b1 * b2, nunits = b0 * b12;
+    const float rb2 = __frcp_rn((float)b2), rb12 = __frcp_rn((float)b12);
     constexpr int LPU = (UNIT == 1) ? 1 : UNIT;          // lanes per tile unit
     const int o = (UNIT == 1) ? 0 : (tid & (LPU - 1));   // float inside the brick
     const int msub = tid / LPU, mstep = kBlock / LPU;
-    for (int i = 0; i < b0; ++i) {
-        for (int m = msub; m < b12; m += mstep) {
-            int v = tile[(i * b12 + m) * UNIT + o];
+    constexpr int FU = 4; // tile reads in flight per thread: the LDS latency is paid once per 4 units, not per unit
+    for (int q0 = msub; q0 < nunits; q0 += mstep * FU) {
+        int v[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int q = q0 + u * mstep;
+            v[u] = (q < nunits) ? tile[q * UNIT + o] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int q = q0 + u * mstep;
             // a half-wave = one brick (bricked) -- skip the address arithmetic for all-zero bricks
-            bool any = v != 0;
-            if (UNIT != 1) any = (unsigned)(__ballot(v != 0) >> (tid & 32)) != 0u;
+            bool any = v[u] != 0;
+            if (UNIT != 1) any = (unsigned)(__ballot(v[u] != 0) >> (tid & 32)) != 0u;
             if (any) {
-                int j = __float2int_rz(((float)m + 0.5f) * rb2); // exact: m < 2^14, b2 <= 2^14
-                int k = m - j * b2;
+                // exact float-reciprocal divisions: q < 2^14 and i * b12 <= q, m < b12 = b1 * b2
+                const int i = __float2int_rz(((float)q + 0.5f) * rb12);
+                const int m = q - i * b12;
+                const int j = __float2int_rz(((float)m + 0.5f) * rb2);
+                const int k = m - j * b2;
                 unsigned g;
                 if (LAYOUT == DIFFUS_CANONICAL)
                     g = ((unsigned)(l0 + i) * (unsigned)A.G.d1 + (unsigned)(l1 + j)) * (unsigned)A.G.d2 + (unsigned)(l2 + k);
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
                 // one plain, idempotent flag store per touched brick; no returning atomic (its latency
                 // would sit on the flush path)
                 if (LAYOUT == DIFFUS_BRICKED && A.gtouched && o == 0) A.gtouched[g >> 5] = 1;
-                if (v != 0) atomicAdd(A.gvol + g, ldexpf((float)v, -fx));
+                if (v[u] != 0) atomicAdd(A.gvol + g, ldexpf((float)v[u], -fx));
             }
         }
     }
