@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     // receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution,
     // typically 2^-23..2^-26; integer adds commute, so a tile sum is bitwise reproducible.
     __shared__ __attribute__((aligned(16))) int tile[kTileCap];
-    __shared__ int s_lo[3], s_hi[3], s_max;
+    __shared__ int s_wlo[kWavesPerBlock][3], s_whi[kWavesPerBlock][3], s_max; // per-WAVE boxes (4 rays x 64 steps each)
     __shared__ float s_sum[kWavesPerBlock];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
 
@@ -64,11 +64,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     const long w = (long)pose * A.R + (ray_ok ? ray : 0);
 
     STAMP(0);
-    if (tid < 3) {
-        s_lo[tid] = 0x7fffffff;
-        s_hi[tid] = -1;
-    }
-    if (tid == 3) s_max = 0;
+    if (tid == 0) s_max = 0;
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     Cell cells[kSamplesPerThread];
@@ -117,39 +113,93 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) zsum += __shfl_xor(zsum, off, kWave);
     __syncthreads();
+    const int wib = tid >> 6;
     if ((tid & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&s_lo[a], lo[a]);
-            atomicMax(&s_hi[a], hi[a]);
+            s_wlo[wib][a] = lo[a];
+            s_whi[wib][a] = hi[a];
         }
         atomicMax(&s_max, __float_as_int(zmax)); // non-negative floats order like their bit patterns
-        s_sum[tid >> 6] = zsum;
+        s_sum[wib] = zsum;
     }
     __syncthreads();
     STAMP(2);
-    const int l0 = s_lo[0], l1 = s_lo[1], l2 = s_lo[2];
-    if (s_hi[0] < 0) return; // nothing to add in this patch (block-uniform)
-    const int b0 = s_hi[0] - l0 + 1, b1 = s_hi[1] - l1 + 1, b2 = s_hi[2] - l2 + 1;
-    const long vol_tile = (long)b0 * b1 * b2 * UNIT;
-
-    if (vol_tile > kTileCap) { // block-uniform fallback: direct atomics
+    // The patch goes through the tile in ONE pass if its bounding box fits, else as 2 or 4 groups of waves (a wave =
+    // 4 rays x 64 steps, a thin strip), each with its own box.  (The first version sent oversized patches -- 1.4 % of
+    // them at config 3 -- to direct global atomics: those 58 blocks took 3x as long as the rest and were the kernel's
+    // tail; a 64 KiB tile without any fallback ran 62 us against 70.)
+    int wlo[kWavesPerBlock][3], whi[kWavesPerBlock][3]; // the four wave boxes, in registers
 #pragma unroll
-        for (int q = 0; q < kSamplesPerThread; ++q)
-            if (zb[q] != 0.f)
-                for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
-                    if (v != 0.f) {
-                        unsigned g = vox_off<LAYOUT>(A.G, i, j, k);
-                        atomicAdd(A.gvol + g, v);
-                        if (LAYOUT == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
-                    }
-                });
-        return;
+    for (int wv = 0; wv < kWavesPerBlock; ++wv)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            wlo[wv][a] = s_wlo[wv][a];
+            whi[wv][a] = s_whi[wv][a];
+        }
+    // box of the waves [w0, w0 + cnt) (compile-time cnt); volume 0 for an empty group, saturated when huge
+    auto box_of = [&](int w0, int cnt, int (&l)[3], int (&b)[3]) -> long {
+        long v = UNIT;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int mn = 0x7fffffff, mx = -1;
+#pragma unroll
+            for (int wv = 0; wv < kWavesPerBlock; ++wv) {
+                const bool in = wv >= w0 && wv < w0 + cnt;
+                mn = in ? min(mn, wlo[wv][a]) : mn;
+                mx = in ? max(mx, whi[wv][a]) : mx;
+            }
+            l[a] = mn;
+            b[a] = mx - mn + 1;
+            v = (mx < 0) ? 0 : v * b[a];
+            if (v > ((long)1 << 40)) v = (long)1 << 40; // only "> kTileCap" matters
+        }
+        return v;
+    };
+    static_assert(kWavesPerBlock == 4, "wave grouping below assumes 4 waves per block");
+    int nsub = 1;
+    {
+        int l[3], b[3];
+        if (box_of(0, 4, l, b) > kTileCap) {
+            nsub = 2;
+            if (box_of(0, 2, l, b) > kTileCap || box_of(2, 2, l, b) > kTileCap) nsub = 4;
+        }
     }
-    const int nt = (int)vol_tile;
     // (s_sum total) * 2^fx in [2^28, 2^29): headroom for the rounding of each contribution
     const float ztot = fmaxf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]), __int_as_float(s_max));
     const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
+    const int wpg = kWavesPerBlock / nsub; // waves per group
+#pragma unroll 1
+    for (int sp = 0; sp < nsub; ++sp) { // block-uniform trip count and branches
+    int lb[3], bb[3];
+    const long vol_tile = box_of(sp * wpg, wpg, lb, bb);
+    if (vol_tile == 0) continue; // nothing to add in this group
+    const bool mine = (wib / wpg) == sp;
+    // keep the per-sample weights INSIDE the trip: hoisted out of this (almost always single-trip) loop they cost
+    // 190 more registers and two of the three blocks per CU
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+        asm volatile("" : "+v"(zb[q]));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(cells[q].t[a]), "+v"(cells[q].i0[a]), "+v"(cells[q].i1[a]));
+    }
+    if (vol_tile > kTileCap) { // a single wave's strip does not fit (never seen with unit steps): direct atomics
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < kSamplesPerThread; ++q)
+                if (zb[q] != 0.f)
+                    for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
+                        if (v != 0.f) {
+                            unsigned g = vox_off<LAYOUT>(A.G, i, j, k);
+                            atomicAdd(A.gvol + g, v);
+                            if (LAYOUT == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
+                        }
+                    });
+        }
+        continue;
+    }
+    const int l0 = lb[0], l1 = lb[1], l2 = lb[2], b0 = bb[0], b1 = bb[1], b2 = bb[2];
+    const int nt = (int)vol_tile;
     STAMP(3);
     // tile index = ex(i) + ey(j) + ez(k): three separable parts, each evaluated for the two
     // coordinates of its axis only (6 small computations per sample instead of 8 full ones)
@@ -162,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     };
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q)
-        if (zb[q] != 0.f) {
+        if (mine && zb[q] != 0.f) {
             const Cell &c = cells[q];
             const float sc = ldexpf(zb[q], fx);
             if (SAMPLER == DIFFUS_NEAREST) {
@@ -205,6 +255,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         for (int u = 0; u < FU; ++u) {
             const int q = q0 + u * mstep;
             v[u] = (q < nunits) ? tile[q * UNIT + o] : 0;
+            if (nsub > 1 && v[u] != 0) tile[q * UNIT + o] = 0; // leave the tile clean for the next group
         }
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
@@ -234,9 +285,11 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
 #ifdef DIFFUS_STAMP
     if (threadIdx.x == 0 && g_stamps) {
         g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)nt;
-        g_stamps[(size_t)blockIdx.x * 8 + 7] = 1;
+        g_stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)nsub;
     }
 #endif
+    if (sp + 1 < nsub) __syncthreads(); // the next group adds into the tile this one has just read and cleared
+    } // groups
 }
 
 } // namespace
