@@ -102,7 +102,7 @@ class HotPath:
         self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
         self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
-        self.loss_ws = torch.zeros(max(128 * self.P, 256), dtype=torch.uint8, device=dev)   # arrival counters: zero once
+        self.loss_ws = torch.zeros(max(512 * self.P, 512), dtype=torch.uint8, device=dev)   # arrival counters: zero once
         nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, S, start), 256)
         self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         self.common = (vp(self.vol_k), d0, d1, d2, self.layout, vp(src), 0, vp(dirs), 0, self.P, self.R, S, start,

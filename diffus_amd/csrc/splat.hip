@@ -220,7 +220,8 @@ __global__ __launch_bounds__(kBlock) void splat_gather_kernel(const float *__res
 // Energy loss used by the benchmarks and examples: loss[p] = sum(frame[p]^2), gframe = 2 * frame,
 // in one streaming pass.  kLossSplit blocks per pose write partial sums, the last of them to arrive adds
 // them in a fixed order (deterministic; one block per pose alone used only P of the 256 CUs).
-constexpr int kLossSplit = 16;
+constexpr int kLossSplit = 16; // blocks per pose.  (64 streamed faster, 5 us, but 64 same-address counter adds per pose
+                               // serialise at the memory side: 25 us)
 // The kLossSplit partial sums of a pose are handed to whichever of its blocks arrives last, which adds them in a
 // fixed order (deterministic) -- no second launch.  The hand-off is 4 bytes per block, so it uses write-through
 // (sc1) stores and loads around one relaxed agent-scope counter instead of fences (a release fence would write
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void loss_sumsq_kernel(const float *__restr
     if (vec) {
         const float4 *f4 = reinterpret_cast<const float4 *>(f);
         float4 *g4 = reinterpret_cast<float4 *>(g);
+#pragma unroll 4
         for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n / 4; i += (long)kLossSplit * kBlock) {
             float4 v = f4[i];
             acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -253,15 +255,23 @@ __global__ __launch_bounds__(kBlock) void loss_sumsq_kernel(const float *__restr
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
+    __shared__ int s_last;
     if (threadIdx.x == 0) {
         __hip_atomic_store(part + pz * kLossSplit + blockIdx.x, (sm[0] + sm[1]) + (sm[2] + sm[3]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial has left this CU before the counter moves
         const int prev = __hip_atomic_fetch_add(cnt + pz, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == kLossSplit - 1) { // every other block of this pose has published its partial
-            float t = 0.f;
-            for (int i = 0; i < kLossSplit; ++i)
-                t += __hip_atomic_load(part + pz * kLossSplit + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == kLossSplit - 1; // every other block of this pose has published its partial
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < kWave) { // one wave: all partials in one round trip, then a fixed-order tree
+        static_assert(kLossSplit <= kWave, "one partial per lane");
+        float t = threadIdx.x < kLossSplit
+                      ? __hip_atomic_load(part + pz * kLossSplit + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, kWave);
+        if (threadIdx.x == 0) {
             loss[pz] = t;
             __hip_atomic_store(cnt + pz, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -346,9 +356,9 @@ int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gfr
                       size_t workspace_bytes, diffus_stream_t stream)
 {
     if (!frame || !loss || P <= 0 || n <= 0) return DIFFUS_EINVAL;
-    if (!workspace || workspace_bytes < (size_t)128 * P) return DIFFUS_EWORKSPACE;
+    if (!workspace || workspace_bytes < (size_t)512 * P) return DIFFUS_EWORKSPACE;
     int *cnt = (int *)workspace;                      // P arrival counters (zero between calls), then the partials
-    float *part = (float *)((char *)workspace + (size_t)64 * P);
+    float *part = (float *)((char *)workspace + (size_t)64 * P);   // kLossSplit floats per pose
     hipLaunchKernelGGL(loss_sumsq_kernel, dim3(kLossSplit, P), dim3(kBlock), 0, (hipStream_t)stream, frame, part, cnt, loss,
                        gframe, n);
     return last_launch();

@@ -252,11 +252,11 @@ int diffus_artifacts(const float *frame, int P, int R, int N,
  * Utility, not a reference function: the energy loss the benchmarks and examples
  * optimise.  loss[p] = sum(frame[p,:]^2) over the n floats of pose p, and (if
  * gframe != NULL) gframe = d loss / d frame = 2 * frame, in one streaming pass, one launch.
- * The workspace (>= 128 * P bytes) holds arrival counters: zero-fill it once before its first use; every
- * call leaves it zero-filled where it matters.  Deterministic (fixed-order sum of 16 partials per pose).
+ * The workspace (>= 512 * P bytes) holds arrival counters: zero-fill it once before its first use; every
+ * call leaves it zero-filled where it matters.  Deterministic (fixed-order tree sum of 16 partials per pose).
  */
 int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gframe,
-                      void *workspace, size_t workspace_bytes /* >= 128 * P bytes, zeroed once */,
+                      void *workspace, size_t workspace_bytes /* >= 512 * P bytes, zeroed once */,
                       diffus_stream_t stream);
 
 /* ------------------------------------------------------------------------
