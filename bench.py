@@ -224,15 +224,22 @@ def main():
     ap.add_argument("--alpha", type=float, default=1e-4)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 logic on a single GPU (every rank on cuda:0)")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: issue the loss all_gather on the compute stream (default: on its own stream, overlapping "
+                         "the next step's kernels)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: initialise torch.distributed even for a single rank, to exercise the N > 1 code path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -257,7 +264,11 @@ def main():
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
 
     # --- the step: eager launches, or one captured hipGraph (compute) + the collective ---
+    # Two loss buffers, used alternately (and one captured graph per buffer): with N > 1 the gather of step k reads
+    # its buffer on the communication stream while step k+1 already writes the other one.
+    loss_buf = [hp.loss, torch.empty_like(hp.loss)]
     graph = None
+    graphs = [None, None]
     side = torch.cuda.Stream()
     if not args.eager:
         try:
@@ -265,26 +276,61 @@ def main():
                 for _ in range(3):
                     hp.step()
             side.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                hp.step()
+            for b in range(2):
+                hp.loss = loss_buf[b]
+                graphs[b] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graphs[b], stream=side):
+                    hp.step()
+            graph = graphs[0]
         except Exception as e:  # capture unsupported -> eager, and say so
             print(f"hipGraph capture failed ({e!r}); running eagerly", file=sys.stderr)
             graph = None
+        hp.loss = loss_buf[0]
+
+    # The one collective of the path: all_gather of the P per-pose losses (P x 4 bytes per rank) over xGMI.  A small
+    # RCCL collective is tens of microseconds of pure latency -- a quarter of the 0.14 ms step -- so by default it
+    # runs on its own stream, reading step k's loss buffer while step k+1 writes the other one (an event per buffer
+    # orders reuse).  Every gather has completed before the closing barrier of the timed region.
+    overlap = dist is not None and args.dist_backend == "nccl" and not args.sync_gather
+    if overlap:
+        try:
+            comm = torch.cuda.Stream()
+            gathered = [torch.empty((P_total,), dtype=torch.float32, device=dev) for _ in range(2)]
+            step_ev = [torch.cuda.Event() for _ in range(2)]
+            gather_ev = [torch.cuda.Event() for _ in range(2)]
+        except Exception as e:
+            print(f"overlapped gather unavailable ({e!r}); gathering on the compute stream", file=sys.stderr)
+            overlap = False
+    kstep = [0]
 
     def step():
+        b = kstep[0] & 1 if overlap else 0
+        if overlap:
+            main = torch.cuda.current_stream()
+            if kstep[0] >= 2:
+                main.wait_event(gather_ev[b])          # loss buffer b is free again (gather k-2 has finished)
+            hp.loss = loss_buf[b]
         if graph is not None:
-            graph.replay()
+            graphs[b].replay()
         else:
             hp.step()
-        if dist is not None and args.dist_backend == "nccl":
-            dist.all_gather_into_tensor(losses_all, hp.loss)   # the one collective: P losses over xGMI
+        if overlap:
+            kstep[0] += 1
+            step_ev[b].record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(step_ev[b])
+                dist.all_gather_into_tensor(gathered[b], loss_buf[b])
+                gather_ev[b].record(comm)
+        elif dist is not None and args.dist_backend == "nccl":
+            dist.all_gather_into_tensor(losses_all, hp.loss)
         elif dist is not None:                                  # gloo rehearsal: through host memory
             out = torch.empty(P_total, dtype=torch.float32)
             dist.all_gather_into_tensor(out, hp.loss.cpu())
             losses_all.copy_(out)
 
     def barrier():
+        if overlap:
+            torch.cuda.current_stream().wait_stream(comm)       # every gather issued so far is part of the step count
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -295,12 +341,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_ms = (time.perf_counter() - t0) * 1e3 / args.steps   # host time to ENQUEUE one step (no device wait)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if overlap:
+            losses_all.copy_(gathered[(kstep[0] - 1) & 1])
         # every rank must hold all P losses, in pose order, and they must be finite
         assert torch.isfinite(losses_all).all() and float(losses_all.abs().min()) > 0, "loss gather failed"
     ray_steps = P_total * args.rays * args.samples
@@ -371,7 +420,9 @@ def main():
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": 0, "alpha": args.alpha,
                 "layout": args.layout, "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": "hipGraph replay" if graph is not None else "eager",
-                "parallelism": f"poses sharded x{ngpu}, volume replicated",
+                "parallelism": f"poses sharded x{ngpu}, volume replicated", "host_enqueue_ms_per_step": host_ms,
+                "loss_gather": ("none (1 GPU)" if dist is None else
+                                ("all_gather on its own stream, overlapping the next step" if overlap else "all_gather on the compute stream")),
             },
             "roofline": {
                 "bound": "hbm",
