@@ -545,6 +545,19 @@ __device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a
     return s;
 }
 
+// Loads at a 32-bit ELEMENT offset from a wave-uniform base: byte offset formed in 32 bits (element offsets are
+// < 2^30, check_common) so that the compiler emits `global_load v, v_off, s[base]` (SGPR base + 32-bit VGPR offset)
+// instead of building a 64-bit address per lane per load (v_lshl_add_u64 / v_mad_u64_u32: 64 of the forward's 1330
+// VALU instructions).
+__device__ __forceinline__ float ld_f32(const float *base, unsigned off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(off << 2));
+}
+__device__ __forceinline__ float2 ld_f32x2(const float *base, unsigned off)
+{
+    return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)(off << 2));
+}
+
 #ifndef DIFFUS_GATHER_GROUP
 #define DIFFUS_GATHER_GROUP 8
 #endif
@@ -575,17 +588,17 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int 
             float p0 = ray_point<PM>(ps, 0, k), p1 = ray_point<PM>(ps, 1, k), p2 = ray_point<PM>(ps, 2, k);
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
                 int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
-                raw[jj][0] = vol[col_off<LAYOUT>(A.G, i0, i1) + z_off<LAYOUT>(i2)];
+                raw[jj][0] = ld_f32(vol, col_off<LAYOUT>(A.G, i0, i1) + z_off<LAYOUT>(i2));
             } else {
                 Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1), c = tri_axis(p2, A.G.d2);
                 unsigned c00 = col_off<LAYOUT>(A.G, a.i0, b.i0), c01 = col_off<LAYOUT>(A.G, a.i0, b.i1);
                 unsigned c10 = col_off<LAYOUT>(A.G, a.i1, b.i0), c11 = col_off<LAYOUT>(A.G, a.i1, b.i1);
                 unsigned z0 = z_off<LAYOUT>(c.i0), z1 = z_off<LAYOUT>(c.i1);
                 if constexpr (LAYOUT == DIFFUS_PAIRED) { // 4 aligned 8-byte loads: (z0, z0+1) of each column
-                    float2 q00 = *reinterpret_cast<const float2 *>(vol + (c00 + z0));
-                    float2 q01 = *reinterpret_cast<const float2 *>(vol + (c01 + z0));
-                    float2 q10 = *reinterpret_cast<const float2 *>(vol + (c10 + z0));
-                    float2 q11 = *reinterpret_cast<const float2 *>(vol + (c11 + z0));
+                    float2 q00 = ld_f32x2(vol, c00 + z0);
+                    float2 q01 = ld_f32x2(vol, c01 + z0);
+                    float2 q10 = ld_f32x2(vol, c10 + z0);
+                    float2 q11 = ld_f32x2(vol, c11 + z0);
                     raw[jj][0] = q00.x; raw[jj][1] = q00.y; raw[jj][2] = q01.x; raw[jj][3] = q01.y;
                     raw[jj][4] = q10.x; raw[jj][5] = q10.y; raw[jj][6] = q11.x; raw[jj][7] = q11.y;
                     (void)z1;
@@ -596,10 +609,10 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int 
                 raw[jj][4] = __uint_as_float(c10 + z0); raw[jj][5] = __uint_as_float(c10 + z1);
                 raw[jj][6] = __uint_as_float(c11 + z0); raw[jj][7] = __uint_as_float(c11 + z1);
 #else
-                raw[jj][0] = vol[c00 + z0]; raw[jj][1] = vol[c00 + z1];
-                raw[jj][2] = vol[c01 + z0]; raw[jj][3] = vol[c01 + z1];
-                raw[jj][4] = vol[c10 + z0]; raw[jj][5] = vol[c10 + z1];
-                raw[jj][6] = vol[c11 + z0]; raw[jj][7] = vol[c11 + z1];
+                raw[jj][0] = ld_f32(vol, c00 + z0); raw[jj][1] = ld_f32(vol, c00 + z1);
+                raw[jj][2] = ld_f32(vol, c01 + z0); raw[jj][3] = ld_f32(vol, c01 + z1);
+                raw[jj][4] = ld_f32(vol, c10 + z0); raw[jj][5] = ld_f32(vol, c10 + z1);
+                raw[jj][6] = ld_f32(vol, c11 + z0); raw[jj][7] = ld_f32(vol, c11 + z1);
 #endif
                 }
                 ta[jj] = a.t; tb[jj] = b.t; tc[jj] = c.t;

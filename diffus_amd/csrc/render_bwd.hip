@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     const bool accum_pose = SEG && A.accum_pose;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 48 more registers
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: ray-derived addresses stay scalar
     const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
     if (w >= (long)A.P * A.R) return;
     const int lane = threadIdx.x & 63;

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
     const float *const cin = SEG ? A.cin : nullptr;
     float *const cout = SEG ? A.cout : nullptr;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: ray-derived addresses stay scalar
     const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
     if (w >= (long)A.P * A.R) return; // wave-uniform; no block-level barrier below
     const int lane = threadIdx.x & 63;
