@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         L = mat_step(L, r[j]);
-        lam -= mat_renorm(L);
+        if ((j & 3) == 3 || j == C - 1) lam -= mat_renorm(L); // every 4th step is enough (echo_chunk, FAST)
     }
     const Mat Lloc = L;   // normalised local product T_first..T_last
     const int lamloc = lam;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     for (int j = 0; j < C; ++j) {
         Pin[j] = Pm;
         Pm = mat_step(Pm, r[j]);
-        ex[j] = mat_renorm(Pm);
+        ex[j] = ((j & 3) == 3 || j == C - 1) ? mat_renorm(Pm) : 0; // compile-time schedule: the zeros fold away
         esum += ex[j];
         float rd = __builtin_amdgcn_rcpf(Pm.d);
         float e = Pm.b * rd;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
             W.b = U.b + gu[j];
             W.c = U.c;
             W.d = U.d - gu[j] * rho[j];
-            W = mat_scale(W, -ex[j]);
+            if ((j & 3) == 3 || j == C - 1) W = mat_scale(W, -ex[j]);
             if (rbar) {
                 Mat Tb = mat_mul_at(Pin[j], W);
                 rbar[j] = __builtin_fmaf(-4.f * r[j], Tb.a, Tb.b - Tb.c);
