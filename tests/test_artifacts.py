@@ -74,3 +74,21 @@ def test_hip_artifacts_seeded_noise_statistics_and_plot_beam_frame():
     assert torch.isfinite(o1).all() and (o1 >= 0).all()
     with pytest.raises(ZeroDivisionError):
         diffus_amd.apply_artifacts(f, 0.1, 0.05, 0.0, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,N,max_sigma", [(40, 70, 3.0), (37, 150, 7.6), (90, 65, 12.0), (5, 33, 4.0), (300, 700, 4.0)])
+def test_hip_artifacts_vs_oracle_shapes_and_radii(R, N, max_sigma):
+    """Tile borders, rays fewer than the blur radius (repeated reflection), and both blur paths: weights in LDS
+    (radius <= 30) and the direct form beyond it."""
+    import diffus_amd
+    from oracle import artifacts as oa
+    rng = np.random.default_rng(R * 1000 + N)
+    f = np.abs(rng.normal(0.0, 1.0, size=(2, R, N))).astype(np.float32)
+    rs, ls = oa.noise_scales(N, 0.05, 0.1)
+    radial = rng.normal(1.0, rs, size=(2, N))
+    local = rng.normal(1.0, ls[None, None, :], size=(2, R, N))
+    out = diffus_amd.apply_artifacts(torch.from_numpy(f).cuda(), 0.05, 0.1, max_sigma, 2.5, noise=(radial, local)).cpu().numpy()
+    for p in range(2):
+        ref = oa.chain(f[p], 0.05, 0.1, max_sigma, 2.5, radial[p], local[p])
+        assert maxnorm_rel(out[p], ref) < 1e-12, (p, R, N, max_sigma)
