@@ -426,12 +426,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
 __device__ __forceinline__ void reduce_gsrc_block(const float *__restrict__ part, float *__restrict__ gsrc, int R, int pose,
                                                   float *sm)
 {
+    // the first kBlock threads of the block do the work; a larger block only has to reach the barriers
+    const bool act = threadIdx.x < kBlock;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int i = threadIdx.x; i < R; i += kBlock) {
-        const float *q = part + ((long)pose * R + i) * 3;
-        a0 += q[0]; a1 += q[1]; a2 += q[2];
+    if (act)
+        for (int i = threadIdx.x; i < R; i += kBlock) {
+            const float *q = part + ((long)pose * R + i) * 3;
+            a0 += q[0]; a1 += q[1]; a2 += q[2];
+        }
+    if (act) {
+        sm[threadIdx.x] = a0; sm[kBlock + threadIdx.x] = a1; sm[2 * kBlock + threadIdx.x] = a2;
     }
-    sm[threadIdx.x] = a0; sm[kBlock + threadIdx.x] = a1; sm[2 * kBlock + threadIdx.x] = a2;
     __syncthreads();
     for (int s = kBlock / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {

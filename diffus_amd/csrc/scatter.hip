@@ -32,8 +32,15 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
     return axis == 2 ? (v >> 1) : (v >> 2);
 }
 
+// threads per scatter block.  The patch stays 16 rays x 64 steps and the tile 48 KiB (3 blocks per CU); 512 threads
+// (2 samples each, twice the waves per CU) measured 70 us against 58 for 256: the barriers over 8 waves cost more than
+// the extra waves hide.
+#ifndef DIFFUS_SCATTER_THREADS
+#define DIFFUS_SCATTER_THREADS 256
+#endif
+constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kPatchRays * kPatchSteps / kSB;
 template <int SAMPLER, int LAYOUT, int PM>
-__global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
+__global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
 {
     // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
     // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
@@ -43,8 +50,8 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     // receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution,
     // typically 2^-23..2^-26; integer adds commute, so a tile sum is bitwise reproducible.
     __shared__ __attribute__((aligned(16))) int tile[kTileCap];
-    __shared__ int s_wlo[kWavesPerBlock][3], s_whi[kWavesPerBlock][3], s_max; // per-WAVE boxes (4 rays x 64 steps each)
-    __shared__ float s_sum[kWavesPerBlock];
+    __shared__ int s_wlo[kSW][3], s_whi[kSW][3], s_max; // per-WAVE boxes (a wave = 64 / kSW rays x 64 steps)
+    __shared__ float s_sum[kSW];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
 
     if (blockIdx.x >= npatch) { // tail blocks of the launch: d/dsource[pose] = fixed-order sum of the per-ray partials
@@ -58,8 +65,8 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     const int pose = Lb / (step_groups * ray_groups);
     const int tid = threadIdx.x;
     // thread -> ray (tid / 16) and 4 consecutive steps ((tid % 16) * 4 ..)
-    const int ray = rg * kPatchRays + tid / (kPatchSteps / kSamplesPerThread);
-    const int nbase = sg * kPatchSteps + (tid % (kPatchSteps / kSamplesPerThread)) * kSamplesPerThread;
+    const int ray = rg * kPatchRays + tid / (kPatchSteps / kSPT);
+    const int nbase = sg * kPatchSteps + (tid % (kPatchSteps / kSPT)) * kSPT;
     const bool ray_ok = ray < A.R;
     const long w = (long)pose * A.R + (ray_ok ? ray : 0);
 
@@ -67,12 +74,12 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     if (tid == 0) s_max = 0;
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
-    Cell cells[kSamplesPerThread];
-    float zb[kSamplesPerThread];
+    Cell cells[kSPT];
+    float zb[kSPT];
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
     float zmax = 0.f;
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) { // issue the loads first ...
+    for (int q = 0; q < kSPT; ++q) { // issue the loads first ...
         int n = nbase + q;
         zb[q] = 0.f;
         if (ray_ok && n < A.N1) zb[q] = A.zbar[w * A.N1 + n];
@@ -82,11 +89,11 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     {
         int4 *t4 = reinterpret_cast<int4 *>(tile);
 #pragma unroll
-        for (int e = 0; e < kTileCap / 4 / kBlock; ++e) t4[e * kBlock + tid] = make_int4(0, 0, 0, 0);
-        static_assert(kTileCap % (4 * kBlock) == 0, "tile clear assumes whole int4 passes");
+        for (int e = 0; e < kTileCap / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
+        static_assert(kTileCap % (4 * kSB) == 0, "tile clear assumes whole int4 passes");
     }
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
+    for (int q = 0; q < kSPT; ++q) {
         int n = nbase + q;
         if (!finitef(zb[q])) zb[q] = 0.f;
         cells[q] = cell_of<SAMPLER, PM>(A, ps, A.start + n);
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     zmax = __int_as_float(wave_reduce_minmax<false>(__float_as_int(zmax))); // zmax >= 0: bits order like floats
     float zsum = 0.f;
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) zsum += fabsf(zb[q]);
+    for (int q = 0; q < kSPT; ++q) zsum += fabsf(zb[q]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) zsum += __shfl_xor(zsum, off, kWave);
     __syncthreads();
@@ -129,9 +136,9 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     // 4 rays x 64 steps, a thin strip), each with its own box.  (The first version sent oversized patches -- 1.4 % of
     // them at config 3 -- to direct global atomics: those 58 blocks took 3x as long as the rest and were the kernel's
     // tail; a 64 KiB tile without any fallback ran 62 us against 70.)
-    int wlo[kWavesPerBlock][3], whi[kWavesPerBlock][3]; // the four wave boxes, in registers
+    int wlo[kSW][3], whi[kSW][3]; // the four wave boxes, in registers
 #pragma unroll
-    for (int wv = 0; wv < kWavesPerBlock; ++wv)
+    for (int wv = 0; wv < kSW; ++wv)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             wlo[wv][a] = s_wlo[wv][a];
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         for (int a = 0; a < 3; ++a) {
             int mn = 0x7fffffff, mx = -1;
 #pragma unroll
-            for (int wv = 0; wv < kWavesPerBlock; ++wv) {
+            for (int wv = 0; wv < kSW; ++wv) {
                 const bool in = wv >= w0 && wv < w0 + cnt;
                 mn = in ? min(mn, wlo[wv][a]) : mn;
                 mx = in ? max(mx, whi[wv][a]) : mx;
@@ -156,19 +163,22 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
         }
         return v;
     };
-    static_assert(kWavesPerBlock == 4, "wave grouping below assumes 4 waves per block");
+    static_assert(kSW == 4 || kSW == 8, "wave grouping below: 1, 2 or 4 groups of waves");
     int nsub = 1;
     {
         int l[3], b[3];
-        if (box_of(0, 4, l, b) > kTileCap) {
+        if (box_of(0, kSW, l, b) > kTileCap) {
             nsub = 2;
-            if (box_of(0, 2, l, b) > kTileCap || box_of(2, 2, l, b) > kTileCap) nsub = 4;
+            if (box_of(0, kSW / 2, l, b) > kTileCap || box_of(kSW / 2, kSW / 2, l, b) > kTileCap) nsub = 4;
         }
     }
     // (s_sum total) * 2^fx in [2^28, 2^29): headroom for the rounding of each contribution
-    const float ztot = fmaxf((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]), __int_as_float(s_max));
+    float ztot = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < kSW; ++wv) ztot += s_sum[wv];
+    ztot = fmaxf(ztot, __int_as_float(s_max));
     const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
-    const int wpg = kWavesPerBlock / nsub; // waves per group
+    const int wpg = kSW / nsub; // waves per group
 #pragma unroll 1
     for (int sp = 0; sp < nsub; ++sp) { // block-uniform trip count and branches
     int lb[3], bb[3];
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     // keep the per-sample weights INSIDE the trip: hoisted out of this (almost always single-trip) loop they cost
     // 190 more registers and two of the three blocks per CU
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
+    for (int q = 0; q < kSPT; ++q) {
         asm volatile("" : "+v"(zb[q]));
 #pragma unroll
         for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(cells[q].t[a]), "+v"(cells[q].i0[a]), "+v"(cells[q].i1[a]));
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     if (vol_tile > kTileCap) { // a single wave's strip does not fit (never seen with unit steps): direct atomics
         if (mine) {
 #pragma unroll
-            for (int q = 0; q < kSamplesPerThread; ++q)
+            for (int q = 0; q < kSPT; ++q)
                 if (zb[q] != 0.f)
                     for_each_corner<SAMPLER>(cells[q], zb[q], [&](int i, int j, int k, float v) {
                         if (v != 0.f) {
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
                                       : (((v >> 1) - l2) * kBrickFloats + (v & 1)));
     };
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q)
+    for (int q = 0; q < kSPT; ++q)
         if (mine && zb[q] != 0.f) {
             const Cell &c = cells[q];
             const float sc = ldexpf(zb[q], fx);
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void scatter_patch_kernel(Args A, int ray_g
     const float rb2 = __frcp_rn((float)b2), rb12 = __frcp_rn((float)b12);
     constexpr int LPU = (UNIT == 1) ? 1 : UNIT;          // lanes per tile unit
     const int o = (UNIT == 1) ? 0 : (tid & (LPU - 1));   // float inside the brick
-    const int msub = tid / LPU, mstep = kBlock / LPU;
+    const int msub = tid / LPU, mstep = kSB / LPU;
     constexpr int FU = 4; // tile reads in flight per thread: the LDS latency is paid once per 4 units, not per unit
     for (int q0 = msub; q0 < nunits; q0 += mstep * FU) {
         int v[FU];
@@ -305,9 +315,9 @@ int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
     return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
         constexpr int SM = decltype(S_)::value, LY = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
         if (f32)
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs, np);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kSB), 0, st, A, rgs, sgs, np);
         else
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), dim3(nb), dim3(kBlock), 0, st, A, rgs, sgs, np);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), dim3(nb), dim3(kSB), 0, st, A, rgs, sgs, np);
         return last_launch();
     });
 }
