@@ -26,7 +26,8 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     float *const uout = SEG ? A.uout : nullptr, *const zcout = SEG ? A.zcout : nullptr;
     const bool accum_pose = SEG && A.accum_pose;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
-    constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 48 more registers
+    constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 12 KiB more LDS per wave
+    __shared__ float stash[KEEP_GRAD ? WPB : 1][KEEP_GRAD ? 3 * kWave * C : 1];
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: ray-derived addresses stay scalar
     const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
     if (w >= (long)A.P * A.R) return;
@@ -34,12 +35,26 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     const long pose = w / A.R;
     const int n0 = lane * C;
     float *wb = lds[wib];
+    float *gst = stash[KEEP_GRAD ? wib : 0];
 
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
-    float zi[C], gi0[C], gi1[C], gi2[C], z[C], r[C], gb[C];
-    gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD, PM>(A, seg0, segN, ps, lane, zi, gi0, gi1, gi2);
+    float zi[C], z[C], r[C], gb[C];
+    {
+        // The spatial gradient of every sample is needed once more, at the very end (pose gradient): it waits in LDS
+        // (lane-private slots, conflict-free), not in 3C registers across the whole scan.
+        float gi0[C], gi1[C], gi2[C];
+        gather_interleaved<C, SAMPLER, LAYOUT, KEEP_GRAD, PM>(A, seg0, segN, ps, lane, zi, gi0, gi1, gi2);
+        if (KEEP_GRAD) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                gst[(0 * C + j) * kWave + lane] = gi0[j];
+                gst[(1 * C + j) * kWave + lane] = gi1[j];
+                gst[(2 * C + j) * kWave + lane] = gi2[j];
+            }
+        }
+    }
     to_chunked<C>(wb, lane, zi, z);
     {
         // upstream gradient row, read as 256-B runs, attenuation folded in
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
                 int k = A.start + seg0 + n;
                 float q0, q1, q2;
                 if (KEEP_GRAD) {
-                    q0 = gi0[j]; q1 = gi1[j]; q2 = gi2[j];
+                    q0 = gst[(0 * C + j) * kWave + lane]; q1 = gst[(1 * C + j) * kWave + lane]; q2 = gst[(2 * C + j) * kWave + lane];
                 } else {
                     TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point<PM>(ps, 0, k), ray_point<PM>(ps, 1, k),
                                                            ray_point<PM>(ps, 2, k));
