@@ -110,6 +110,15 @@ def _pose_dtype(t: torch.Tensor) -> torch.dtype:
     return torch.float64 if t.dtype == torch.float64 else torch.float32
 
 
+def _as(t: torch.Tensor, dev: torch.device, dtype: torch.dtype) -> torch.Tensor:
+    """t.detach().to(dev, dtype).contiguous() without dispatching the ops that would be no-ops (each costs
+    microseconds of host time, and a training step through autograd is host-bound)."""
+    t = t.detach()
+    if t.device != dev or t.dtype != dtype:
+        t = t.to(device=dev, dtype=dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -209,18 +218,20 @@ class _Problem:
             self.dev = _device_for(volume)
             self.shape = tuple(shape)
             self.vol = None
-            self.bricked = volume.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+            self.bricked = _as(volume, self.dev, torch.float32)
         else:
             if volume.dim() != 3:
                 raise ValueError(f"volume must be 3-D, got shape {tuple(volume.shape)}")
             self.dev = _device_for(volume)
             self.shape = tuple(volume.shape)
-            self.vol = volume.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+            self.vol = _as(volume, self.dev, torch.float32)
             self.bricked = None
         self._layout_req, self._vol_src = layout, volume
         sd, dd = _pose_dtype(sources), _pose_dtype(directions)
-        self.src = sources.detach().to(device=self.dev, dtype=sd).reshape(-1, 3).contiguous()
-        d = directions.detach().to(device=self.dev, dtype=dd)
+        self.src = _as(sources, self.dev, sd).reshape(-1, 3)
+        if not self.src.is_contiguous():
+            self.src = self.src.contiguous()
+        d = _as(directions, self.dev, dd)
         if d.dim() == 1:
             d = d.unsqueeze(0)
         self.P = self.src.shape[0]
@@ -228,7 +239,7 @@ class _Problem:
             d = d.unsqueeze(0).expand(self.P, -1, -1)
         if d.dim() != 3 or d.shape[0] != self.P or d.shape[-1] != 3:
             raise ValueError(f"directions must be (R,3) or (P,R,3); got {tuple(directions.shape)} for P={self.P}")
-        self.dirs = d.contiguous()
+        self.dirs = d if d.is_contiguous() else d.contiguous()
         self.R = self.dirs.shape[1]
         self.S, self.start, self.alpha = int(S), int(start), float(alpha)
         self.N1 = self.S - self.start
@@ -279,7 +290,7 @@ class _RenderFn(torch.autograd.Function):
         vdev, vdt, sdev, sdt, sshape, ddev, ddt, dshape = ctx.meta
         need_v, need_s, need_d = ctx.needs_input_grad[:3]
         with torch.cuda.device(pb.dev):
-            g = gframe.detach().to(device=pb.dev, dtype=torch.float32).contiguous()
+            g = _as(gframe, pb.dev, torch.float32)
             gvol = touched = None
             sparse = False
             if need_v:      # gradient buffer in the layout that goes with the volume's
@@ -301,8 +312,12 @@ class _RenderFn(torch.autograd.Function):
                 rc = lib.diffus_gradbuf_flush(_ptr(gvol), _ptr(touched), *pb.shape, _ptr(dense), 0, _stream(pb.dev))
                 _lib.check(rc, "diffus_gradbuf_flush")
                 gvol = dense
-        out_v = gvol.to(device=vdev, dtype=vdt) if need_v else None
-        out_s = gsrc.reshape(sshape).to(device=sdev, dtype=sdt) if need_s else None
+        out_v = (gvol if (gvol.device == vdev and gvol.dtype == vdt) else gvol.to(device=vdev, dtype=vdt)) if need_v else None
+        out_s = None
+        if need_s:
+            out_s = gsrc.reshape(sshape)
+            if out_s.device != sdev or out_s.dtype != sdt:
+                out_s = out_s.to(device=sdev, dtype=sdt)
         out_d = None
         if need_d:
             if len(dshape) == 3:
@@ -311,7 +326,8 @@ class _RenderFn(torch.autograd.Function):
                 out_d = gdirs.sum(0)
             else:
                 out_d = gdirs.sum(0).reshape(dshape)
-            out_d = out_d.to(device=ddev, dtype=ddt)
+            if out_d.device != ddev or out_d.dtype != ddt:
+                out_d = out_d.to(device=ddev, dtype=ddt)
         return out_v, out_s, out_d, None, None, None, None, None, None, None
 
 
