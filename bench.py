@@ -254,7 +254,8 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     P_total = args.poses * ngpu
-    vol = torch.from_numpy(phantom(args.n)).to(dev)
+    # config 5 (--n 512): one distinct volume per GPU -- the phantom variant (tumour position) is the rank
+    vol = torch.from_numpy(phantom(args.n, variant=rank if args.n >= 512 else 0)).to(dev)
     src_all, dirs_all = pose_ring(args.n, P_total, args.rays)
     lo = rank * args.poses
     src = torch.from_numpy(src_all[lo:lo + args.poses]).to(dev).contiguous()
