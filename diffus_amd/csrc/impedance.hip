@@ -84,7 +84,9 @@ __global__ __launch_bounds__(kBlock, 4) void mlp_fwd_kernel(MlpArgs A)
         }
         xv = __fdiv_rn(xv - A.shift, A.div); // zscore_normalize, reference src/utils.py:38
         const float x0 = __shfl(xv, r, kWave), x1 = __shfl(xv, 32 + r, kWave);
-        f32x16 D0 = {0}, D1 = {0};
+        f32x16 D0, D1; // accumulators start at the bias b2 (row idx(i,h) lives in register i): no add afterwards
+#pragma unroll
+        for (int i = 0; i < 16; ++i) D0[i] = D1[i] = b2h[i];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float hb0 = fmaxf(__builtin_fmaf(w1h[i], x0, b1h[i]), 0.f); // B operand: h1[voxel r][j = idx(i,h)]
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(kBlock, 4) void mlp_fwd_kernel(MlpArgs A)
         float s0 = 0.f, s1 = 0.f; // D[i] = pre-activation of hidden unit idx(i,h) at voxel r
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            s0 = __builtin_fmaf(w3h[i], fmaxf(D0[i] + b2h[i], 0.f), s0);
-            s1 = __builtin_fmaf(w3h[i], fmaxf(D1[i] + b2h[i], 0.f), s1);
+            s0 = __builtin_fmaf(w3h[i], fmaxf(D0[i], 0.f), s0);
+            s1 = __builtin_fmaf(w3h[i], fmaxf(D1[i], 0.f), s1);
         }
         s0 += __shfl_xor(s0, 32, kWave);
         s1 += __shfl_xor(s1, 32, kWave);
@@ -169,7 +171,12 @@ __global__ __launch_bounds__(kBlock) void mlp_bwd_kernel(MlpArgs A)
         }
         // forward, both orientations
         float hb[16];
-        f32x16 D = {0}, Dt = {0};
+        f32x16 D, Dt; // start at the bias: row k = idx(i,h) of D in register i, column k = r of Dt in every register
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            D[i] = b2h[i];
+            Dt[i] = b2l;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             hb[i] = fmaxf(__builtin_fmaf(w1h[i], xl, b1h[i]), 0.f); // h1[voxel r][j = idx(i,h)]
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(kBlock) void mlp_bwd_kernel(MlpArgs A)
         float g2[16], g2q[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            g2[i] = (D[i] + b2h[i] > 0.f) ? w3h[i] * gyl : 0.f;
-            const float a2 = Dt[i] + b2l;
+            g2[i] = (D[i] > 0.f) ? w3h[i] * gyl : 0.f;
+            const float a2 = Dt[i];
             g2q[i] = (a2 > 0.f) ? w3l * gq[i] : 0.f;
             aw3 = __builtin_fmaf(fmaxf(a2, 0.f), gq[i], aw3);
             ab2 += g2q[i];
