@@ -106,3 +106,38 @@ def test_loss_sumsq_single_launch(P, n):
     assert torch.equal(gframe, 2 * frame)
     assert torch.all(ws[:4 * P].view(torch.int32) == 0)
     assert lib.diffus_loss_sumsq(vp(frame), P, n, vp(loss), None, vp(ws), 256 * P, None) == -4
+
+
+def test_step_is_hipgraph_capturable_and_replays_on_new_inputs(hot):
+    """The C-ABI never allocates or synchronises: a whole step (forward, loss, backward, persistent flush) is captured
+    once and replayed after the poses and the volume were changed IN PLACE; results equal the eager step's."""
+    n, P, R, S = 64, 3, 24, 1100                      # S > 1024: the segmented launches are captured too
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, 8, R)
+    s = torch.from_numpy(src[:P]).cuda().contiguous()
+    d = (torch.from_numpy(dirs[:P]) * 0.05).cuda().contiguous()
+    hp = hot.HotPath(vol, s, d, S, 1e-3, "trilinear", layout="bricked")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            hp.step()
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        hp.step()
+    # new inputs, in place (the bricked copy of the volume is part of the caller's state here: rebuild it in place too)
+    s.copy_(torch.from_numpy(src[4:4 + P]).cuda())
+    vol.mul_(1.01)
+    from diffus_amd import _lib
+    _lib.check(hp.lib.diffus_brick_volume(vp(vol), *hp.dims, vp(hp.vol_k), None), "brick")
+    g.replay()
+    torch.cuda.synchronize()
+    got = (hp.frame.clone(), hp.loss.clone(), hp.gvol.clone(), hp.gsrc.clone(), hp.gdirs.clone())
+    ref = hot.HotPath(vol, s, d, S, 1e-3, "trilinear", layout="bricked", persistent=False)
+    ref.step()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], ref.frame) and torch.equal(got[1], ref.loss)
+    assert torch.equal(got[3], ref.gsrc) and torch.equal(got[4], ref.gdirs)
+    assert torch.equal(got[2] != 0, ref.gvol != 0)
+    assert float((got[2] - ref.gvol).abs().max()) <= 1e-5 * float(ref.gvol.abs().max())
+    assert float(ref.gvol.abs().max()) > 0 and float(ref.frame.abs().max()) > 0
