@@ -18,7 +18,7 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
            "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd",
            "diffus_artifacts_workspace_bytes", "diffus_artifacts",
            "diffus_mlp_fwd", "diffus_mlp_workspace_bytes", "diffus_mlp_bwd", "diffus_brain_mask_workspace_bytes",
-           "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats")
+           "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats", "diffus_rows_conv1d")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
@@ -100,6 +100,8 @@ def load():
     lib.diffus_masked_stats_workspace_bytes.argtypes = []
     lib.diffus_masked_stats.restype = i
     lib.diffus_masked_stats.argtypes = [vp, vp, sz, vp, vp, sz, vp]
+    lib.diffus_rows_conv1d.restype = i
+    lib.diffus_rows_conv1d.argtypes = [vp, i, i, vp, i, i, vp, vp]
     if lib.diffus_abi_version() != 1:
         raise DiffusError("libdiffus_hip.so ABI version mismatch")
     _lib = lib

@@ -175,6 +175,23 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
     }
 }
 
+// Rows correlated with a short kernel, zero padding (torch conv1d semantics: no flip): the pulse stage of
+// compute_gaussian_pulse, reference src/renderer.py:477.  out[b][m] = sum_t k[t] * in[b][m + t - pad], m < M.
+__global__ __launch_bounds__(kBlock) void rows_conv1d_kernel(const float *__restrict__ in, const float *__restrict__ k,
+                                                             float *__restrict__ out, int B, int N, int L, int pad, int M)
+{
+    const long total = (long)B * M;
+    for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long)gridDim.x * kBlock) {
+        const int b = (int)(e / M), m = (int)(e - (long)b * M);
+        float acc = 0.f;
+        for (int t = 0; t < L; ++t) {
+            const int j = m + t - pad;
+            if (j >= 0 && j < N) acc = __builtin_fmaf(k[t], in[(long)b * N + j], acc);
+        }
+        out[e] = acc;
+    }
+}
+
 template <int SM, int LY, int PM>
 int launch_fwd_t(const Args &A, hipStream_t st)
 {
@@ -298,6 +315,19 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stre
     case 8: hipLaunchKernelGGL(echo_traces_kernel<8>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
     default: hipLaunchKernelGGL(echo_traces_kernel<16>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
     }
+    return last_launch();
+}
+
+int diffus_rows_conv1d(const float *in, int B, int N, const float *kernel, int L, int pad, float *out,
+                       diffus_stream_t stream)
+{
+    if (!in || !kernel || !out || B <= 0 || N <= 0 || L <= 0 || pad < 0) return DIFFUS_EINVAL;
+    const long M = (long)N + 2L * pad - L + 1;
+    if (M <= 0 || M > 0x7fffffffL) return DIFFUS_EINVAL;
+    const long total = (long)B * M;
+    unsigned nb = (unsigned)((total + kBlock - 1) / kBlock);
+    if (nb > 4096u) nb = 4096u;
+    hipLaunchKernelGGL(rows_conv1d_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, in, kernel, out, B, N, L, pad, (int)M);
     return last_launch();
 }
 

@@ -394,14 +394,25 @@ def gaussian_pulse(length: int, sigma: float):
 
 def compute_gaussian_pulse(refLR: torch.Tensor, spacing: float = 1.0, c: float = 1.54e3, length: int = 10,
                            sigma: int = 1, pulse=None) -> torch.Tensor:
-    """Echo traces convolved with a Gaussian pulse (reference src/renderer.py:459-479): the echo
-    series comes from the HIP kernel (diffus_echo_traces), the short conv1d stays in torch."""
-    echo_signals, _ = compute_echo_traces(refLR, spacing, c)
-    if pulse is None:
-        pulse = gaussian_pulse(length=length, sigma=sigma)
-        pulse = torch.tensor(pulse, dtype=echo_signals.dtype, device=echo_signals.device).unsqueeze(0).unsqueeze(0)
-    echo_signals = torch.nn.functional.conv1d(echo_signals.unsqueeze(1), pulse, padding=length // 2)
-    return echo_signals.squeeze(1)
+    """Echo series of every ray passed through the transducer pulse (reference src/renderer.py:459-479): echo traces
+    by diffus_echo_traces, then each row correlated with the pulse (`length` taps, `length // 2` zeros of padding on
+    both sides, like the F.conv1d at :477) by diffus_rows_conv1d.  `pulse` may be given as a (1,1,L) tensor like the
+    reference's; the default is gaussian_pulse(length, sigma)."""
+    lib = _lib.load()
+    echo, _ = compute_echo_traces(refLR, spacing, c)
+    dev = echo.device if echo.is_cuda else _device_for(echo)
+    taps = gaussian_pulse(length=length, sigma=sigma) if pulse is None else pulse
+    taps = _as(torch.as_tensor(taps, dtype=torch.float32).reshape(-1), dev, torch.float32)
+    e = _as(echo, dev, torch.float32)
+    B, N = e.shape
+    L, pad = int(taps.numel()), length // 2
+    M = N + 2 * pad - L + 1
+    if M <= 0:
+        raise RuntimeError("Kernel size can't be greater than actual input size")     # what F.conv1d raises
+    with torch.cuda.device(dev):
+        out = torch.empty((B, M), dtype=torch.float32, device=dev)
+        _lib.check(lib.diffus_rows_conv1d(_ptr(e), B, N, _ptr(taps), L, pad, _ptr(out), _stream(dev)), "diffus_rows_conv1d")
+    return out.to(echo.device)
 
 
 class UltrasoundRenderer:

@@ -207,6 +207,13 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo,
                        diffus_stream_t stream);
 
 /*
+ * The pulse stage of compute_gaussian_pulse (reference src/renderer.py:459-479, the F.conv1d at :477): every row of
+ * `in` (B,N) correlated with `kernel` (L taps, no flip) with `pad` zeros on both sides -> out (B, N + 2*pad - L + 1).
+ */
+int diffus_rows_conv1d(const float *in, int B, int N, const float *kernel, int L, int pad, float *out,
+                       diffus_stream_t stream);
+
+/*
  * Scan conversion (the step after the path): replaces
  * differentiable_splat (reference src/renderer.py:694-737) for P frames at once.
  *   c0, c1  (P,n) float32: the two plotted coordinates of every sample (the
