@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void splat_winner_kernel(const float *__res
     }
 }
 
-// The same, privatised: a block takes a patch of 16 rows x 64 columns of the (rows, cols) sample
+// The same, privatised: a block takes a patch of kPatchRays rows x kPatchSteps columns of the (rows, cols) sample
 // grid (adjacent rays x consecutive steps: a compact pixel footprint), resolves the winner per
 // pixel in an LDS tile over the patch's pixel bounding box (ds_max_i32), and issues ONE global
 // atomicMax per touched pixel.  Falls back to the direct form when the box does not fit.
