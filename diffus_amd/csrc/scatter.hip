@@ -32,7 +32,7 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
     return axis == 2 ? (v >> 1) : (v >> 2);
 }
 
-// threads per scatter block.  The patch stays kPatchRays x kPatchSteps = 1024 samples and the tile 48 KiB (3 blocks per CU); 512 threads
+// threads per scatter block.  The patch stays kPatchRays x kPatchSteps = 1024 samples and the tile 24 KiB (6 blocks per CU); 512 threads
 // (2 samples each, twice the waves per CU) measured 70 us against 58 for 256: the barriers over 8 waves cost more than
 // the extra waves hide.
 #ifndef DIFFUS_SCATTER_THREADS
