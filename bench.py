@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: before any GPU call
+it starts N child ranks (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1), waits
+for them and exits non-zero if any of them failed.  Under torch.distributed.run the ranks already exist and the
+process is one of them.  Rank 0 prints the one JSON line.
+
 Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays x
 512 steps.  One *step* = one pass of the hot path over one batch of poses:
   forward frame (diffus_render_fwd)
@@ -21,28 +26,34 @@ reported separately as `single_pose`).  Multi-GPU: poses shard contiguously over
 ranks, 32 per GPU (weak scaling; N=8 is BASELINE config 4), the volume is
 replicated, the only collective is one all_gather of P losses.
 
-Inputs (volume -- canonical and its bricked copy --, poses) are resident in HBM
-before the timed region.  The step is issued either eagerly or, by default, as a
+Inputs (volume -- canonical and its converted copy --, poses) are resident in HBM
+before the timed region.  The step (diffus_amd.CapturedStep) is issued either eagerly or, by default, as a
 captured hipGraph replay (the C-ABI never syncs or allocates, so it captures).
 Kernel durations for the roofline come from HIP events recorded on the launch
 stream (torch's current stream, which is the one handed to the C-ABI).
+
+`roofline` carries two figures for the dominant kernel: `achieved` = the no-reuse ALGORITHMIC bytes
+over its live launch time, and `measured_hbm_GBs` = HBM-side bytes of the committed rocprofv3 PMC passes for
+exactly this workload (profiles/*_pmc_*.json) over the same time.  `bound` names what the counters say limits
+the kernel; it is "hbm" only when the measured traffic is near the HBM rate.
+
+`callers` (N = 1 only) times the shapes the reference's notebooks actually run: the REUBEN demo frame
+(start > 0, artifacts, splat), a learnable volume (re-converted every step) and poses that move every step.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from diffus_amd import _lib  # noqa: E402
-from diffus_amd.phantom import phantom, pose_ring  # noqa: E402
 
 # Algorithmic bytes per ray-step, no-reuse model (SURVEY §8d / DESIGN.md §Roofline), per kernel:
 #   fwd      8 corner reads x 4 B + 4 B frame write                         = 36 (nearest: 4 + 4 = 8)
@@ -53,106 +64,104 @@ BYTES = {
     "nearest": {"render_fwd_kernel": 8, "render_bwd_kernel": 8, "scatter_patch_kernel": 8},
 }
 HBM_PEAK_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--poses", type=int, default=32, help="poses per GPU")
+    ap.add_argument("--rays", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=512)
+    ap.add_argument("--start", type=int, default=0, help="start crop (reference src/renderer.py:237-244)")
+    ap.add_argument("--n", type=int, default=256, help="volume edge")
+    ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
+    ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
+    ap.add_argument("--layout", default="paired", choices=["paired", "bricked", "canonical"])
+    ap.add_argument("--learnable-volume", action="store_true",
+                    help="re-convert the volume to the kernels' layout inside every step (a volume an optimiser updates)")
+    ap.add_argument("--memset-grad", action="store_true",
+                    help="zero the whole canonical gradient tensor every step instead of keeping it persistent "
+                         "(diffus_gradbuf_flush mode STORE instead of PERSISTENT)")
+    ap.add_argument("--dense-grad", action="store_true",
+                    help="hand the gradient back by a dense conversion instead of the touched-brick flush")
+    ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-callers", action="store_true", help="skip the `callers` legs (demo shape, learnable volume, moving poses)")
+    ap.add_argument("--alpha", type=float, default=1e-4)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 logic on a single GPU (every rank on cuda:0)")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: issue the loss all_gather on the compute stream (default: on its own stream, overlapping "
+                         "the next step's kernels)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: initialise torch.distributed even for a single rank, to exercise the N > 1 code path")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work at all: ranks rendezvous (gloo), gather stand-in losses and time empty steps; "
+                         "checks the launcher / rendezvous / gather / max-over-ranks logic on a CPU-only box")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank exits 3 before the rendezvous
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own N ranks.  Nothing here touches the GPU (torch.cuda.device_count()
+# does not initialise it on this image); the children are ordinary child processes, never an exec of this one.
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args) -> int:
+    n = args.gpus
+    if args.dist_backend == "nccl" and not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (use --dist-backend gloo to rehearse {n} ranks "
+                  f"on one GPU)", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0 owns stdout (the one JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, kill_at = 0, None
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:          # a rank failed: the others would wait in a collective for ever
+                rc = code if 0 < code < 256 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending.values():
+                    q.terminate()
+                kill_at = time.time() + 10
+        if kill_at is not None and pending and time.time() > kill_at:
+            for q in pending.values():
+                q.kill()
+            kill_at = None
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-class HotPath:
-    """Pre-allocated buffers + direct C-ABI calls (what a captured training step does)."""
-
-    def __init__(self, vol, src, dirs, S, alpha, sampler, start=0, want_gvol=True, layout="paired", sparse=True,
-                 persistent=True):
-        self.lib = _lib.load()
-        self.vol, self.src, self.dirs = vol, src, dirs
-        self.layout = {"canonical": 0, "bricked": 1, "paired": 2}[layout]
-        self.P, self.R = dirs.shape[0], dirs.shape[1]
-        self.S, self.start, self.alpha = S, start, alpha
-        self.sampler = {"nearest": 0, "trilinear": 1}[sampler]
-        dev = vol.device
-        self.N1 = S - start
-        self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
-        self.gframe = torch.empty_like(self.frame)
-        d0, d1, d2 = vol.shape
-        self.dims = (d0, d1, d2)
-        # canonical gradient, what the caller gets.  persistent: the tensor is kept across steps and
-        # diffus_gradbuf_flush(PERSISTENT) clears what the previous step left where this step adds nothing, so it
-        # always equals this step's dense gradient without a 64 MiB memset per step.
-        self.persistent = persistent and sparse and want_gvol and self.layout != 0
-        self.gvol = torch.zeros_like(vol) if want_gvol else None
-        if self.layout != 0:
-            # HBM-resident converted copy of the (constant) volume, made once outside the timed region;
-            # the bricked gradient scratch is zeroed, filled and converted back EVERY step.
-            nb = self.lib.diffus_bricked_floats(d0, d1, d2)
-            if self.layout == 1:
-                self.vol_k = torch.empty(nb, dtype=torch.float32, device=dev)
-                _lib.check(self.lib.diffus_brick_volume(vp(vol), d0, d1, d2, vp(self.vol_k), self.stream()), "brick")
-            else:
-                self.vol_k = torch.empty(self.lib.diffus_paired_floats(d0, d1, d2), dtype=torch.float32, device=dev)
-                _lib.check(self.lib.diffus_pair_volume(vp(vol), d0, d1, d2, vp(self.vol_k), self.stream()), "pair")
-            # sparse gradient hand-back: the bricked scratch and its touched-brick flags are all-zero
-            # between steps (diffus_gradbuf_flush restores that), only touched bricks are converted
-            self.gvol_k = torch.zeros(nb, dtype=torch.float32, device=dev) if want_gvol else None
-            self.touched = (torch.zeros(self.lib.diffus_brick_count(d0, d1, d2), dtype=torch.int32, device=dev)
-                            if (want_gvol and sparse) else None)
-        else:
-            self.vol_k, self.gvol_k, self.touched = vol, self.gvol, None
-        self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
-        self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
-        self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
-        self.loss_ws = torch.zeros(max(512 * self.P, 512), dtype=torch.uint8, device=dev)   # arrival counters: zero once
-        nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, S, start), 256)
-        self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        self.common = (vp(self.vol_k), d0, d1, d2, self.layout, vp(src), 0, vp(dirs), 0, self.P, self.R, S, start,
-                       float(alpha), self.sampler)
-
-    def stream(self):
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def fwd(self):
-        _lib.check(self.lib.diffus_render_fwd(*self.common, vp(self.frame), None, vp(self.ws), self.ws.numel(),
-                                              self.stream()), "diffus_render_fwd")
-
-    def bwd(self, stages=_lib.BWD_ALL):
-        _lib.check(self.lib.diffus_render_bwd(*self.common, vp(self.gframe), vp(self.gvol_k), vp(self.touched),
-                                              vp(self.gsrc), vp(self.gdirs), stages, vp(self.ws), self.ws.numel(),
-                                              self.stream()), "diffus_render_bwd")
-
-    def loss_and_grad(self):
-        _lib.check(self.lib.diffus_loss_sumsq(vp(self.frame), self.P, self.R * self.N1, vp(self.loss),
-                                              vp(self.gframe), vp(self.loss_ws), self.loss_ws.numel(), self.stream()),
-                   "diffus_loss_sumsq")
-
-    def zero_grad(self):
-        """A fresh dense gradient every step: zero the caller's canonical (d0,d1,d2) tensor (sparse
-        hand-back), or the bricked scratch (dense hand-back: the conversion overwrites every voxel)."""
-        if self.gvol is not None and not self.persistent:
-            (self.gvol if (self.touched is not None or self.layout == 0) else self.gvol_k).zero_()
-
-    def finish_grad(self):
-        """touched bricks of the scratch -> added into the canonical gradient; scratch back to all-zero."""
-        if self.layout != 0 and self.gvol is not None and self.touched is not None:
-            # accumulate = 0: the tensor was zeroed this step and every touched voxel is written once
-            _lib.check(self.lib.diffus_gradbuf_flush(vp(self.gvol_k), vp(self.touched), *self.dims, vp(self.gvol),
-                                                     2 if self.persistent else 0, self.stream()), "diffus_gradbuf_flush")
-        elif self.layout != 0 and self.gvol is not None:
-            _lib.check(self.lib.diffus_unbrick_volume(vp(self.gvol_k), *self.dims, vp(self.gvol), 0, self.stream()),
-                       "diffus_unbrick_volume")
-
-    def step(self):
-        # (a forked stream for zero_grad beside the forward was measured: the fork/join events cost
-        # more than the 10 us they hide -- 0.217 vs 0.202 ms/step -- so the step stays on one stream)
-        self.fwd()
-        self.loss_and_grad()
-        self.zero_grad()
-        self.bwd()
-        self.finish_grad()
-
-
 def time_events(fn, iters, pre=None):
     """Device time of fn() in ms (mean, median, min): HIP events on the current (launch) stream."""
+    import torch
     e0 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     e1 = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     for i in range(iters):
@@ -166,10 +175,25 @@ def time_events(fn, iters, pre=None):
     return {"mean": sum(ts) / len(ts), "median": ts[len(ts) // 2], "min": ts[0]}
 
 
+def time_wall(fn, iters, warm=3):
+    """Wall ms per call, device drained at both ends (what a Python caller waits for)."""
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / iters
+
+
 def cpu_baseline(budget_rays=64, budget_steps=256):
     """The reference's algorithm (N+1 dense torch.linalg.solve, oracle/dense.py) on
     the host cores, on a bounded sample: config 1 = 64 rays x 256 steps, forward
     only (the dense backward needs ~rays*steps^3 memory)."""
+    import torch
+    from diffus_amd.phantom import phantom, pose_ring
     from oracle import dense
     from oracle import oracle as orc
     n = 256
@@ -202,38 +226,169 @@ def cpu_baseline(budget_rays=64, budget_steps=256):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--poses", type=int, default=32, help="poses per GPU")
-    ap.add_argument("--rays", type=int, default=256)
-    ap.add_argument("--samples", type=int, default=512)
-    ap.add_argument("--n", type=int, default=256, help="volume edge")
-    ap.add_argument("--sampler", default="trilinear", choices=["trilinear", "nearest"])
-    ap.add_argument("--no-gvol", action="store_true", help="pose-gradient-only backward")
-    ap.add_argument("--layout", default="paired", choices=["paired", "bricked", "canonical"])
-    ap.add_argument("--memset-grad", action="store_true",
-                    help="zero the whole canonical gradient tensor every step instead of keeping it persistent "
-                         "(diffus_gradbuf_flush mode STORE instead of PERSISTENT)")
-    ap.add_argument("--dense-grad", action="store_true",
-                    help="hand the gradient back by a dense conversion instead of the touched-brick flush")
-    ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--alpha", type=float, default=1e-4)
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo = rehearsal of the N>1 logic on a single GPU (every rank on cuda:0)")
-    ap.add_argument("--sync-gather", action="store_true",
-                    help="N > 1: issue the loss all_gather on the compute stream (default: on its own stream, overlapping "
-                         "the next step's kernels)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="debug: initialise torch.distributed even for a single rank, to exercise the N > 1 code path")
-    args = ap.parse_args()
+def workload_key(args):
+    """What a PMC summary must have been collected on to speak for this run."""
+    return {"n": args.n, "poses": args.poses, "rays": args.rays, "samples": args.samples, "start": args.start,
+            "sampler": args.sampler, "layout": args.layout}
 
+
+def find_pmc_summary(key):
+    """Newest committed profiles/*pmc*.json whose `workload` equals `key` (None if there is none)."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json"))):
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if pm.get("workload") == key:
+            best = (os.path.relpath(f, ROOT), pm)          # names sort by round: the last match is the newest
+    return best
+
+
+def config_label(args, ngpu):
+    """Which BASELINE.json config (if any) this run is."""
+    shape2 = (args.rays, args.samples, args.start) == (256, 512, 0)
+    if args.n == 256 and shape2 and args.poses == 32:
+        return "BASELINE config 3" if ngpu == 1 else ("BASELINE config 4" if ngpu == 8 else f"BASELINE config 4 shape at {ngpu} of 8 GPUs")
+    if args.n == 256 and shape2 and args.poses == 1 and ngpu == 1:
+        return "BASELINE config 2"
+    if args.n == 512 and (args.rays, args.samples, args.start) == (512, 1024, 0):
+        return f"BASELINE config 5 shape ({args.poses} poses per 512^3 volume, one volume per GPU)"
+    return "custom workload (not a BASELINE.json config)"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# `callers`: the shapes the reference's notebooks run (SURVEY App. C), N = 1 only
+def callers_legs(args, vol, dev):
+    import numpy as np
+    import torch
+    import diffus_amd
+    from diffus_amd import CapturedStep
+    from diffus_amd.phantom import pose_ring
+    out = {}
+    n = args.n
+    # (a) `[DEMO] REUBEN DATA 46` cell 14: 256 rays x 185 samples, start = 40, artifacts=True, alpha = 1e-4, an f64
+    #     apex outside the volume, then differentiable_splat onto 256 x 256 (sigma = 1) -- through the drop-in API
+    R, S, start = 256, 185, 40
+    source = torch.tensor([88.0769, -11.5385, 110.0], dtype=torch.float64) * (n / 256.0)
+    dirs = diffus_amd.generate_cone_directions(np.array([0.35, 0.94]), np.radians(52.47), R)
+    rend = diffus_amd.UltrasoundRenderer(num_samples=S, attenuation_coeff=1e-4)
+
+    def demo_frame():
+        x, y, z, I = rend.plot_beam_frame(volume=vol, source=source, directions=dirs, plot=False, artifacts=True,
+                                          start=start, seed=0)
+        return diffus_amd.differentiable_splat(x, y, z, I, H=256, W=256, sigma=1)
+
+    def demo_render_only():
+        return rend.plot_beam_frame(volume=vol, source=source, directions=dirs, plot=False, artifacts=False, start=start)
+
+    ms_full = time_wall(demo_frame, 20)
+    ms_render = time_wall(demo_render_only, 20)
+    out["demo_reuben46"] = {
+        "call": "UltrasoundRenderer(185, 1e-4).plot_beam_frame(artifacts=True, start=40) + differentiable_splat(256x256, sigma=1), "
+                "nearest sampling, f64 apex outside the volume (reference notebooks/[DEMO] REUBEN DATA 46.ipynb cell 14)",
+        "ms_per_frame_wall": ms_full, "ms_plot_beam_frame_only_wall": ms_render,
+        "ray_steps_per_s": R * S / (ms_full * 1e-3),
+        "reference_published": "2.54 s/frame on the authors' laptop CPU at 200 rays x 150 samples (BASELINE.md)"}
+    # the same shape as a batch of 32 captured training steps (forward + loss + backward with the start-crop median)
+    src32, dirs32 = pose_ring(n, 32, R)
+    s32 = torch.from_numpy(src32).to(dev)
+    d32 = torch.from_numpy(dirs32).to(dev)
+    for sampler in ("trilinear", "nearest"):
+        st = CapturedStep(vol, s32, d32, S, 1e-4, sampler, start=start, layout=args.layout)
+        st.capture()
+        ms = time_events(st.replay, 30)["median"]
+        out["demo_reuben46"][f"batch32_fwd_bwd_{sampler}_ms"] = ms
+        out["demo_reuben46"][f"batch32_fwd_bwd_{sampler}_ray_steps_per_s"] = 32 * R * S / (ms * 1e-3)
+        del st
+    # (b) a learnable volume: the optimiser changes it every step, so the layout conversion is part of the step
+    leg = {}
+    src_a, dirs_a = pose_ring(n, args.poses, args.rays)
+    sa, da = torch.from_numpy(src_a).to(dev), torch.from_numpy(dirs_a).to(dev)
+    for layout in ("paired", "bricked", "canonical"):
+        st = CapturedStep(vol, sa, da, args.samples, args.alpha, args.sampler, layout=layout, learnable_volume=True)
+        st.capture()
+        leg[f"{layout}_ms_per_step"] = time_events(st.replay, 30)["median"]
+        del st
+    leg["note"] = ("headline workload with the volume re-converted inside every step (paired: diffus_pair_volume, bricked: "
+                   "diffus_brick_volume, canonical: no conversion, kernels read the caller's tensor)")
+    out["learnable_volume"] = leg
+    # (c) poses that move: a different ring of poses every step, copied in place into the captured step's buffers
+    pool = [pose_ring(n, args.poses, args.rays, phase=0.013 * i) for i in range(16)]
+    pool = [(torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)) for s, d in pool]
+    st = CapturedStep(vol, pool[0][0].clone(), pool[0][1].clone(), args.samples, args.alpha, args.sampler, layout=args.layout)
+    st.capture()
+    k = [0]
+
+    def moving():
+        s, d = pool[k[0] % len(pool)]
+        k[0] += 1
+        st.set_poses(s, d)
+        st.replay()
+
+    ms_move = time_events(moving, 48)["median"]
+    ms_fixed = time_events(st.replay, 48)["median"]
+    out["moving_poses"] = {"ms_per_step": ms_move, "fixed_poses_ms_per_step": ms_fixed,
+                           "note": "16 rings of poses, 0.013 rad apart, cycled: every step the persistent gradient tensor meets "
+                                   "bricks the previous step wrote and this one does not (stale-brick clearing is exercised)"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def dry_run(args, world, rank):
+    """Launcher / rendezvous / gather / timing logic without any GPU work (CPU-only boxes, tests)."""
+    import torch
+    import torch.distributed as dist
+    if rank == args.fail_rank:
+        print(f"rank {rank}: failing on request (--fail-rank)", file=sys.stderr)
+        sys.exit(3)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    P_total = args.poses * world
+    local = torch.arange(rank * args.poses, (rank + 1) * args.poses, dtype=torch.float32) + 1.0
+    allv = torch.empty(P_total)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_gather_into_tensor(allv, local)
+        else:
+            allv.copy_(local)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        every = torch.empty(world, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, t)
+        per_rank = [float(x) for x in every]
+        dt = max(per_rank)
+    assert torch.equal(allv, torch.arange(P_total, dtype=torch.float32) + 1.0), "loss gather out of order"
+    if rank == 0:
+        print(json.dumps({"metric": "ray-steps/sec fwd+bwd", "value": None, "unit": "ray-steps/s", "n_gpus": world,
+                          "world_size_observed": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
+                          "per_rank_ms_per_step": [x / max(args.steps, 1) * 1e3 for x in per_rank],
+                          "higher_is_better": True, "scaling": "weak", "dry_run": True, "data": "none (dry run: no GPU work)"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def worker(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import torch
+    from diffus_amd import CapturedStep, _lib
+    from diffus_amd.phantom import phantom, pose_ring
+
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -248,8 +403,8 @@ def main():
             dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; reporting n_gpus = {world}", file=sys.stderr)
     ngpu = world
     dev = torch.device("cuda", torch.cuda.current_device())
 
@@ -260,8 +415,13 @@ def main():
     lo = rank * args.poses
     src = torch.from_numpy(src_all[lo:lo + args.poses]).to(dev).contiguous()
     dirs = torch.from_numpy(dirs_all[lo:lo + args.poses]).to(dev).contiguous()
-    hp = HotPath(vol, src, dirs, args.samples, args.alpha, args.sampler, want_gvol=not args.no_gvol,
-                 layout=args.layout, sparse=not args.dense_grad, persistent=not args.memset_grad)
+
+    def make_step(s, d, want_gvol=not args.no_gvol, learnable=args.learnable_volume):
+        return CapturedStep(vol, s, d, args.samples, args.alpha, args.sampler, start=args.start, want_gvol=want_gvol,
+                            layout=args.layout, sparse=not args.dense_grad, persistent=not args.memset_grad,
+                            learnable_volume=learnable)
+
+    hp = make_step(src, dirs)
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
 
     # --- the step: eager launches, or one captured hipGraph (compute) + the collective ---
@@ -345,10 +505,16 @@ def main():
     host_ms = (time.perf_counter() - t0) * 1e3 / args.steps   # host time to ENQUEUE one step (no device wait)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / args.steps * 1e3]
+    world_seen = 1
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        on = dev if args.dist_backend == "nccl" else "cpu"
+        mine = torch.tensor([dt], dtype=torch.float64, device=on)
+        every = torch.empty(world, dtype=torch.float64, device=on)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_ms = [float(x) / args.steps * 1e3 for x in every.cpu()]
+        dt = float(every.max().item())                          # MAX over ranks
+        world_seen = dist.get_world_size()
         if overlap:
             losses_all.copy_(gathered[(kstep[0] - 1) & 1])
         # every rank must hold all P losses, in pose order, and they must be finite
@@ -365,41 +531,50 @@ def main():
         k_ms["scatter_patch_kernel"] = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), it,
                                                    pre=(hp.finish_grad if hp.touched is not None else hp.zero_grad))
         hp.finish_grad()
+    if args.start > 0:
+        k_ms["note"] = "start > 0: the forward and scan figures include the per-pose median launch"
     local_rs = args.poses * args.rays * args.samples
     b = BYTES[args.sampler]
-    dom = max(k_ms, key=lambda k: k_ms[k]["mean"])
-    dom_ms = k_ms[dom]["mean"]
+    kern = {k: v for k, v in k_ms.items() if isinstance(v, dict)}
+    dom = max(kern, key=lambda k: kern[k]["mean"])
+    dom_ms = kern[dom]["mean"]
     achieved = b[dom] * local_rs / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    if os.path.exists(PMC_SUMMARY):      # HBM bytes per launch from the committed PMC passes (profiles/)
-        try:
-            pm = json.load(open(PMC_SUMMARY))
-            if pm.get("workload_ray_steps") == local_rs and pm.get("sampler") == args.sampler:
-                traffic = pm["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM-side bytes per launch from the committed PMC passes, only if they were collected on exactly this workload
+    traffic = measured = limiter = pmc_file = None
+    evidence = None
+    found = find_pmc_summary(workload_key(args))
+    if found is not None:
+        pmc_file, pm = found
+        e = pm.get("kernels", {}).get(dom, {})
+        traffic = e.get("hbm_bytes_per_launch")
+        limiter = e.get("limiter")
+        evidence = {k: e[k] for k in ("l2_hit_rate", "valu_busy_frac", "wait_any_frac_of_wave", "active_valu_frac_of_wave",
+                                      "lds_busy_frac", "insts_valu_per_wave", "insts_lds_per_wave", "atomic_GBs", "vgpr",
+                                      "avg_us") if k in e}
+        if traffic is not None:
+            measured = traffic / (dom_ms * 1e-3) / 1e9
+    if measured is not None and measured / HBM_PEAK_GBS >= 0.4:
+        bound = "hbm"
+    elif limiter:
+        bound = limiter
+    elif measured is not None:
+        bound = "latency/issue (measured HBM-side traffic is %.0f %% of peak; no SQ counters committed for this workload)" % (100 * measured / HBM_PEAK_GBS)
+    else:
+        bound = "hbm (no-reuse model only: no PMC summary committed for this workload)"
 
     # --- single-pose latency (BASELINE config 2): 1 pose, fwd + bwd, eager and graph-replayed ---
-    hp1 = HotPath(vol, src[:1].contiguous(), dirs[:1].contiguous(), args.samples, args.alpha, args.sampler,
-                  want_gvol=not args.no_gvol, layout=args.layout, sparse=not args.dense_grad,
-                  persistent=not args.memset_grad)
+    hp1 = make_step(src[:1].contiguous(), dirs[:1].contiguous(), learnable=False)
     for _ in range(5):
         hp1.step()
     sp = time_events(hp1.step, 20)
     sp_graph = None
     try:
-        with torch.cuda.stream(side):
-            hp1.step()
-        side.synchronize()
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, stream=side):
-            hp1.step()
+        g1 = hp1.capture()
         sp_graph = time_events(g1.replay, 20)
     except Exception:
         pass
     # the same frame with the pose-gradient-only backward that config 2 names (no d/dvolume: no scatter, no flush)
-    hp1p = HotPath(vol, src[:1].contiguous(), dirs[:1].contiguous(), args.samples, args.alpha, args.sampler,
-                   want_gvol=False, layout=args.layout)
+    hp1p = make_step(src[:1].contiguous(), dirs[:1].contiguous(), want_gvol=False, learnable=False)
     for _ in range(5):
         hp1p.step()
     sp_pose = time_events(hp1p.step, 20)
@@ -411,45 +586,64 @@ def main():
             "value": value,
             "unit": "ray-steps/s",
             "n_gpus": ngpu,
+            "world_size_observed": world_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE config {'3' if ngpu == 1 else '4-style'}: {args.poses} poses/GPU x "
+                "workload": (f"{config_label(args, ngpu)}: {args.poses} poses/GPU x "
                              f"{args.rays} rays x {args.samples} steps through a {args.n}^3 analytic head phantom; "
                              f"{args.sampler} sampling; forward + sum-of-squares loss + backward ({grads}) "
                              f"+ canonical gradient + per-pose loss gather"),
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
-                "volume": [args.n] * 3, "sampler": args.sampler, "start": 0, "alpha": args.alpha,
-                "layout": args.layout, "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": "hipGraph replay" if graph is not None else "eager",
-                "parallelism": f"poses sharded x{ngpu}, volume replicated", "host_enqueue_ms_per_step": host_ms,
+                "volume": [args.n] * 3, "sampler": args.sampler, "start": args.start, "alpha": args.alpha,
+                "layout": args.layout,
+                "volume_conversion": ("inside every step (learnable volume)" if args.learnable_volume else
+                                      "once, outside the timed region (constant volume; see callers.learnable_volume)") if args.layout != "canonical" else "none",
+                "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": "hipGraph replay" if graph is not None else "eager",
+                "parallelism": f"poses sharded x{ngpu}, volume replicated" if args.n < 512 else f"one volume per GPU x{ngpu} (replicas only)",
+                "host_enqueue_ms_per_step": host_ms,
                 "loss_gather": ("none (1 GPU)" if dist is None else
                                 ("all_gather on its own stream, overlapping the next step" if overlap else "all_gather on the compute stream")),
+                "dist_backend": None if dist is None else args.dist_backend,
             },
             "roofline": {
-                "bound": "hbm",
+                "bound": bound,
                 "kernel": dom,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "model": f"no-reuse algorithmic bytes, {b[dom]} B per ray-step (SURVEY §8d); `achieved` is that model over the live "
+                         "launch time, NOT bytes that crossed the HBM interface -- see measured_hbm_GBs",
                 "traffic": traffic,
+                "measured_hbm_GBs": measured,
+                "measured_hbm_frac": None if measured is None else measured / HBM_PEAK_GBS,
+                "pmc_summary": pmc_file,
+                "evidence": evidence,
                 "bytes_per_ray_step": b[dom],
                 "ray_steps_per_launch": local_rs,
                 "launch_ms": dom_ms,
                 "kernels_ms": k_ms,
-                "whole_step_algorithmic_GBs": (sum(b[k] for k in k_ms) * local_rs) / (dt / args.steps) / 1e9,
+                "whole_step_algorithmic_GBs": (sum(b[k] for k in kern) * local_rs) / (dt / args.steps) / 1e9,
             },
-            "single_pose": {"workload": "BASELINE config 2: 1 pose x 256 rays x 512 steps, fwd+bwd",
+            "single_pose": {"workload": f"{'BASELINE config 2: ' if (args.n, args.rays, args.samples, args.start) == (256, 256, 512, 0) else ''}"
+                                        f"1 pose x {args.rays} rays x {args.samples} steps, {args.n}^3 volume, fwd+bwd",
                             "eager_ms": sp["median"], "graph_ms": sp_graph["median"] if sp_graph else None,
                             "pose_gradient_only_ms": sp_pose["median"],
                             "value": args.rays * args.samples / (min(sp["median"], (sp_graph or sp)["median"]) * 1e-3)},
         }
+        if ngpu == 1 and not args.no_callers:
+            try:
+                out["callers"] = callers_legs(args, vol, dev)
+            except Exception as e:
+                out["callers"] = {"failed": repr(e)}
         if ngpu == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()
@@ -460,6 +654,13 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,200 @@
+"""CapturedStep -- the hot path as a training loop runs it: persistent buffers, direct C-ABI calls, one hipGraph.
+
+`render_poses` + torch autograd (renderer.py) is the drop-in path: it allocates its outputs, goes through the
+autograd engine and costs ~0.1-0.2 ms of HOST time per step whatever the batch.  A loop that renders the same
+number of poses every iteration (the reference's `[DEMO] Train MRI to Impedance MLP - GPU` cell 16, or a pose
+registration) does not need any of that: every buffer can be allocated once and the whole step -- forward
+(reference src/renderer.py:201-275), loss, backward, gradient hand-back -- replayed as one
+captured hipGraph, because libdiffus_hip.so never allocates or synchronises.
+
+    step = CapturedStep(volume, sources, directions, num_samples=512, attenuation_coeff=1e-4)
+    step.capture()
+    for it in range(iters):
+        step.set_poses(new_sources, new_directions)      # in place: the graph reads the same buffers
+        step.replay()                                    # forward + sum-of-squares loss + backward + hand-back
+        use(step.loss, step.gvol, step.gsrc, step.gdirs) # (P,), (d0,d1,d2), (P,3), (P,R,3)
+
+With an external loss (splat -> SSIM, ...) run `forward()`, write dL/dframe into `step.gframe`, then
+`backward()`; both halves capture separately.  A learnable volume (`learnable_volume=True`) is re-converted to
+the kernels' layout inside every step, so an optimiser may update `volume` in place between replays.
+
+The volume gradient comes back in the caller's canonical (d0,d1,d2) tensor `gvol`.  By default it is PERSISTENT:
+never memset, `diffus_gradbuf_flush(PERSISTENT)` stores the bricks this step touched and clears the ones only the
+previous step touched, so after every step `gvol` is exactly this step's dense gradient.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_LAYOUT_ID = {"canonical": _lib.CANONICAL, "bricked": _lib.BRICKED, "paired": _lib.PAIRED}
+_SAMPLER_ID = {"nearest": _lib.NEAREST, "prop": _lib.NEAREST, "trilinear": _lib.TRILINEAR}
+
+
+def _vp(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _pose_tensor(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
+    """f64 stays f64 (it selects the reference's rounding sequence, src/renderer.py:119-124), anything else -> f32;
+    a tensor that is already resident, contiguous and of that dtype is used as is, so the caller can update it in place."""
+    dt = torch.float64 if t.dtype == torch.float64 else torch.float32
+    t = t.detach()
+    if t.device != dev or t.dtype != dt:
+        t = t.to(device=dev, dtype=dt)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class CapturedStep:
+    """Pre-allocated buffers + direct C-ABI calls; `capture()` turns `step()` into one hipGraph."""
+
+    def __init__(self, volume: torch.Tensor, sources: torch.Tensor, directions: torch.Tensor, num_samples: int,
+                 attenuation_coeff: float, sampler: str = "trilinear", start: int = 0, want_gvol: bool = True,
+                 layout: str = "paired", sparse: bool = True, persistent: bool = True,
+                 learnable_volume: bool = False):
+        if not volume.is_cuda:
+            raise _lib.DiffusError("CapturedStep needs a HIP-resident volume; there is no CPU fallback")
+        if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous():
+            raise ValueError("volume must be a contiguous (d0,d1,d2) float32 tensor")
+        self.lib = _lib.load()
+        dev = volume.device
+        self.dev = dev
+        self.vol = volume
+        self.src = _pose_tensor(sources, dev).reshape(-1, 3)
+        self.dirs = _pose_tensor(directions, dev)
+        if self.dirs.dim() != 3 or self.dirs.shape[0] != self.src.shape[0] or self.dirs.shape[2] != 3:
+            raise ValueError(f"directions must be (P,R,3) with P = {self.src.shape[0]}; got {tuple(self.dirs.shape)}")
+        self.layout = _LAYOUT_ID[layout]
+        self.sampler = _SAMPLER_ID[sampler]
+        self.P, self.R = self.dirs.shape[0], self.dirs.shape[1]
+        self.S, self.start, self.alpha = int(num_samples), int(start), float(attenuation_coeff)
+        self.N1 = self.S - self.start
+        self.learnable_volume = bool(learnable_volume)
+        self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
+        self.gframe = torch.empty_like(self.frame)
+        d0, d1, d2 = (int(x) for x in volume.shape)
+        self.dims = (d0, d1, d2)
+        # canonical gradient, what the caller gets.  persistent: the tensor is kept across steps and
+        # diffus_gradbuf_flush(PERSISTENT) clears what the previous step left where this step adds nothing, so it
+        # always equals this step's dense gradient without a 64 MiB memset per step.
+        self.persistent = persistent and sparse and want_gvol and self.layout != _lib.CANONICAL
+        self.gvol = torch.zeros_like(volume) if want_gvol else None
+        if self.layout != _lib.CANONICAL:
+            # HBM-resident converted copy of the volume; the bricked gradient scratch goes with it
+            nb = self.lib.diffus_bricked_floats(d0, d1, d2)
+            nk = nb if self.layout == _lib.BRICKED else self.lib.diffus_paired_floats(d0, d1, d2)
+            self.vol_k = torch.empty(nk, dtype=torch.float32, device=dev)
+            self.refresh_volume()
+            # sparse gradient hand-back: the bricked scratch and its touched-brick flags are all-zero
+            # between steps (diffus_gradbuf_flush restores that), only touched bricks are converted
+            self.gvol_k = torch.zeros(nb, dtype=torch.float32, device=dev) if want_gvol else None
+            self.touched = (torch.zeros(self.lib.diffus_brick_count(d0, d1, d2), dtype=torch.int32, device=dev)
+                            if (want_gvol and sparse) else None)
+        else:
+            self.vol_k, self.gvol_k, self.touched = volume, self.gvol, None
+        self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
+        self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
+        self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
+        self.loss_ws = torch.zeros(max(512 * self.P, 512), dtype=torch.uint8, device=dev)   # arrival counters: zero once
+        nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, self.S, self.start), 256)
+        self.ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        sdt = _lib.DIFFUS_F64 if self.src.dtype == torch.float64 else _lib.DIFFUS_F32
+        ddt = _lib.DIFFUS_F64 if self.dirs.dtype == torch.float64 else _lib.DIFFUS_F32
+        # every pointer below is fixed for the life of the object (inputs are updated in place)
+        self.common = (_vp(self.vol_k), d0, d1, d2, self.layout, _vp(self.src), sdt, _vp(self.dirs), ddt, self.P, self.R,
+                       self.S, self.start, self.alpha, self.sampler)
+        self._graphs: dict = {}
+        self._side: Optional[torch.cuda.Stream] = None
+
+    # -- plumbing ---------------------------------------------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+
+    # -- inputs, updated in place (a captured graph keeps reading the same buffers) -----------------------------
+    def set_poses(self, sources: torch.Tensor, directions: Optional[torch.Tensor] = None):
+        self.src.copy_(sources.reshape(self.src.shape))
+        if directions is not None:
+            self.dirs.copy_(directions.reshape(self.dirs.shape))
+
+    def refresh_volume(self):
+        """Rebuild the converted copy from `self.vol` (after the caller changed the volume in place)."""
+        if self.layout == _lib.BRICKED:
+            _lib.check(self.lib.diffus_brick_volume(_vp(self.vol), *self.dims, _vp(self.vol_k), self.stream()), "diffus_brick_volume")
+        elif self.layout == _lib.PAIRED:
+            _lib.check(self.lib.diffus_pair_volume(_vp(self.vol), *self.dims, _vp(self.vol_k), self.stream()), "diffus_pair_volume")
+
+    # -- the stages ---------------------------------------------------------------------------------------------
+    def fwd(self):
+        _lib.check(self.lib.diffus_render_fwd(*self.common, _vp(self.frame), None, _vp(self.ws), self.ws.numel(),
+                                              self.stream()), "diffus_render_fwd")
+
+    def bwd(self, stages=_lib.BWD_ALL):
+        _lib.check(self.lib.diffus_render_bwd(*self.common, _vp(self.gframe), _vp(self.gvol_k), _vp(self.touched),
+                                              _vp(self.gsrc), _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(),
+                                              self.stream()), "diffus_render_bwd")
+
+    def loss_and_grad(self):
+        """loss_p = sum(frame_p^2), dL/dframe = 2 frame (one launch)."""
+        _lib.check(self.lib.diffus_loss_sumsq(_vp(self.frame), self.P, self.R * self.N1, _vp(self.loss),
+                                              _vp(self.gframe), _vp(self.loss_ws), self.loss_ws.numel(), self.stream()),
+                   "diffus_loss_sumsq")
+
+    def zero_grad(self):
+        """A fresh dense gradient every step: zero the caller's canonical (d0,d1,d2) tensor (sparse
+        hand-back), or the bricked scratch (dense hand-back: the conversion overwrites every voxel)."""
+        if self.gvol is not None and not self.persistent:
+            (self.gvol if (self.touched is not None or self.layout == _lib.CANONICAL) else self.gvol_k).zero_()
+
+    def finish_grad(self):
+        """touched bricks of the scratch -> the canonical gradient; scratch back to all-zero."""
+        if self.layout != _lib.CANONICAL and self.gvol is not None and self.touched is not None:
+            # mode STORE: the tensor was zeroed this step and every touched voxel is written once
+            _lib.check(self.lib.diffus_gradbuf_flush(_vp(self.gvol_k), _vp(self.touched), *self.dims, _vp(self.gvol),
+                                                     2 if self.persistent else 0, self.stream()), "diffus_gradbuf_flush")
+        elif self.layout != _lib.CANONICAL and self.gvol is not None:
+            _lib.check(self.lib.diffus_unbrick_volume(_vp(self.gvol_k), *self.dims, _vp(self.gvol), 0, self.stream()),
+                       "diffus_unbrick_volume")
+
+    def forward(self):
+        """[volume re-conversion +] forward frame into `self.frame`."""
+        if self.learnable_volume:
+            self.refresh_volume()
+        self.fwd()
+
+    def backward(self):
+        """`self.gframe` (dL/dframe, written by the caller or by loss_and_grad) -> gvol, gsrc, gdirs."""
+        self.zero_grad()
+        self.bwd()
+        self.finish_grad()
+
+    def step(self):
+        # (a forked stream for zero_grad beside the forward was measured: the fork/join events cost
+        # more than the 10 us they hide -- 0.217 vs 0.202 ms/step -- so the step stays on one stream)
+        self.forward()
+        self.loss_and_grad()
+        self.backward()
+
+    # -- hipGraph -------------------------------------------------------------------------------------------------
+    def capture(self, what: str = "step", warmup: int = 2):
+        """Capture `what` ("step", "forward" or "backward") on a side stream; returns the torch.cuda.CUDAGraph."""
+        fn = getattr(self, what)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.dev)
+        self._side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self._side):
+            for _ in range(warmup):
+                fn()
+        self._side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self._side):
+            fn()
+        self._graphs[what] = g
+        return g
+
+    def replay(self, what: str = "step"):
+        self._graphs[what].replay()

@@ -69,8 +69,8 @@ def cone_directions_np(direction, opening_angle: float, n_rays: int) -> np.ndarr
     return out.astype(np.float32)
 
 
-def pose_ring(n: int, P: int, R: int, opening_deg: float = 60.0):
-    """P probe poses on a ring inside the head.
+def pose_ring(n: int, P: int, R: int, opening_deg: float = 60.0, phase: float = 0.0):
+    """P probe poses on a ring inside the head; `phase` (radians) turns the whole ring.
 
     -> sources (P,3) float32, directions (P,R,3) float32.  Apex p sits at
     (0.5n + 0.30n cos phi, 0.5n + 0.30n sin phi, 0.5n + 0.05n sin 3phi) and the
@@ -79,7 +79,7 @@ def pose_ring(n: int, P: int, R: int, opening_deg: float = 60.0):
     src = np.zeros((P, 3), dtype=np.float32)
     dirs = np.zeros((P, R, 3), dtype=np.float32)
     for p in range(P):
-        phi = 2.0 * math.pi * p / P
+        phi = 2.0 * math.pi * p / P + phase
         src[p] = (0.5 * n + 0.30 * n * math.cos(phi),
                   0.5 * n + 0.30 * n * math.sin(phi),
                   0.5 * n + 0.05 * n * math.sin(3 * phi))

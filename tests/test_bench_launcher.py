@@ -1,0 +1,87 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` must start N ranks itself, and under
+`python -m torch.distributed.run` it must be one of the existing ranks.  No GPU here, so the ranks run `--dry-run`:
+the launcher, the rendezvous on 127.0.0.1, the loss gather in pose order and the max-over-ranks timing are the real
+code; only the kernels are skipped."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "4", "--poses", "3"], env=_env(),
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["world_size_observed"] == 2 and out["dry_run"] is True
+    assert len(out["per_rank_ms_per_step"]) == 2
+    assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]))      # MAX over ranks
+
+
+def test_under_torchrun_it_is_a_rank_not_a_launcher():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--dry-run",
+                        "--steps", "2"], env=_env(), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["world_size_observed"] == 2
+
+
+def test_a_failing_rank_fails_the_launcher_and_stops_the_others():
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--fail-rank", "1"], env=_env(),
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0
+    assert "rank 1 exited with 3" in r.stderr
+    assert time.time() - t0 < 120            # rank 0 was stopped, not left waiting in the rendezvous
+
+
+def test_single_gpu_default_does_not_spawn():
+    r = subprocess.run([sys.executable, BENCH, "--dry-run", "--steps", "2"], env=_env(), capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert _json_line(r.stdout)["n_gpus"] == 1
+
+
+def test_labels_and_pmc_lookup_follow_the_workload(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert bench.config_label(a, 1) == "BASELINE config 3"
+    assert bench.config_label(a, 8) == "BASELINE config 4"
+    assert "config 4" in bench.config_label(a, 2)
+    a5 = bench.parse_args(["--n", "512", "--rays", "512", "--samples", "1024", "--poses", "8"])
+    assert "config 5" in bench.config_label(a5, 1) and "config 3" not in bench.config_label(a5, 1)
+    odd = bench.parse_args(["--n", "512"])
+    assert "custom" in bench.config_label(odd, 1)            # a 512^3 run is never labelled config 3
+    # the PMC summary speaks for a run only when volume, poses, rays, samples, start, sampler and layout all match
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    key = bench.workload_key(a)
+    (prof / "r02_pmc_c3.json").write_text(json.dumps({"workload": key, "kernels": {"k": {"hbm_bytes_per_launch": 7}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.find_pmc_summary(key)[1]["kernels"]["k"]["hbm_bytes_per_launch"] == 7
+    assert bench.find_pmc_summary(bench.workload_key(a5)) is None
+    assert bench.find_pmc_summary(dict(key, n=512)) is None

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_<TAG>/ (tools/collect_profiles.sh) into committed summaries under profiles/:
   profiles/<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats, copied as is
-  profiles/<TAG>_kernel_times.txt    per-kernel median/max of the batch (largest-grid) launches
-  profiles/<TAG>_pmc_summary.json    HBM-side bytes per launch per kernel, corrected as
-                                     MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE (KiB) x 2 (gfx950
-                                     tallies 128-B reads as 64 B; confirmed here on brick_convert_kernel,
-                                     a known 64 MiB read) + WRITE_SIZE (KiB, exact)
-bench.py reads the JSON to fill roofline.traffic.
+  profiles/<TAG>_kernel_times.txt    per-kernel avg/median/max of the batch (largest-grid) launches
+  profiles/<TAG>_pmc_summary.json    per kernel: HBM-side bytes per launch, corrected as MI355X_MICROARCH.md §HBM
+                                     prescribes -- FETCH_SIZE (KiB) x 2 (gfx950 tallies 128-B reads as 64 B) +
+                                     WRITE_SIZE (KiB, exact) --, measured HBM GB/s, L2 hit rate, SQ instruction
+                                     and stall counters, and the limiter they point to.
+The summary carries the `workload` it was collected on (bench.workload_key); bench.py attaches its figures to a
+run only when that matches exactly.
 """
 import collections
 import csv
@@ -16,9 +17,11 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_c3"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
+HBM_PEAK_GBS = 8000.0
+N_SIMD = 256 * 4
 
 
 def short(n):
@@ -32,75 +35,108 @@ def newest(pattern, recursive=False):
 
 
 def rows(pattern):
-    f = newest(pattern)
+    f = newest(pattern, recursive=True)
     return list(csv.DictReader(open(f))) if f else []
 
+
+workload = json.load(open(os.path.join(src, "workload.json")))
 
 # 1. kernel stats as produced by rocprofv3
 ks = newest(os.path.join("trace", "**", "*kernel_stats.csv"), recursive=True)
 if ks:
     shutil.copy(ks, f"profiles/{tag}_kernel_stats.csv")
 
-# 2. per-kernel durations of the batch launches (largest grid of each kernel = the P=32 workload)
-tr = rows("trace/**/*kernel_trace.csv") or rows("trace/*/*kernel_trace.csv")
+# 2. per-kernel durations of the batch launches (largest grid of each kernel = the batch workload)
+tr = rows("trace/**/*kernel_trace.csv")
 by = collections.defaultdict(list)
+regs = {}
 for r in tr:
     g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-    by[short(r["Kernel_Name"])].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    k = short(r["Kernel_Name"])
+    by[k].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    regs[(k, g)] = {x: r.get(x) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size") if x in r}
 lines = []
 dur = {}
 for k, v in sorted(by.items(), key=lambda kv: -sum(d for _, d in kv[1])):
     g = max(x for x, _ in v)
     d = sorted(t for x, t in v if x == g)
-    dur[k] = {"launches": len(d), "avg_us": sum(d) / len(d), "median_us": d[len(d) // 2], "max_us": d[-1], "grid_threads": g}
-    lines.append("%-28s grid=%9d launches=%4d avg=%8.1f us median=%8.1f us max=%8.1f us" % (k, g, len(d), dur[k]["avg_us"], dur[k]["median_us"], d[-1]))
+    dur[k] = {"launches": len(d), "avg_us": sum(d) / len(d), "median_us": d[len(d) // 2], "max_us": d[-1], "grid_threads": g,
+              **{kk: vv for kk, vv in regs.get((k, g), {}).items()}}
+    lines.append("%-28s grid=%9d launches=%4d avg=%8.1f us median=%8.1f us max=%8.1f us  %s" % (
+        k, g, len(d), dur[k]["avg_us"], dur[k]["median_us"], d[-1], " ".join(f"{a}={b}" for a, b in regs.get((k, g), {}).items())))
 open(f"profiles/{tag}_kernel_times.txt", "w").write(
-    "# batch launches (largest grid per kernel) from rocprofv3 --kernel-trace; bench.py --steps 30 --eager\n" + "\n".join(lines) + "\n")
+    f"# workload {json.dumps(workload)}\n# batch launches (largest grid per kernel) from rocprofv3 --kernel-trace; bench.py --steps 30 --eager\n"
+    + "\n".join(lines) + "\n")
 
-# 3. PMC passes
-def pmc(name):
-    out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in rows(f"pmc_{name}/*/*counter_collection.csv"):
-        out[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
-    res = {}
-    for k, cs in out.items():
-        res[k] = {}
-        for c, v in cs.items():
-            g = max(x for x, _ in v)
-            vals = sorted(t for x, t in v if x == g)
-            res[k][c] = vals[len(vals) // 2]
-    return res
+# 3. PMC passes: median over the batch launches of each kernel
+cnt = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    tmp = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        tmp[(short(r["Kernel_Name"]), r["Counter_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    for (k, c), v in tmp.items():
+        g = max(x for x, _ in v)
+        vals = sorted(t for x, t in v if x == g)
+        cnt[k][c] = vals[len(vals) // 2]
 
-
-fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
-tcc, atom = pmc("TCC_HIT_sum_TCC_MISS_sum"), pmc("TCC_EA0_ATOMIC_sum")
-summary = {"tag": tag, "workload_ray_steps": 32 * 256 * 512, "sampler": "trilinear",
-           "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  [FETCH_SIZE x2 on gfx950]",
-           "calibration": {}, "kernels": {},
-           "note": ("FETCH_SIZE counts 64 B per fabric read request: exactly 1/2 of the bytes for wide coalesced streams "
-                    "(brick_convert_kernel, 256-B rows: 32 781 KiB reported for a 65 536 KiB read), but 0.94 of them for "
-                    "pair_convert_kernel's 132-B rows.  The x2 prescribed for gfx950 is therefore an UPPER bound of the "
-                    "read traffic of the gather kernels; hbm_bytes_per_launch uses it.")}
-if "pair_convert_kernel" in fetch:
-    summary["calibration"] = {"kernel": "pair_convert_kernel (reads 64 MiB, writes 128 MiB)", "FETCH_SIZE_KiB": fetch["pair_convert_kernel"].get("FETCH_SIZE"), "WRITE_SIZE_KiB": write.get("pair_convert_kernel", {}).get("WRITE_SIZE"), "expected_KiB": [65536, 131072]}
-elif "brick_convert_kernel" in fetch:
-    summary["calibration"] = {"kernel": "brick_convert_kernel (reads 64 MiB, writes 64 MiB)",
-                              "FETCH_SIZE_KiB": fetch["brick_convert_kernel"].get("FETCH_SIZE"),
-                              "WRITE_SIZE_KiB": write.get("brick_convert_kernel", {}).get("WRITE_SIZE"),
-                              "expected_KiB": 65536}
-for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "gradbuf_flush_kernel", "pair_convert_kernel", "brick_convert_kernel", "loss_sumsq_kernel"):
-    if k not in fetch:
+summary = {"tag": tag, "workload": workload,
+           "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  [FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md §HBM]",
+           "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; *_frac_of_wave = share of a "
+                    "wave's resident cycles; valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)",
+           "kernels": {}}
+for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "gradbuf_flush_kernel", "median_kernel",
+          "median_bwd_kernel", "pair_convert_kernel", "brick_convert_kernel", "loss_sumsq_kernel"):
+    c = cnt.get(k)
+    if not c or k not in dur:
         continue
-    f, w = fetch[k].get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
-    e = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    if k in tcc:
-        h, m = tcc[k].get("TCC_HIT_sum", 0), tcc[k].get("TCC_MISS_sum", 0)
-        e["l2_hit_rate"] = h / (h + m) if h + m else None
-    if k in atom:
-        e["TCC_EA0_ATOMIC"] = atom[k].get("TCC_EA0_ATOMIC_sum")
-    if k in dur:
-        e.update({"avg_us": dur[k]["avg_us"], "median_us": dur[k]["median_us"]})
+    f, w = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+    us = dur[k]["avg_us"]
+    e = {"avg_us": us, "median_us": dur[k]["median_us"], "launches": dur[k]["launches"],
+         "vgpr": dur[k].get("VGPR_Count"), "lds_bytes": dur[k].get("LDS_Block_Size"), "scratch": dur[k].get("Scratch_Size"),
+         "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+    e["measured_hbm_GBs"] = e["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9
+    e["measured_hbm_frac"] = e["measured_hbm_GBs"] / HBM_PEAK_GBS
+    h, m = c.get("TCC_HIT_sum"), c.get("TCC_MISS_sum")
+    if h is not None and m is not None and h + m:
+        e["l2_hit_rate"] = h / (h + m)
+    if "TCC_EA0_ATOMIC_sum" in c:
+        e["TCC_EA0_ATOMIC"] = c["TCC_EA0_ATOMIC_sum"]
+        e["atomic_GBs"] = c["TCC_EA0_ATOMIC_sum"] * 64 / (us * 1e-6) / 1e9
+    waves = c.get("SQ_WAVES")
+    if waves:
+        for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"):
+            if name in c:
+                e[name.replace("SQ_INSTS_", "insts_").lower() + "_per_wave"] = c[name] / waves
+        e["waves"] = waves
+    wc = c.get("SQ_WAVE_CYCLES")
+    if wc:
+        for name, key in (("SQ_WAIT_ANY", "wait_any_frac_of_wave"), ("SQ_WAIT_INST_ANY", "wait_inst_frac_of_wave"),
+                          ("SQ_ACTIVE_INST_ANY", "active_inst_frac_of_wave"), ("SQ_ACTIVE_INST_VALU", "active_valu_frac_of_wave"),
+                          ("SQ_ACTIVE_INST_LDS", "active_lds_frac_of_wave")):
+            if name in c:
+                e[key] = c[name] / wc
+    gui = c.get("GRBM_GUI_ACTIVE")
+    if gui and "SQ_ACTIVE_INST_VALU" in c:
+        e["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4 / N_SIMD / (gui / 8)
+    if gui and "SQ_LDS_IDX_ACTIVE" in c:
+        e["lds_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / 256 / (gui / 8)
+        e["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c["SQ_LDS_IDX_ACTIVE"], 1.0)
+    # what the counters point to
+    if e["measured_hbm_frac"] >= 0.4:
+        e["limiter"] = "hbm"
+    else:
+        wa, vb = e.get("wait_any_frac_of_wave"), e.get("valu_busy_frac")
+        parts = []
+        if wa is not None:
+            parts.append("waves parked %.0f %% of their cycles" % (100 * wa))
+        if vb is not None:
+            parts.append("VALU pipes busy %.0f %%" % (100 * vb))
+        parts.append("HBM-side traffic %.0f %% of 8 TB/s" % (100 * e["measured_hbm_frac"]))
+        kind = "latency" if (wa or 0) >= 0.5 and (vb or 0) < 0.5 else ("valu-issue" if (vb or 0) >= 0.5 else "latency+issue")
+        e["limiter"] = f"{kind} ({', '.join(parts)})"
+    e["counters"] = {a: b for a, b in sorted(c.items())}
     summary["kernels"][k] = e
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 print(open(f"profiles/{tag}_kernel_times.txt").read())
-print(json.dumps(summary, indent=1))
+for k, e in summary["kernels"].items():
+    print("%-24s %7.1f us  hbm %6.0f GB/s (%4.1f %%)  %s" % (k, e["avg_us"], e["measured_hbm_GBs"], 100 * e["measured_hbm_frac"], e["limiter"]))
