@@ -134,15 +134,75 @@ __device__ __forceinline__ int wave_reduce_minmax(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ Mat mat_shfl_up(const Mat &m, int off)
+// ---- cross-lane moves on the DPP path ---------------------------------------------------------
+// The scans below used ds_bpermute (`__shfl_up/down`): 127 LDS-crossbar round trips per wave in the backward,
+// each an address VGPR, an LDS issue slot shared by the CU's four SIMDs and ~100 cycles of latency behind an
+// s_waitcnt.  A DPP move is one full-rate VALU instruction with no memory counter at all.  gfx950 is a GFX9
+// target, so it has the whole-wave forms too: wave_shr:1 / wave_shl:1 (neighbour lane across row boundaries)
+// and row_bcast:15 / row_bcast:31 (last lane of a row / of the lower half to the rows above).
+// A lane whose source lane does not exist (or whose row is masked out) keeps `old`.
+// The move must execute with every lane active: a source lane that EXEC disables counts as non-existent.
+constexpr int kDppRowShl = 0x100, kDppRowShr = 0x110;              // + n, n = 1..15: lane i <- lane i+n / i-n of its row of 16
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;          // lane i <- lane i+1 / i-1 of the wave
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;            // lane 15 of each row -> next row; lane 31 -> rows 2,3
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_mov(int old, int v)
 {
-    return Mat{__shfl_up(m.a, off, kWave), __shfl_up(m.b, off, kWave), __shfl_up(m.c, off, kWave),
-               __shfl_up(m.d, off, kWave)};
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ Mat mat_shfl_down(const Mat &m, int off)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float v)
 {
-    return Mat{__shfl_down(m.a, off, kWave), __shfl_down(m.b, off, kWave), __shfl_down(m.c, off, kWave),
-               __shfl_down(m.d, off, kWave)};
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ Mat mat_dpp(const Mat &old, const Mat &m)
+{
+    return Mat{dpp_mov<CTRL, ROW_MASK>(old.a, m.a), dpp_mov<CTRL, ROW_MASK>(old.b, m.b), dpp_mov<CTRL, ROW_MASK>(old.c, m.c),
+               dpp_mov<CTRL, ROW_MASK>(old.d, m.d)};
+}
+__device__ __forceinline__ float lane_bcast(float v, int srclane) // wave-uniform value of one lane (v_readlane_b32)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+__device__ __forceinline__ Mat mat_lane_bcast(const Mat &m, int srclane)
+{
+    return Mat{lane_bcast(m.a, srclane), lane_bcast(m.b, srclane), lane_bcast(m.c, srclane), lane_bcast(m.d, srclane)};
+}
+// value of the previous / next lane of the wave; lane 0 / lane 63 gets `edge`
+__device__ __forceinline__ float lane_prev(float v, float edge) { return dpp_mov<kDppWaveShr1>(edge, v); }
+__device__ __forceinline__ float lane_next(float v, float edge) { return dpp_mov<kDppWaveShl1>(edge, v); }
+__device__ __forceinline__ int lane_prev(int v, int edge) { return dpp_mov<kDppWaveShr1>(edge, v); }
+__device__ __forceinline__ int lane_next(int v, int edge) { return dpp_mov<kDppWaveShl1>(edge, v); }
+__device__ __forceinline__ Mat mat_lane_prev(const Mat &m, const Mat &edge) { return mat_dpp<kDppWaveShr1>(edge, m); }
+__device__ __forceinline__ Mat mat_lane_next(const Mat &m, const Mat &edge) { return mat_dpp<kDppWaveShl1>(edge, m); }
+
+// Inclusive scan over the 64 lanes, LOWER lanes on the left: six Hillis-Steele rounds, offsets 1, 2, 4, 8 inside
+// the rows of 16 (row_shr), then the last lane of a row / of the lower half broadcast to the rows above it.
+// f(has_source, round) is called once per round with every lane active; `fetch` inside it does the DPP moves.
+// Round r of this schedule combines exactly the lanes a shuffle scan with offset 2^r would.
+#define DIFFUS_SCAN_UP_ROUNDS(LANE, ROUND)                                   \
+    ROUND(kDppRowShr + 1, 0xf, ((LANE) & 15) >= 1)                           \
+    ROUND(kDppRowShr + 2, 0xf, ((LANE) & 15) >= 2)                           \
+    ROUND(kDppRowShr + 4, 0xf, ((LANE) & 15) >= 4)                           \
+    ROUND(kDppRowShr + 8, 0xf, ((LANE) & 15) >= 8)                           \
+    ROUND(kDppBcast15, 0xa, ((LANE) & 16) != 0)                              \
+    ROUND(kDppBcast31, 0xc, (LANE) >= 32)
+
+// Sum over the wave on the DPP path; the total is valid in lane 63 only.
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+#define DIFFUS_SUM_STEP(ctrl, rmask) \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true));
+    DIFFUS_SUM_STEP(kDppRowShr + 1, 0xf)
+    DIFFUS_SUM_STEP(kDppRowShr + 2, 0xf)
+    DIFFUS_SUM_STEP(kDppRowShr + 4, 0xf)
+    DIFFUS_SUM_STEP(kDppRowShr + 8, 0xf)
+    DIFFUS_SUM_STEP(kDppBcast15, 0xa)
+    DIFFUS_SUM_STEP(kDppBcast31, 0xc)
+#undef DIFFUS_SUM_STEP
+    return v;
 }
 
 // ----------------------------------------------------------------------------
@@ -700,16 +760,20 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
         L = mat_step(L, r[j]);
         if (!FAST || (j & 3) == 3 || j == C - 1) mat_renorm(L);
     }
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        Mat o = mat_shfl_up(L, off);
-        if (lane >= off) {
-            L = mat_mul(o, L);
-            mat_renorm(L);
-        }
+    {
+        const Mat I = mat_identity();
+#define DIFFUS_ROUND(CTRL, RMASK, HAS)             \
+    {                                              \
+        const Mat o = mat_dpp<CTRL, RMASK>(I, L);  \
+        if (HAS) {                                 \
+            L = mat_mul(o, L);                     \
+            mat_renorm(L);                         \
+        }                                          \
     }
-    Mat Pm = mat_shfl_up(L, 1);
-    if (lane == 0) Pm = mat_identity();
+        DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
+#undef DIFFUS_ROUND
+    }
+    Mat Pm = mat_lane_prev(L, mat_identity()); // exclusive prefix; lane 0: identity
     if (carry_in) { // segment > 0: everything is preceded by the product of the earlier segments
         Pm = mat_mul(*carry_in, Pm);
         mat_renorm(Pm);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         }
         to_chunked<C>(wb, lane, zi, gb);
     }
-    float zprev = __shfl_up(z[C - 1], 1, kWave);
+    float zprev = lane_prev(z[C - 1], z[C - 1]);
     if (cin && lane == 0) zprev = cin[w * 5 + 4]; // last sample of the previous segment
     const float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r);
@@ -82,21 +82,23 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     const Mat Lloc = L;   // normalised local product T_first..T_last
     const int lamloc = lam;
     int iota = lam;       // inclusive prefix exponent
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        Mat o = mat_shfl_up(L, off);
-        int oe = __shfl_up(iota, off, kWave);
-        if (lane >= off) {
-            L = mat_mul(o, L);
-            iota = oe + iota - mat_renorm(L);
-        }
+    {
+        // six scan rounds on the DPP path (diffus_device.hpp): matrix and exponent move together
+        const Mat I = mat_identity();
+#define DIFFUS_ROUND(CTRL, RMASK, HAS)                   \
+    {                                                    \
+        const Mat o = mat_dpp<CTRL, RMASK>(I, L);        \
+        const int oe = dpp_mov<CTRL, RMASK>(0, iota);    \
+        if (HAS) {                                       \
+            L = mat_mul(o, L);                           \
+            iota = oe + iota - mat_renorm(L);            \
+        }                                                \
     }
-    Mat Pm = mat_shfl_up(L, 1);
-    int eps = __shfl_up(iota, 1, kWave); // exponent of the exclusive prefix
-    if (lane == 0) {
-        Pm = mat_identity();
-        eps = 0;
+        DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
+#undef DIFFUS_ROUND
     }
+    Mat Pm = mat_lane_prev(L, mat_identity()); // exclusive prefix (lane 0: identity) ...
+    int eps = lane_prev(iota, 0);              // ... and its exponent
     if (cin) { // segment > 0: P'_{seg0-1} of the carry-only forward pass precedes everything (its scale is exponent 0)
         Pm = mat_mul(Mat{cin[w * 5 + 0], cin[w * 5 + 1], cin[w * 5 + 2], cin[w * 5 + 3]}, Pm);
         eps -= mat_renorm(Pm);
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
 
     // exponent of this lane's last P' and the hop to the next lane's exclusive prefix
     const int elast = eps - esum;
-    int eps_next = __shfl_down(eps, 1, kWave);
+    const int eps_next = lane_next(eps, 0);
     const int delta = (lane == kWave - 1) ? 0 : (eps_next - elast);
 
     // ---- lane-local affine map: A-part = sweep from U = 0 ----
@@ -153,20 +155,45 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     if (!mat_finite(Bn)) Bn = Mat{0.f, 0.f, 0.f, 0.f}; // a non-finite chunk passes nothing
 
     // ---- reverse inclusive scan of affine maps: G_l = F_l o F_{l+1} o ... o F_63 ----
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        Mat oA = mat_shfl_down(Aacc, off);
-        Mat oB = mat_shfl_down(Bn, off);
-        int ob = __shfl_down(beta, off, kWave);
-        if (lane + off < kWave) {
+    // Same six rounds mirrored: offsets 1, 2, 4, 8 towards HIGHER lanes inside the rows of 16 (row_shl), then the
+    // first lane of the row above (lanes 16 / 48, then lane 32) broadcast downwards.  DPP has no broadcast in that
+    // direction, so those two rounds read the lane through an SGPR (v_readlane_b32).
+    {
+        const Mat Z{0.f, 0.f, 0.f, 0.f}, I = mat_identity();
+        auto combine = [&](const Mat &oA, const Mat &oB, int ob) {
             Mat t = mat_scale(mat_mul_bt(oA, Bn), beta);
             Aacc.a += t.a; Aacc.b += t.b; Aacc.c += t.c; Aacc.d += t.d;
             Bn = mat_mul(Bn, oB);
             beta = beta + ob + mat_renorm(Bn); // B = Bn * 2^beta: a rescale of Bn by 2^-ex adds ex
+        };
+#define DIFFUS_ROUND_DOWN(N)                                        \
+    {                                                               \
+        const Mat oA = mat_dpp<kDppRowShl + N>(Z, Aacc);            \
+        const Mat oB = mat_dpp<kDppRowShl + N>(I, Bn);              \
+        const int ob = dpp_mov<kDppRowShl + N>(0, beta);            \
+        if ((lane & 15) + N < 16) combine(oA, oB, ob);              \
+    }
+        DIFFUS_ROUND_DOWN(1)
+        DIFFUS_ROUND_DOWN(2)
+        DIFFUS_ROUND_DOWN(4)
+        DIFFUS_ROUND_DOWN(8)
+#undef DIFFUS_ROUND_DOWN
+        {   // rows 0 and 2 take the row above them (its suffix sits in its first lane)
+            const Mat a16 = mat_lane_bcast(Aacc, 16), b16 = mat_lane_bcast(Bn, 16);
+            const Mat a48 = mat_lane_bcast(Aacc, 48), b48 = mat_lane_bcast(Bn, 48);
+            const int e16 = __builtin_amdgcn_readlane(beta, 16), e48 = __builtin_amdgcn_readlane(beta, 48);
+            const bool up = lane >= 32;
+            if (!(lane & 16))
+                combine(Mat{up ? a48.a : a16.a, up ? a48.b : a16.b, up ? a48.c : a16.c, up ? a48.d : a16.d},
+                        Mat{up ? b48.a : b16.a, up ? b48.b : b16.b, up ? b48.c : b16.c, up ? b48.d : b16.d}, up ? e48 : e16);
+        }
+        {   // the lower half takes the upper half
+            const Mat a32 = mat_lane_bcast(Aacc, 32), b32 = mat_lane_bcast(Bn, 32);
+            const int e32 = __builtin_amdgcn_readlane(beta, 32);
+            if (lane < 32) combine(a32, b32, e32);
         }
     }
-    Mat Uin = mat_shfl_down(Aacc, 1);
-    if (lane == kWave - 1) Uin = Mat{0.f, 0.f, 0.f, 0.f};
+    Mat Uin = mat_lane_next(Aacc, Mat{0.f, 0.f, 0.f, 0.f}); // lane 63: nothing enters from above
     if (uin) {
         // Adjoint entering from the next segment.  It was written relative to the scale of that segment's
         // carry-in P' (cnext); lane 63's final P' is the same matrix up to a power of two (idle samples
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         Mat Kn{cnext[w * 5 + 0], cnext[w * 5 + 1], cnext[w * 5 + 2], cnext[w * 5 + 3]};
         float mk = fmaxf(fmaxf(fabsf(Kn.a), fabsf(Kn.b)), fmaxf(fabsf(Kn.c), fabsf(Kn.d)));
         float mp = fmaxf(fmaxf(fabsf(Pm.a), fabsf(Pm.b)), fmaxf(fabsf(Pm.c), fabsf(Pm.d)));
-        mp = __shfl(mp, kWave - 1, kWave);
+        mp = lane_bcast(mp, kWave - 1);
         float ratio = mk / mp;
         Mat Uc{uin[w * 4 + 0], uin[w * 4 + 1], uin[w * 4 + 2], uin[w * 4 + 3]};
         if (finitef(ratio) && ratio > 0.f && mat_finite(Uc))
@@ -182,8 +209,8 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         else
             Uc = Mat{0.f, 0.f, 0.f, 0.f};
         // U entering lane l = G_{l+1}(Uc) = Aacc_{l+1} + Uc (B_{l+1} 2^beta_{l+1})^T
-        Mat Bs = mat_shfl_down(Bn, 1);
-        int bs = __shfl_down(beta, 1, kWave);
+        const Mat Bs = mat_lane_next(Bn, mat_identity());
+        const int bs = lane_next(beta, 0);
         Mat t = mat_scale(mat_mul_bt(Uc, Bs), bs);
         Uin.a += t.a; Uin.b += t.b; Uin.c += t.c; Uin.d += t.d;
         if (lane == kWave - 1) Uin = Uc;
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         else
             zbar[j == 0 ? 0 : j - 1] += c0;
     }
-    const float cnb = __shfl_down(carry, 1, kWave);
+    const float cnb = lane_next(carry, 0.f);
     if (lane != kWave - 1) zbar[C - 1] += cnb;
     if (zcout && lane == 0) zcout[w] = carry; // belongs to the last sample of the previous segment
     if (zcin) {
@@ -275,16 +302,9 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
                 gd2 = __builtin_fmaf(kf, a2, gd2);
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            gs0 += __shfl_xor(gs0, off, kWave);
-            gs1 += __shfl_xor(gs1, off, kWave);
-            gs2 += __shfl_xor(gs2, off, kWave);
-            gd0 += __shfl_xor(gd0, off, kWave);
-            gd1 += __shfl_xor(gd1, off, kWave);
-            gd2 += __shfl_xor(gd2, off, kWave);
-        }
-        if (lane == 0) {
+        gs0 = wave_sum_to_lane63(gs0); gs1 = wave_sum_to_lane63(gs1); gs2 = wave_sum_to_lane63(gs2);
+        gd0 = wave_sum_to_lane63(gd0); gd1 = wave_sum_to_lane63(gd1); gd2 = wave_sum_to_lane63(gd2);
+        if (lane == kWave - 1) { // the DPP ladder leaves the wave's total in its last lane
             if (accum_pose) { // later-processed segment of a long ray: add to the partial sums
                 if (A.gsrc_part) {
                     gs0 += A.gsrc_part[w * 3 + 0]; gs1 += A.gsrc_part[w * 3 + 1]; gs2 += A.gsrc_part[w * 3 + 2];

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #else
     to_chunked<C>(wb, lane, zi, z);
 #endif
-    float zprev = __shfl_up(z[C - 1], 1, kWave);
+    float zprev = lane_prev(z[C - 1], z[C - 1]); // last sample of the lane below (lane 0: unused unless a carry comes in)
     Mat K = mat_identity(), Klast = mat_identity();
     if (cin) { // carry of the earlier segments: running product and the sample just before this segment
         K = Mat{cin[w * 5 + 0], cin[w * 5 + 1], cin[w * 5 + 2], cin[w * 5 + 3]};
@@ -165,8 +165,7 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
         }
         Mat Kl = K;
         echo_chunk<C>(r, lane, e, base ? &K : nullptr, kWave * C - 1, &Kl);
-        K = Mat{__shfl(Kl.a, kWave - 1, kWave), __shfl(Kl.b, kWave - 1, kWave), __shfl(Kl.c, kWave - 1, kWave),
-                __shfl(Kl.d, kWave - 1, kWave)};
+        K = mat_lane_bcast(Kl, kWave - 1);
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = n0 + j;
