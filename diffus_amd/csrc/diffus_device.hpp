@@ -113,23 +113,25 @@ __device__ __forceinline__ int mat_renorm(Mat &m)
 __device__ __forceinline__ bool finitef(float x) { return fabsf(x) < __builtin_inff(); }
 __device__ __forceinline__ bool mat_finite(const Mat &m) { return finitef(m.a) && finitef(m.b) && finitef(m.c) && finitef(m.d); }
 
-// Wave-wide min/max of an int by the classic DPP ladder (row_shr 1,2,3,4,8, row_bcast 15,31):
-// 7 VALU+DPP steps instead of 6 ds_bpermute round trips.  Result valid in every lane (readlane 63).
+// Wave-wide min/max of an int on the DPP path: Hillis-Steele offsets 1, 2, 4, 8 inside the rows of 16, then
+// row_bcast:15 / row_bcast:31.  `old` = the identity of the operation, so hipcc folds each move into its
+// v_min_i32_dpp / v_max_i32_dpp: 6 instructions (with old = v it was mov + mov_dpp + min per step, 21 in all).
+// Result valid in every lane (readlane 63).
 template <bool IS_MIN>
 __device__ __forceinline__ int wave_reduce_minmax(int v)
 {
-#define DIFFUS_DPP_STEP(ctrl, rmask, bmask)                                                   \
+    constexpr int ident = IS_MIN ? 0x7fffffff : (int)0x80000000;
+#define DIFFUS_DPP_STEP(ctrl, rmask)                                                          \
     {                                                                                         \
-        int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, bmask, false);                 \
+        int o = __builtin_amdgcn_update_dpp(ident, v, ctrl, rmask, 0xf, false);               \
         v = IS_MIN ? min(v, o) : max(v, o);                                                   \
     }
-    DIFFUS_DPP_STEP(0x111, 0xf, 0xf) // row_shr:1
-    DIFFUS_DPP_STEP(0x112, 0xf, 0xf) // row_shr:2
-    DIFFUS_DPP_STEP(0x113, 0xf, 0xf) // row_shr:3
-    DIFFUS_DPP_STEP(0x114, 0xf, 0xe) // row_shr:4
-    DIFFUS_DPP_STEP(0x118, 0xf, 0xc) // row_shr:8
-    DIFFUS_DPP_STEP(0x142, 0xa, 0xf) // row_bcast:15
-    DIFFUS_DPP_STEP(0x143, 0xc, 0xf) // row_bcast:31
+    DIFFUS_DPP_STEP(0x111, 0xf) // row_shr:1
+    DIFFUS_DPP_STEP(0x112, 0xf) // row_shr:2
+    DIFFUS_DPP_STEP(0x114, 0xf) // row_shr:4
+    DIFFUS_DPP_STEP(0x118, 0xf) // row_shr:8
+    DIFFUS_DPP_STEP(0x142, 0xa) // row_bcast:15
+    DIFFUS_DPP_STEP(0x143, 0xc) // row_bcast:31
 #undef DIFFUS_DPP_STEP
     return __builtin_amdgcn_readlane(v, 63);
 }
@@ -162,6 +164,24 @@ __device__ __forceinline__ Mat mat_dpp(const Mat &old, const Mat &m)
     return Mat{dpp_mov<CTRL, ROW_MASK>(old.a, m.a), dpp_mov<CTRL, ROW_MASK>(old.b, m.b), dpp_mov<CTRL, ROW_MASK>(old.c, m.c),
                dpp_mov<CTRL, ROW_MASK>(old.d, m.d)};
 }
+// The same moves when a lane without a source does not care what it gets (the scans only use the value under
+// `if (has source)`): zero for a missing source lane, the register's previous content where the row is masked.
+// ONE v_mov_b32_dpp -- dpp_mov has to load `old` into the destination first, a second VALU instruction per move.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_get(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, ROW_MASK, 0xf, true);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_get(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ Mat mat_dpp_get(const Mat &m)
+{
+    return Mat{dpp_get<CTRL, ROW_MASK>(m.a), dpp_get<CTRL, ROW_MASK>(m.b), dpp_get<CTRL, ROW_MASK>(m.c), dpp_get<CTRL, ROW_MASK>(m.d)};
+}
 __device__ __forceinline__ float lane_bcast(float v, int srclane) // wave-uniform value of one lane (v_readlane_b32)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
@@ -177,6 +197,12 @@ __device__ __forceinline__ int lane_prev(int v, int edge) { return dpp_mov<kDppW
 __device__ __forceinline__ int lane_next(int v, int edge) { return dpp_mov<kDppWaveShl1>(edge, v); }
 __device__ __forceinline__ Mat mat_lane_prev(const Mat &m, const Mat &edge) { return mat_dpp<kDppWaveShr1>(edge, m); }
 __device__ __forceinline__ Mat mat_lane_next(const Mat &m, const Mat &edge) { return mat_dpp<kDppWaveShl1>(edge, m); }
+// ... with 0 at the edge: one instruction each
+__device__ __forceinline__ float lane_prev0(float v) { return dpp_get<kDppWaveShr1>(v); }
+__device__ __forceinline__ float lane_next0(float v) { return dpp_get<kDppWaveShl1>(v); }
+__device__ __forceinline__ int lane_prev0(int v) { return dpp_get<kDppWaveShr1>(v); }
+__device__ __forceinline__ int lane_next0(int v) { return dpp_get<kDppWaveShl1>(v); }
+__device__ __forceinline__ Mat mat_lane_next0(const Mat &m) { return mat_dpp_get<kDppWaveShl1>(m); }
 
 // Inclusive scan over the 64 lanes, LOWER lanes on the left: six Hillis-Steele rounds, offsets 1, 2, 4, 8 inside
 // the rows of 16 (row_shr), then the last lane of a row / of the lower half broadcast to the rows above it.
@@ -251,6 +277,18 @@ __device__ __forceinline__ void load_pose(Pose &ps, const void *src, int src_f64
 // p_c = source_c + float(k) * dir_c with the reference's rounding sequence
 // (src/renderer.py:119-124, cast to f32 at :751).  No FMA contraction.
 template <int PM = 1>
+__device__ __forceinline__ float ray_point_f(const Pose &ps, int c, float stepf) // stepf = float(k), exact below 2^24
+{
+    if (PM == 0 || ps.pmode == 0) {
+        return __fadd_rn(ps.sf[c], __fmul_rn(stepf, ps.df[c]));
+    } else if (ps.pmode == 1) {
+        float t = __fmul_rn(stepf, ps.df[c]);
+        return (float)__dadd_rn(ps.sd[c], (double)t);
+    } else {
+        return (float)__dadd_rn(ps.sd[c], __dmul_rn((double)stepf, ps.dd[c]));
+    }
+}
+template <int PM = 1>
 __device__ __forceinline__ float ray_point(const Pose &ps, int c, int k)
 {
     float stepf = (float)k;
@@ -295,6 +333,9 @@ namespace diffus { // types that cross translation units need linkage
 struct Geom {
     int d0, d1, d2;
     int nb1, nb2; // bricks along dim 1 / dim 2
+    // BYTE strides of the volume layout in use, for the separable offsets of the gather (part_x/part_y/part_z):
+    // canonical: one step along dim 0 / dim 1; bricked and paired: one brick row (4 voxels of dim 0) / brick column
+    unsigned sxB, syB;
 };
 } // namespace diffus
 using diffus::Geom;
@@ -333,7 +374,7 @@ __device__ __forceinline__ Axis tri_axis(float p, int dim)
     a.m = (p > 0.f && p < hi) ? 1.f : 0.f;
     float pc = p;
     if (!(pc > 0.f)) pc = 0.f; // also catches NaN
-    if (pc > hi) pc = hi;
+    pc = fminf(pc, hi);        // pc is a number here: one v_min_f32 instead of compare + select
     float f = floorf(pc);
     a.i0 = (int)f;
     a.t = pc - f;
@@ -426,6 +467,7 @@ __device__ __forceinline__ float reflect(float z1, float z2) { return __fdiv_rn(
 // are accurate to ~1 ulp, far inside the 1e-5 frame tolerance; 0/0 stays NaN, x/0 stays +-inf.
 __device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float reflect_fast(float z1, float z2) { return fast_div(z2 - z1, z1 + z2); }
 
 // ----------------------------------------------------------------------------
@@ -451,7 +493,8 @@ struct Args {
     float *zcout;      // backward, nullable (P*R): contribution of this segment's first r to sample seg0-1
     float *gsrc_out;   // scatter launch only, nullable (P,3): its P extra blocks sum gsrc_part over rays into it
     int accum_pose;    // backward: add to (instead of overwrite) the per-ray pose-gradient partials
-    float neg_alpha;
+    float neg_alpha;     // -alpha
+    float neg_alpha_l2e; // -alpha * log2(e): attenuation = exp2(neg_alpha_l2e * n), one multiply in front of v_exp_f32
     // forward
     float *frame;
     long long *idx;
@@ -563,64 +606,70 @@ __device__ __forceinline__ void to_interleaved(float *wb, int lane, const float 
     wave_lds_sync();
 }
 
-// Column / depth parts of a voxel offset: off(x,y,z) = col_off(x,y) + z_off(z).
+// Byte offset of voxel (x,y,z) as three separable parts: off = part_x(x) + part_y(y) + part_z(z).  A trilinear
+// sample needs part_x and part_y for two coordinates each and sums them with v_add3_u32 -- 4 x (shift, 24-bit
+// multiply, and, shift-add) instead of the 4 x (two multiplies, one of them the quarter-rate v_mul_lo_u32, and ~8
+// bit operations) the nested form (x/4 * nb1 + y/4) * stride costs; the offsets come out in bytes, so no shift
+// in front of the load either.  Bricked / paired strides are < 2^24 bytes (check_common), coordinates/4 < 2^22.
 template <int LAYOUT>
-__device__ __forceinline__ unsigned col_off(const Geom &G, int x, int y)
+__device__ __forceinline__ unsigned part_x(const Geom &G, int x)
 {
-    // v_mul_u32_u24 is full rate, v_mul_lo_u32 quarter rate; every factor here is < 2^24 except the
-    // final row stride, which is applied as a shift (bricked) or one 32-bit multiply (canonical)
-    if (LAYOUT == DIFFUS_CANONICAL)
-        return (__umul24((unsigned)x, (unsigned)G.d1) + (unsigned)y) * (unsigned)G.d2;
-    if (LAYOUT == DIFFUS_PAIRED)
-        return ((__umul24((unsigned)(x >> 2), (unsigned)G.nb1) + (unsigned)(y >> 2)) * (unsigned)G.d2 << 5) +
-               (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
-    return ((__umul24((unsigned)(x >> 2), (unsigned)G.nb1) + (unsigned)(y >> 2)) * (unsigned)G.nb2 << 5) +
-           (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
+    if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)x * G.sxB;
+    return __umul24((unsigned)x >> 2, G.sxB) + (((unsigned)x & 3u) << 5);
 }
 template <int LAYOUT>
-__device__ __forceinline__ unsigned z_off(int z)
+__device__ __forceinline__ unsigned part_y(const Geom &G, int y)
 {
-    if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)z;
-    if (LAYOUT == DIFFUS_PAIRED) return (unsigned)z << 5;
-    return (unsigned)(z >> 1) * kBrickFloats + (unsigned)(z & 1);
+    if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)y * G.syB;
+    return __umul24((unsigned)y >> 2, G.syB) + (((unsigned)y & 3u) << 3);
+}
+template <int LAYOUT>
+__device__ __forceinline__ unsigned part_z(int z)
+{
+    if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)z << 2;
+    if (LAYOUT == DIFFUS_PAIRED) return (unsigned)z << 7;
+    return (((unsigned)z >> 1) << 7) | (((unsigned)z & 1u) << 2);
 }
 
 // lerps of one trilinear sample from its 8 corner values (order 000,001,010,011,100,101,110,111 =
-// dim0,dim1,dim2 bits); same operation sequence as oracle/diffus_oracle.c orc_sample_trilinear
+// dim0,dim1,dim2 bits), lerp order dim 2, dim 1, dim 0 like oracle/diffus_oracle.c orc_sample_trilinear.  Each lerp
+// is ONE fused multiply-add, a + t (b - a) rounded once: the fused kernels are VALU-issue-bound (PMC: VALU pipes
+// 60-80 % busy) and the separate multiply and add of the oracle's sequence were 7 (11 with the gradient) of a
+// sample's ~100 instructions.  The result differs from the oracle's by at most the rounding of t (b - a), ~1e-7
+// relative, inside the 1e-5 frame tolerance; the stage-wise kernels (tri_sample) keep the oracle's exact sequence.
 template <bool GRAD>
 __device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a, const Axis &b, const Axis &c)
 {
     float e00 = v[1] - v[0], e01 = v[3] - v[2], e10 = v[5] - v[4], e11 = v[7] - v[6];
-    float c00 = __fadd_rn(v[0], __fmul_rn(c.t, e00)), c01 = __fadd_rn(v[2], __fmul_rn(c.t, e01));
-    float c10 = __fadd_rn(v[4], __fmul_rn(c.t, e10)), c11 = __fadd_rn(v[6], __fmul_rn(c.t, e11));
+    float c00 = __builtin_fmaf(c.t, e00, v[0]), c01 = __builtin_fmaf(c.t, e01, v[2]);
+    float c10 = __builtin_fmaf(c.t, e10, v[4]), c11 = __builtin_fmaf(c.t, e11, v[6]);
     float f0 = c01 - c00, f1 = c11 - c10;
-    float q0 = __fadd_rn(c00, __fmul_rn(b.t, f0)), q1 = __fadd_rn(c10, __fmul_rn(b.t, f1));
+    float q0 = __builtin_fmaf(b.t, f0, c00), q1 = __builtin_fmaf(b.t, f1, c10);
     float g = q1 - q0;
     TriSample s;
-    s.v = __fadd_rn(q0, __fmul_rn(a.t, g));
+    s.v = __builtin_fmaf(a.t, g, q0);
     if (GRAD) {
-        float h0 = __fadd_rn(e00, __fmul_rn(b.t, e01 - e00));
-        float h1 = __fadd_rn(e10, __fmul_rn(b.t, e11 - e10));
+        float h0 = __builtin_fmaf(b.t, e01 - e00, e00);
+        float h1 = __builtin_fmaf(b.t, e11 - e10, e10);
         s.g0 = g * a.m;
-        s.g1 = __fadd_rn(f0, __fmul_rn(a.t, f1 - f0)) * b.m;
-        s.g2 = __fadd_rn(h0, __fmul_rn(a.t, h1 - h0)) * c.m;
+        s.g1 = __builtin_fmaf(a.t, f1 - f0, f0) * b.m;
+        s.g2 = __builtin_fmaf(a.t, h1 - h0, h0) * c.m;
     } else {
         s.g0 = s.g1 = s.g2 = 0.f;
     }
     return s;
 }
 
-// Loads at a 32-bit ELEMENT offset from a wave-uniform base: byte offset formed in 32 bits (element offsets are
-// < 2^30, check_common) so that the compiler emits `global_load v, v_off, s[base]` (SGPR base + 32-bit VGPR offset)
-// instead of building a 64-bit address per lane per load (v_lshl_add_u64 / v_mad_u64_u32: 64 of the forward's 1330
-// VALU instructions).
-__device__ __forceinline__ float ld_f32(const float *base, unsigned off)
+// Loads at a 32-bit BYTE offset from a wave-uniform base (byte offsets are < 2^32: check_common keeps element
+// offsets below 2^30), so that the compiler emits `global_load v, v_off, s[base]` (SGPR base + 32-bit VGPR offset)
+// instead of building a 64-bit address per lane per load.
+__device__ __forceinline__ float ldb_f32(const float *base, unsigned byte_off)
 {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(off << 2));
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
 }
-__device__ __forceinline__ float2 ld_f32x2(const float *base, unsigned off)
+__device__ __forceinline__ float2 ldb_f32x2(const float *base, unsigned byte_off)
 {
-    return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)(off << 2));
+    return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
 }
 
 #ifndef DIFFUS_GATHER_GROUP
@@ -633,13 +682,16 @@ __device__ __forceinline__ float2 ld_f32x2(const float *base, unsigned off)
 // interpolation weights and consumes the values.  The first version (load -> use per corner,
 // behind exec-mask branches) made hipcc emit `s_waitcnt vmcnt(0)` after almost every load:
 // ~50 dependent memory round trips per wave, 43 % of wave time in SQ_WAIT_ANY.
-template <int C, int SAMPLER, int LAYOUT, bool GRAD, int PM>
-__device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int segN, const Pose &ps, int lane, float (&z)[C],
-                                                   float (&g0)[C], float (&g1)[C], float (&g2)[C])
+// ZCONST: the ray does not move along dim 2 (direction component exactly 0 -- every fan of the reference,
+// src/cone.py:258): p2 = s2 + k*0 = s2 for every sample, so that axis' cell, weight and offset are computed once.
+template <int C, int SAMPLER, int LAYOUT, bool GRAD, int PM, bool ZCONST>
+__device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, int segN, const Pose &ps, int lane, float (&z)[C],
+                                                     float (&g0)[C], float (&g1)[C], float (&g2)[C])
 {
     constexpr int G = (C < DIFFUS_GATHER_GROUP) ? C : DIFFUS_GATHER_GROUP;
     constexpr int NV = (SAMPLER == DIFFUS_NEAREST) ? 1 : 8;
     const float *__restrict__ vol = A.vol;
+    const float kf0 = (float)(A.start + seg0 + lane);
 #pragma unroll
     for (int gb = 0; gb < C; gb += G) {
         float raw[G][NV];
@@ -648,36 +700,44 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int 
         // ---- phase A: addresses + loads
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) {
-            int n = min((gb + jj) * kWave + lane, segN - 1);
-            int k = A.start + seg0 + n;
-            float p0 = ray_point<PM>(ps, 0, k), p1 = ray_point<PM>(ps, 1, k), p2 = ray_point<PM>(ps, 2, k);
+            // step index as a float (exact: k < 2^24).  Lanes past the end of the ray sample further along it -- any
+            // point is clamped into the volume, so the loads stay in bounds -- and are masked in phase B.
+            const float kf = kf0 + (float)((gb + jj) * kWave);
+            const float p0 = ray_point_f<PM>(ps, 0, kf), p1 = ray_point_f<PM>(ps, 1, kf);
+            const float p2 = ray_point_f<PM>(ps, 2, ZCONST ? 0.f : kf); // ZCONST: loop-invariant, hoisted with all that follows from it
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
                 int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
-                raw[jj][0] = ld_f32(vol, col_off<LAYOUT>(A.G, i0, i1) + z_off<LAYOUT>(i2));
+                raw[jj][0] = ldb_f32(vol, part_x<LAYOUT>(A.G, i0) + part_y<LAYOUT>(A.G, i1) + part_z<LAYOUT>(i2));
             } else {
                 Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1), c = tri_axis(p2, A.G.d2);
-                unsigned c00 = col_off<LAYOUT>(A.G, a.i0, b.i0), c01 = col_off<LAYOUT>(A.G, a.i0, b.i1);
-                unsigned c10 = col_off<LAYOUT>(A.G, a.i1, b.i0), c11 = col_off<LAYOUT>(A.G, a.i1, b.i1);
-                unsigned z0 = z_off<LAYOUT>(c.i0), z1 = z_off<LAYOUT>(c.i1);
+                const unsigned x0 = part_x<LAYOUT>(A.G, a.i0), x1 = part_x<LAYOUT>(A.G, a.i1);
+                const unsigned y0 = part_y<LAYOUT>(A.G, b.i0), y1 = part_y<LAYOUT>(A.G, b.i1);
+                const unsigned z0 = part_z<LAYOUT>(c.i0);
                 if constexpr (LAYOUT == DIFFUS_PAIRED) { // 4 aligned 8-byte loads: (z0, z0+1) of each column
-                    float2 q00 = ld_f32x2(vol, c00 + z0);
-                    float2 q01 = ld_f32x2(vol, c01 + z0);
-                    float2 q10 = ld_f32x2(vol, c10 + z0);
-                    float2 q11 = ld_f32x2(vol, c11 + z0);
+#ifdef DIFFUS_ABLATE_LOADS // timing probe (tools/): the addresses are computed, nothing is loaded
+                    float2 q00 = make_float2(__uint_as_float(x0 + y0 + z0), 1.f), q01 = make_float2(__uint_as_float(x0 + y1 + z0), 1.f);
+                    float2 q10 = make_float2(__uint_as_float(x1 + y0 + z0), 1.f), q11 = make_float2(__uint_as_float(x1 + y1 + z0), 1.f);
+#else
+                    float2 q00 = ldb_f32x2(vol, x0 + y0 + z0);
+                    float2 q01 = ldb_f32x2(vol, x0 + y1 + z0);
+                    float2 q10 = ldb_f32x2(vol, x1 + y0 + z0);
+                    float2 q11 = ldb_f32x2(vol, x1 + y1 + z0);
+#endif
                     raw[jj][0] = q00.x; raw[jj][1] = q00.y; raw[jj][2] = q01.x; raw[jj][3] = q01.y;
                     raw[jj][4] = q10.x; raw[jj][5] = q10.y; raw[jj][6] = q11.x; raw[jj][7] = q11.y;
-                    (void)z1;
                 } else {
+                    const unsigned z1 = part_z<LAYOUT>(c.i1);
+                    const unsigned c00 = x0 + y0, c01 = x0 + y1, c10 = x1 + y0, c11 = x1 + y1;
 #ifdef DIFFUS_ABLATE_LOADS
                 raw[jj][0] = __uint_as_float(c00 + z0); raw[jj][1] = __uint_as_float(c00 + z1);
                 raw[jj][2] = __uint_as_float(c01 + z0); raw[jj][3] = __uint_as_float(c01 + z1);
                 raw[jj][4] = __uint_as_float(c10 + z0); raw[jj][5] = __uint_as_float(c10 + z1);
                 raw[jj][6] = __uint_as_float(c11 + z0); raw[jj][7] = __uint_as_float(c11 + z1);
 #else
-                raw[jj][0] = ld_f32(vol, c00 + z0); raw[jj][1] = ld_f32(vol, c00 + z1);
-                raw[jj][2] = ld_f32(vol, c01 + z0); raw[jj][3] = ld_f32(vol, c01 + z1);
-                raw[jj][4] = ld_f32(vol, c10 + z0); raw[jj][5] = ld_f32(vol, c10 + z1);
-                raw[jj][6] = ld_f32(vol, c11 + z0); raw[jj][7] = ld_f32(vol, c11 + z1);
+                raw[jj][0] = ldb_f32(vol, c00 + z0); raw[jj][1] = ldb_f32(vol, c00 + z1);
+                raw[jj][2] = ldb_f32(vol, c01 + z0); raw[jj][3] = ldb_f32(vol, c01 + z1);
+                raw[jj][4] = ldb_f32(vol, c10 + z0); raw[jj][5] = ldb_f32(vol, c10 + z1);
+                raw[jj][6] = ldb_f32(vol, c11 + z0); raw[jj][7] = ldb_f32(vol, c11 + z1);
 #endif
                 }
                 ta[jj] = a.t; tb[jj] = b.t; tc[jj] = c.t;
@@ -723,6 +783,22 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int 
     }
 }
 
+template <int C, int SAMPLER, int LAYOUT, bool GRAD, int PM>
+__device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int segN, const Pose &ps, int lane, float (&z)[C],
+                                                   float (&g0)[C], float (&g1)[C], float (&g2)[C])
+{
+    // wave-uniform (the pose sits in SGPRs): a whole wave takes one of the two copies of the gather
+#ifdef DIFFUS_COUNT_PLANAR // tools/kernel_resources.py -DDIFFUS_COUNT_PLANAR=1|0: static count of ONE of the two copies
+    const bool planar = DIFFUS_COUNT_PLANAR;
+#else
+    const bool planar = (PM == 0 || ps.pmode != 2) ? (ps.df[2] == 0.f) : (ps.dd[2] == 0.0);
+#endif
+    if (planar)
+        gather_interleaved_z<C, SAMPLER, LAYOUT, GRAD, PM, true>(A, seg0, segN, ps, lane, z, g0, g1, g2);
+    else
+        gather_interleaved_z<C, SAMPLER, LAYOUT, GRAD, PM, false>(A, seg0, segN, ps, lane, z, g0, g1, g2);
+}
+
 // r'_{n-1} for the lane's samples (CHUNKED): r[j] couples sample n-1 and n
 // (n = lane*C+j).  r = 0 (identity transfer matrix) for n = 0 and n >= N1; with
 // start > 0 the first kept coefficient is replaced by the per-pose median
@@ -761,10 +837,9 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
         if (!FAST || (j & 3) == 3 || j == C - 1) mat_renorm(L);
     }
     {
-        const Mat I = mat_identity();
 #define DIFFUS_ROUND(CTRL, RMASK, HAS)             \
     {                                              \
-        const Mat o = mat_dpp<CTRL, RMASK>(I, L);  \
+        const Mat o = mat_dpp_get<CTRL, RMASK>(L); \
         if (HAS) {                                 \
             L = mat_mul(o, L);                     \
             mat_renorm(L);                         \

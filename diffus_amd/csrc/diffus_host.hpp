@@ -10,12 +10,27 @@ namespace {
 // host side
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-Geom make_geom(int d0, int d1, int d2)
+// byte strides of the gather's separable offsets (diffus_device.hpp part_x / part_y) for a volume layout
+size_t stride_x_bytes(int layout, int d1, int d2)
+{
+    const size_t nb1 = (size_t)(d1 + 3) / 4, nb2 = (size_t)(d2 + 1) / 2;
+    if (layout == DIFFUS_CANONICAL) return (size_t)d1 * d2 * 4;
+    return layout == DIFFUS_PAIRED ? nb1 * d2 * 128 : nb1 * nb2 * 128;
+}
+size_t stride_y_bytes(int layout, int d2)
+{
+    if (layout == DIFFUS_CANONICAL) return (size_t)d2 * 4;
+    return layout == DIFFUS_PAIRED ? (size_t)d2 * 128 : (size_t)((d2 + 1) / 2) * 128;
+}
+
+Geom make_geom(int d0, int d1, int d2, int layout = DIFFUS_CANONICAL)
 {
     Geom G;
     G.d0 = d0; G.d1 = d1; G.d2 = d2;
     G.nb1 = (d1 + 3) / 4;
     G.nb2 = (d2 + 1) / 2;
+    G.sxB = (unsigned)stride_x_bytes(layout, d1, d2);
+    G.syB = (unsigned)stride_y_bytes(layout, d2);
     return G;
 }
 
@@ -88,22 +103,26 @@ int check_common(const float *vol, int d0, int d1, int d2, const void *src, int 
     if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24)) return DIFFUS_EUNSUPPORTED; // float(dim-1) must be exact
     if (bricked_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;    // 32-bit element offsets
     if (layout == DIFFUS_PAIRED && paired_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;
+    // bricked / paired: the brick-row stride is the 24-bit operand of a v_mul_u32_u24 (part_x); slices of 2^17 bricks
+    // or more (e.g. 2048 x 1024) are not bricked -- the caller keeps such a volume canonical
+    if (layout != DIFFUS_CANONICAL && stride_x_bytes(layout, d1, d2) >= ((size_t)1 << 24)) return DIFFUS_EUNSUPPORTED;
     if (need_scan && S - start > DIFFUS_MAX_SAMPLES * DIFFUS_MAX_SEGMENTS) return DIFFUS_EUNSUPPORTED;
     if (start > 0 && (size_t)R * sizeof(float) > 64 * 1024) return DIFFUS_EUNSUPPORTED; // median LDS
     return DIFFUS_OK;
 }
 
-Args make_args(const float *vol, int d0, int d1, int d2, const void *src, int src_dtype, const void *dirs,
+Args make_args(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype, const void *dirs,
                int dirs_dtype, int P, int R, int S, int start, float alpha, const Workspace &ws)
 {
     Args A{};
     A.vol = vol;
-    A.G = make_geom(d0, d1, d2);
+    A.G = make_geom(d0, d1, d2, layout);
     A.src = src; A.dirs = dirs;
     A.src_f64 = src_dtype == DIFFUS_F64; A.dir_f64 = dirs_dtype == DIFFUS_F64;
     A.P = P; A.R = R; A.S = S; A.start = start; A.N1 = S - start;
     A.seg0 = 0; A.segN = A.N1; // one launch covers the ray unless the caller loops over segments
     A.neg_alpha = -alpha;
+    A.neg_alpha_l2e = (float)(-(double)alpha * 1.4426950408889634);
     A.med = ws.med; A.who = ws.who; A.gmed = ws.gmed;
     return A;
 }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = j * kWave + lane;
-            zi[j] = (n < segN) ? gin[n] * fast_exp(__fmul_rn(A.neg_alpha, (float)(seg0 + n))) : 0.f;
+            zi[j] = (n < segN) ? gin[n] * fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n)) : 0.f;
         }
         to_chunked<C>(wb, lane, zi, gb);
     }
@@ -84,11 +84,10 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     int iota = lam;       // inclusive prefix exponent
     {
         // six scan rounds on the DPP path (diffus_device.hpp): matrix and exponent move together
-        const Mat I = mat_identity();
 #define DIFFUS_ROUND(CTRL, RMASK, HAS)                   \
     {                                                    \
-        const Mat o = mat_dpp<CTRL, RMASK>(I, L);        \
-        const int oe = dpp_mov<CTRL, RMASK>(0, iota);    \
+        const Mat o = mat_dpp_get<CTRL, RMASK>(L);       \
+        const int oe = dpp_get<CTRL, RMASK>(iota);       \
         if (HAS) {                                       \
             L = mat_mul(o, L);                           \
             iota = oe + iota - mat_renorm(L);            \
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
 #undef DIFFUS_ROUND
     }
     Mat Pm = mat_lane_prev(L, mat_identity()); // exclusive prefix (lane 0: identity) ...
-    int eps = lane_prev(iota, 0);              // ... and its exponent
+    int eps = lane_prev0(iota);                // ... and its exponent
     if (cin) { // segment > 0: P'_{seg0-1} of the carry-only forward pass precedes everything (its scale is exponent 0)
         Pm = mat_mul(Mat{cin[w * 5 + 0], cin[w * 5 + 1], cin[w * 5 + 2], cin[w * 5 + 3]}, Pm);
         eps -= mat_renorm(Pm);
@@ -115,22 +114,27 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         Pm = mat_step(Pm, r[j]);
         ex[j] = ((j & 3) == 3 || j == C - 1) ? mat_renorm(Pm) : 0; // compile-time schedule: the zeros fold away
         esum += ex[j];
-        float rd = __builtin_amdgcn_rcpf(Pm.d);
-        float e = Pm.b * rd;
-        float g = (e == e) ? gb[j] : 0.f; // echoes zeroed by nan_to_num are constants
-        float q = g * rd;
-        gu[j] = (g != 0.f) ? q : 0.f;
-        rho[j] = (e == e) ? e : 0.f;
-        // past a non-finite reflection coefficient every echo is the constant 0
-        if (!finitef(r[j]) || !mat_finite(Pin[j]) || !finitef(gu[j]) || !finitef(rho[j])) gu[j] = 0.f;
+        const float rd = __builtin_amdgcn_rcpf(Pm.d);
+        const float e = Pm.b * rd;
+        const bool num = (e == e);         // echoes zeroed by nan_to_num are constants: no gradient through them
+        const float q = (num ? gb[j] : 0.f) * rd;
+        rho[j] = num ? e : 0.f;
+        // Nothing but a finite seed may enter the adjoint chain (a NaN in U would wipe out every earlier step as well).
+        // Two compares are enough: a non-finite r or P'_{n-1} makes P'_n -- hence e or q -- non-finite too, an infinite
+        // echo fails the second test, and 0 * inf = NaN fails the first.  (Per-entry tests of r and P'_{n-1} here
+        // were 6 more compares and a branch per sample.)
+        gu[j] = (finitef(q) && finitef(e)) ? q : 0.f;
     }
 
     // exponent of this lane's last P' and the hop to the next lane's exclusive prefix
     const int elast = eps - esum;
-    const int eps_next = lane_next(eps, 0);
+    const int eps_next = lane_next0(eps);
     const int delta = (lane == kWave - 1) ? 0 : (eps_next - elast);
 
     // ---- lane-local affine map: A-part = sweep from U = 0 ----
+    float rr[C]; // r with non-finite steps cut (U is zero there anyway)
+#pragma unroll
+    for (int j = 0; j < C; ++j) rr[j] = finitef(r[j]) ? r[j] : 0.f;
     auto sweep = [&](Mat U, float *rbar) {
 #pragma unroll
         for (int j = C - 1; j >= 0; --j) {
@@ -144,8 +148,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
                 Mat Tb = mat_mul_at(Pin[j], W);
                 rbar[j] = __builtin_fmaf(-4.f * r[j], Tb.a, Tb.b - Tb.c);
             }
-            float rr = finitef(r[j]) ? r[j] : 0.f; // non-finite step: cut the chain (U is zero there anyway)
-            U = mat_mul_bt(W, mat_of_r(rr));
+            U = mat_mul_bt(W, mat_of_r(rr[j]));
         }
         return U;
     };
@@ -159,7 +162,6 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     // first lane of the row above (lanes 16 / 48, then lane 32) broadcast downwards.  DPP has no broadcast in that
     // direction, so those two rounds read the lane through an SGPR (v_readlane_b32).
     {
-        const Mat Z{0.f, 0.f, 0.f, 0.f}, I = mat_identity();
         auto combine = [&](const Mat &oA, const Mat &oB, int ob) {
             Mat t = mat_scale(mat_mul_bt(oA, Bn), beta);
             Aacc.a += t.a; Aacc.b += t.b; Aacc.c += t.c; Aacc.d += t.d;
@@ -168,9 +170,9 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         };
 #define DIFFUS_ROUND_DOWN(N)                                        \
     {                                                               \
-        const Mat oA = mat_dpp<kDppRowShl + N>(Z, Aacc);            \
-        const Mat oB = mat_dpp<kDppRowShl + N>(I, Bn);              \
-        const int ob = dpp_mov<kDppRowShl + N>(0, beta);            \
+        const Mat oA = mat_dpp_get<kDppRowShl + N>(Aacc);           \
+        const Mat oB = mat_dpp_get<kDppRowShl + N>(Bn);             \
+        const int ob = dpp_get<kDppRowShl + N>(beta);               \
         if ((lane & 15) + N < 16) combine(oA, oB, ob);              \
     }
         DIFFUS_ROUND_DOWN(1)
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
             if (lane < 32) combine(a32, b32, e32);
         }
     }
-    Mat Uin = mat_lane_next(Aacc, Mat{0.f, 0.f, 0.f, 0.f}); // lane 63: nothing enters from above
+    Mat Uin = mat_lane_next0(Aacc); // lane 63: nothing enters from above (0)
     if (uin) {
         // Adjoint entering from the next segment.  It was written relative to the scale of that segment's
         // carry-in P' (cnext); lane 63's final P' is the same matrix up to a power of two (idle samples
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
             Uc = Mat{0.f, 0.f, 0.f, 0.f};
         // U entering lane l = G_{l+1}(Uc) = Aacc_{l+1} + Uc (B_{l+1} 2^beta_{l+1})^T
         const Mat Bs = mat_lane_next(Bn, mat_identity());
-        const int bs = lane_next(beta, 0);
+        const int bs = lane_next0(beta);
         Mat t = mat_scale(mat_mul_bt(Uc, Bs), bs);
         Uin.a += t.a; Uin.b += t.b; Uin.c += t.c; Uin.d += t.d;
         if (lane == kWave - 1) Uin = Uc;
@@ -233,9 +235,8 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         int n = seg0 + n0 + j;
         bool live = (n >= 1 && n0 + j < segN);
         float rb = live ? rbar[j] : 0.f;
-        if (!finitef(rb)) rb = 0.f; // drop non-finite
-        if (n == 1 && A.start > 0) {
-            gmed_lane = rb;
+        if (n == 1 && A.start > 0) { // the first kept coefficient is the per-pose median: its gradient goes there
+            gmed_lane = finitef(rb) ? rb : 0.f;
             rb = 0.f;
         }
         float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         float dz = 2.f * zp * inv * inv;     // d r / d Z_n
         float dzp = -2.f * z[j] * inv * inv; // d r / d Z_{n-1}
         float c1 = rb * dz, c0 = rb * dzp;
-        if (!finitef(c1)) c1 = 0.f;
+        if (!finitef(c1)) c1 = 0.f; // drop non-finite contributions (a non-finite rbar makes both of them so)
         if (!finitef(c0)) c0 = 0.f;
         zbar[j] += c1;
         if (j == 0)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         else
             zbar[j == 0 ? 0 : j - 1] += c0;
     }
-    const float cnb = lane_next(carry, 0.f);
+    const float cnb = lane_next0(carry);
     if (lane != kWave - 1) zbar[C - 1] += cnb;
     if (zcout && lane == 0) zcout[w] = carry; // belongs to the last sample of the previous segment
     if (zcin) {
@@ -455,7 +456,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
         if (gdirs && hipMemsetAsync(gdirs, 0, sizeof(float) * (size_t)P * R * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
     }
     if (sampler == DIFFUS_NEAREST && !gvol) return DIFFUS_OK;
-    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
+    Args A = make_args(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.gframe = gframe;
     A.gvol = gvol;
     A.gtouched = (gvol && layout != DIFFUS_CANONICAL) ? gvol_touched : nullptr;

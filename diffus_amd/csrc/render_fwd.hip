@@ -3,6 +3,18 @@
 
 namespace {
 
+#ifdef DIFFUS_STAMP // diagnostic build only (tools/fwd_stamps.py): per-wave phase timestamps of the forward kernel
+__device__ unsigned long long *g_fwd_stamps = nullptr;
+#define STAMPW(i)                                                                                             \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (g_fwd_stamps && lane == 0) g_fwd_stamps[(size_t)w * 8 + (i)] = __builtin_readcyclecounter();      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#else
+#define STAMPW(i) ((void)0)
+#endif
+
 // ----------------------------------------------------------------------------
 // FORWARD  (replaces reference src/renderer.py:201-275 with artifacts=False)
 #ifndef DIFFUS_FWD_MIN_WAVES
@@ -25,6 +37,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
     const int n0 = lane * C;
     float *wb = lds[wib];
 
+    STAMPW(0);
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
@@ -35,12 +48,14 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #else
     gather_interleaved<C, SAMPLER, LAYOUT, false, PM>(A, seg0, segN, ps, lane, zi, u0, u1, u2);
 #endif
+    STAMPW(1);
 #ifdef DIFFUS_ABLATE_TRANSPOSE
 #pragma unroll
     for (int j = 0; j < C; ++j) z[j] = zi[j];
 #else
     to_chunked<C>(wb, lane, zi, z);
 #endif
+    STAMPW(2);
     float zprev = lane_prev(z[C - 1], z[C - 1]); // last sample of the lane below (lane 0: unused unless a carry comes in)
     Mat K = mat_identity(), Klast = mat_identity();
     if (cin) { // carry of the earlier segments: running product and the sample just before this segment
@@ -49,6 +64,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
     }
     float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r);
+    STAMPW(3);
 #ifdef DIFFUS_ABLATE_SCAN
 #pragma unroll
     for (int j = 0; j < C; ++j) e[j] = r[j];
@@ -66,10 +82,11 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
         }
     }
     if (SEG && !A.frame) return; // carry-only pass (first half of a segmented backward)
+    STAMPW(4);
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        // attenuation, reference :256-259: f32(-alpha) * f32(n), exp, multiply
-        float att = fast_exp(__fmul_rn(A.neg_alpha, (float)(seg0 + n0 + j)));
+        // attenuation, reference :256-259: exp(-alpha * n), as exp2 of the pre-scaled exponent
+        float att = fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
         e[j] = __fmul_rn(e[j], att);
     }
 #ifdef DIFFUS_ABLATE_TRANSPOSE
@@ -78,6 +95,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #else
     to_interleaved<C>(wb, lane, e, zi);
 #endif
+    STAMPW(5);
     float *out = A.frame + w * A.N1 + seg0;
 #ifdef DIFFUS_ABLATE_STORE
     float acc = 0.f;
@@ -92,6 +110,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
     }
 #endif
 
+    STAMPW(6);
     if (A.idx) {
         const long plane = (long)A.P * A.R * A.N1;
         long long *ix = A.idx + w * A.N1 + seg0;
@@ -260,7 +279,7 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, cons
     Workspace ws = carve(workspace, P, R, S - start);
     if ((start > 0 || ws.nseg > 1) && (!workspace || workspace_bytes < ws.bytes)) return DIFFUS_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
+    Args A = make_args(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.frame = frame;
     A.idx = (long long *)idx;
     if (start > 0) {
@@ -288,7 +307,7 @@ int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout, cons
     if (rc) return rc;
     if (!imp && !refl && !idx) return DIFFUS_OK;
     Workspace ws = carve(nullptr, P, R, S);
-    Args A = make_args(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, 0.f, ws);
+    Args A = make_args(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, 0, 0.f, ws);
     const long total = (long)P * R * S;
     unsigned nblk = (unsigned)((total + kBlock - 1) / kBlock);
     if (nblk > 256u * 16u) nblk = 256u * 16u;
@@ -300,7 +319,13 @@ int diffus_trace_rays(const float *vol, int d0, int d1, int d2, int layout, cons
     });
 }
 
-// ---- scan conversion ----
+#ifdef DIFFUS_STAMP
+int diffus_debug_set_fwd_stamps(unsigned long long *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
+
 
 int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stream_t stream)
 {

@@ -10,10 +10,11 @@ namespace {
 // (measured: 17.5 ms for 33 M atomics at config 3).  Instead a block takes a PATCH
 // of kPatchRays adjacent rays x kPatchSteps consecutive steps of one pose, whose
 // footprint is a small box of voxels; it accumulates the patch into an LDS tile
-// covering that box (ds_add_f32) and flushes each touched voxel ONCE.  In the
-// bricked layout the tile is a box of whole bricks, so the flush is made of
-// 128-B contiguous atomic runs (the full-rate shape of global_atomic_add_f32).
-// Patches whose box does not fit the tile fall back to direct global atomics.
+// covering that box -- in int32 fixed point with ds_add_u32, see the kernel -- and
+// flushes each touched voxel ONCE with global_atomic_add_f32.  In the bricked layout
+// the tile is a box of whole bricks, so the flush is made of 128-B contiguous atomic
+// runs (the full-rate shape of that atomic).  A patch whose box exceeds the tile goes
+// through it as 2 or 4 groups of waves, each with its own box.
 #ifdef DIFFUS_STAMP // diagnostic build only (tools/): per-block phase timestamps of the scatter kernel
 __device__ unsigned long long *g_stamps = nullptr;
 #define STAMP(i)                                                                          \
@@ -40,7 +41,7 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
 #endif
 constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kPatchRays * kPatchSteps / kSB;
 template <int SAMPLER, int LAYOUT, int PM>
-__global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
+__global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
 {
     // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
     // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
@@ -50,9 +51,16 @@ __global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_grou
     // receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution,
     // typically 2^-23..2^-26; integer adds commute, so a tile sum is bitwise reproducible.
     __shared__ __attribute__((aligned(16))) int tile[kTileCap];
-    __shared__ int s_wlo[kSW][3], s_whi[kSW][3], s_max; // per-WAVE boxes (a wave = 64 / kSW rays x 64 steps)
+    __shared__ int s_wlo[kSW][3], s_whi[kSW][3]; // per-WAVE boxes (a wave = 64 / kPatchSteps * kSPT rays x kPatchSteps steps)
     __shared__ float s_sum[kSW];
+    __shared__ int s_planar[kSW];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
+    // PLANAR patches (bricked gradient, trilinear): no ray of the patch moves along dim 2 -- every fan of the reference
+    // (src/cone.py:258) -- so all its samples share ONE dim-2 cell (iz0, iz1, tz).  The tile then holds the 2-D
+    // footprint only, 16 entries per brick column: 4 LDS adds per sample instead of 8, half (z0 even) or a quarter
+    // (z0 odd) of the tile entries, and the two depth weights are applied once per entry in the flush.
+    constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED) && (SAMPLER == DIFFUS_TRILINEAR);
+    constexpr int UNIT2 = 16; // tile entries per brick column in planar mode
 
     if (blockIdx.x >= npatch) { // tail blocks of the launch: d/dsource[pose] = fixed-order sum of the per-ray partials
         reduce_gsrc_block(A.gsrc_part, A.gsrc_out, A.R, (int)(blockIdx.x - npatch), reinterpret_cast<float *>(tile));
@@ -68,27 +76,25 @@ __global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_grou
     const int rg = Lb % ray_groups;
     const int pose = Lb / ray_groups;
     const int tid = threadIdx.x;
-    // thread -> ray (tid / 16) and 4 consecutive steps ((tid % 16) * 4 ..)
+    // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..)
     const int ray = rg * kPatchRays + tid / (kPatchSteps / kSPT);
     const int nbase = sg * kPatchSteps + (tid % (kPatchSteps / kSPT)) * kSPT;
     const bool ray_ok = ray < A.R;
     const long w = (long)pose * A.R + (ray_ok ? ray : 0);
 
     STAMP(0);
-    if (tid == 0) s_max = 0;
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     Cell cells[kSPT];
     float zb[kSPT];
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-    float zmax = 0.f;
 #pragma unroll
     for (int q = 0; q < kSPT; ++q) { // issue the loads first ...
         int n = nbase + q;
         zb[q] = 0.f;
         if (ray_ok && n < A.N1) zb[q] = A.zbar[w * A.N1 + n];
     }
-    // ... and clear the WHOLE tile while they are in flight (12 ds_write_b128 per thread, ~400 cycles per block):
+    // ... and clear the WHOLE tile while they are in flight (6 ds_write_b128 per thread, ~400 cycles per block):
     // clearing just the bounding box afterwards was a phase of its own with its own barrier (10 % of the block's time)
     {
         int4 *t4 = reinterpret_cast<int4 *>(tile);
@@ -96,12 +102,14 @@ __global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_grou
         for (int e = 0; e < kTileCap / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
         static_assert(kTileCap % (4 * kSB) == 0, "tile clear assumes whole int4 passes");
     }
+    // the cells need the pose only: they are worked out while the zbar loads are still in flight
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) cells[q] = cell_of<SAMPLER, PM>(A, ps, A.start + nbase + q);
+    float zsum = 0.f;
 #pragma unroll
     for (int q = 0; q < kSPT; ++q) {
-        int n = nbase + q;
         if (!finitef(zb[q])) zb[q] = 0.f;
-        cells[q] = cell_of<SAMPLER, PM>(A, ps, A.start + n);
-        zmax = fmaxf(zmax, fabsf(zb[q]));
+        zsum += fabsf(zb[q]);
         if (zb[q] != 0.f) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -111,46 +119,50 @@ __global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_grou
         }
     }
     STAMP(1);
-    // block bounding box: DPP wave reduce, then one LDS atomic per wave
+    // per-wave bounding boxes and sum of |zbar|: DPP reductions (6 instructions each), one LDS record per wave
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         lo[a] = wave_reduce_minmax<true>(lo[a]);
         hi[a] = wave_reduce_minmax<false>(hi[a]);
     }
-    zmax = __int_as_float(wave_reduce_minmax<false>(__float_as_int(zmax))); // zmax >= 0: bits order like floats
-    float zsum = 0.f;
-#pragma unroll
-    for (int q = 0; q < kSPT; ++q) zsum += fabsf(zb[q]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) zsum += __shfl_xor(zsum, off, kWave);
-    __syncthreads();
+    zsum = wave_sum_to_lane63(zsum);
+    const bool ray_planar = (PM == 0 || ps.pmode != 2) ? (ps.df[2] == 0.f) : (ps.dd[2] == 0.0);
+    const bool wave_planar = kCanPlanar && __ballot(ray_planar) == ~0ull;
     const int wib = tid >> 6;
-    if ((tid & 63) == 0) {
+    if ((tid & 63) == 63) {
+        s_planar[wib] = wave_planar;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             s_wlo[wib][a] = lo[a];
             s_whi[wib][a] = hi[a];
         }
-        atomicMax(&s_max, __float_as_int(zmax)); // non-negative floats order like their bit patterns
         s_sum[wib] = zsum;
     }
-    __syncthreads();
+    __syncthreads(); // also: the tile is clear
     STAMP(2);
     // The patch goes through the tile in ONE pass if its bounding box fits, else as 2 or 4 groups of waves (a wave =
-    // 4 rays x 64 steps, a thin strip), each with its own box.  (The first version sent oversized patches -- 1.4 % of
+    // 8 rays x 32 steps), each with its own box.  (The first version sent oversized patches -- 1.4 % of
     // them at config 3 -- to direct global atomics: those 58 blocks took 3x as long as the rest and were the kernel's
     // tail; a 64 KiB tile without any fallback ran 62 us against 70.)
-    int wlo[kSW][3], whi[kSW][3]; // the four wave boxes, in registers
+    // Everything from here to the accumulation is BLOCK-UNIFORM bookkeeping: it is moved into SGPRs
+    // (readfirstlane) so that it runs on the scalar unit, in 32-bit saturating arithmetic -- as 64-bit VALU
+    // arithmetic repeated by all 256 threads it was 15 % of a block's time.
+    int wlo[kSW][3], whi[kSW][3]; // the wave boxes, wave-uniform
 #pragma unroll
     for (int wv = 0; wv < kSW; ++wv)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            wlo[wv][a] = s_wlo[wv][a];
-            whi[wv][a] = s_whi[wv][a];
+            wlo[wv][a] = __builtin_amdgcn_readfirstlane(s_wlo[wv][a]);
+            whi[wv][a] = __builtin_amdgcn_readfirstlane(s_whi[wv][a]);
         }
-    // box of the waves [w0, w0 + cnt) (compile-time cnt); volume 0 for an empty group, saturated when huge
-    auto box_of = [&](int w0, int cnt, int (&l)[3], int (&b)[3]) -> long {
-        long v = UNIT;
+    int all_planar = 1; // no short-circuit: the four flags come back with the box records, in one LDS round trip
+#pragma unroll
+    for (int wv = 0; wv < kSW; ++wv) all_planar &= s_planar[wv];
+    const bool planar = kCanPlanar && __builtin_amdgcn_readfirstlane(all_planar) != 0;
+    // box of the waves [w0, w0 + cnt); tile entries it needs: 0 for an empty group, kTileCap + 1 when it does not fit
+    auto box_of = [&](int w0, int cnt, int (&l)[3], int (&b)[3]) -> int {
+        unsigned v = planar ? UNIT2 : UNIT;
+        bool empty = false;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             int mn = 0x7fffffff, mx = -1;
@@ -162,31 +174,31 @@ __global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_grou
             }
             l[a] = mn;
             b[a] = mx - mn + 1;
-            v = (mx < 0) ? 0 : v * b[a];
-            if (v > ((long)1 << 40)) v = (long)1 << 40; // only "> kTileCap" matters
+            empty |= mx < 0;
+            // only "> kTileCap" matters: saturate so that the 32-bit product cannot overflow
+            const unsigned e = (a == 2 && planar) ? 1u : (unsigned)min(max(b[a], 0), 0x7fff);
+            v = min(v, (unsigned)kTileCap + 1u) * e;
         }
-        return v;
+        return empty ? 0 : (int)min(v, (unsigned)kTileCap + 1u);
     };
     static_assert(kSW == 4 || kSW == 8, "wave grouping below: 1, 2 or 4 groups of waves");
     int nsub = 1;
-    {
+    int lb[3], bb[3];
+    int vol_tile = box_of(0, kSW, lb, bb); // the whole patch: 85 % of the patches need nothing else
+    if (vol_tile > kTileCap) {
         int l[3], b[3];
-        if (box_of(0, kSW, l, b) > kTileCap) {
-            nsub = 2;
-            if (box_of(0, kSW / 2, l, b) > kTileCap || box_of(kSW / 2, kSW / 2, l, b) > kTileCap) nsub = 4;
-        }
+        nsub = 2;
+        if (box_of(0, kSW / 2, l, b) > kTileCap || box_of(kSW / 2, kSW / 2, l, b) > kTileCap) nsub = 4;
     }
     // (s_sum total) * 2^fx in [2^28, 2^29): headroom for the rounding of each contribution
-    float ztot = 0.f;
+    float ztot = 0.f; // >= every single |zbar| of the patch (a float sum of non-negative terms is monotone)
 #pragma unroll
-    for (int wv = 0; wv < kSW; ++wv) ztot += s_sum[wv];
-    ztot = fmaxf(ztot, __int_as_float(s_max));
+    for (int wv = 0; wv < kSW; ++wv) ztot += __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_sum[wv])));
     const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
     const int wpg = kSW / nsub; // waves per group
 #pragma unroll 1
     for (int sp = 0; sp < nsub; ++sp) { // block-uniform trip count and branches
-    int lb[3], bb[3];
-    const long vol_tile = box_of(sp * wpg, wpg, lb, bb);
+    if (nsub > 1) vol_tile = box_of(sp * wpg, wpg, lb, bb);
     if (vol_tile == 0) continue; // nothing to add in this group
     const bool mine = (wib / wpg) == sp;
     // keep the per-sample weights INSIDE the trip: hoisted out of this (almost always single-trip) loop they cost
@@ -213,8 +225,81 @@ __global__ __launch_bounds__(kSB) void scatter_patch_kernel(Args A, int ray_grou
         continue;
     }
     const int l0 = lb[0], l1 = lb[1], l2 = lb[2], b0 = bb[0], b1 = bb[1], b2 = bb[2];
-    const int nt = (int)vol_tile;
+    const int nt = vol_tile;
     STAMP(3);
+    if (kCanPlanar && planar) {
+        // ---- planar patch: 2-D tile, entry = (brick column, x & 3, y & 3) ----
+        auto part2 = [&](int v, int axis) -> int {
+            return axis == 0 ? ((((v >> 2) - l0) * b1) * UNIT2 + ((v & 3) << 2)) : ((((v >> 2) - l1) * UNIT2) + (v & 3));
+        };
+#pragma unroll
+        for (int q = 0; q < kSPT; ++q)
+            if (mine && zb[q] != 0.f) {
+                const Cell &c = cells[q];
+                const float sc = ldexpf(zb[q], fx);
+                const int ex0 = part2(c.i0[0], 0), ex1 = part2(c.i1[0], 0), ey0 = part2(c.i0[1], 1), ey1 = part2(c.i1[1], 1);
+                const float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1;
+                auto add = [&](int e, float v) {
+                    int qi = __float2int_rn(v);
+                    if (qi != 0) atomicAdd(&tile[e], qi);
+                };
+                add(ex0 + ey0, sc * wa0 * wb0);
+                add(ex0 + ey1, sc * wa0 * wb1);
+                add(ex1 + ey0, sc * wa1 * wb0);
+                add(ex1 + ey1, sc * wa1 * wb1);
+            }
+        // the patch's dim-2 cell (the same in every thread: p2 = source[2] for every sample)
+        const int iz0 = __builtin_amdgcn_readfirstlane(cells[0].i0[2]), iz1 = __builtin_amdgcn_readfirstlane(cells[0].i1[2]);
+        const float tz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cells[0].t[2])));
+        __syncthreads();
+        STAMP(4);
+        // flush: a half-wave = one brick column = the 32 floats (x & 3, y & 3, z) of its brick(s); two lanes share a
+        // tile entry and apply the two depth weights.  z0 even: one brick, a contiguous 128-B atomic run.
+        const int ncols = b0 * b1;
+        const float rb1 = __frcp_rn((float)b1);
+        const int o = tid & 31, msub = tid >> 5, mstep = kSB / 32;
+        const int zz = (o & 1) ? iz1 : iz0;
+        const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
+        const unsigned zpart = (unsigned)(zz >> 1) * kBrickFloats + (unsigned)((o >> 1) << 1) + (unsigned)(zz & 1);
+        const float unscale = ldexpf(wz, -fx);
+        constexpr int FU2 = 4;
+        for (int q0 = msub; q0 < ncols; q0 += mstep * FU2) {
+            int v[FU2];
+#pragma unroll
+            for (int u = 0; u < FU2; ++u) {
+                const int q = q0 + u * mstep;
+                v[u] = (q < ncols) ? tile[q * UNIT2 + (o >> 1)] : 0;
+            }
+            if (nsub > 1) { // leave the tile clean for the next group (after both lanes of a pair have read their entry)
+#pragma unroll
+                for (int u = 0; u < FU2; ++u) {
+                    const int q = q0 + u * mstep;
+                    if (v[u] != 0 && !(o & 1)) tile[q * UNIT2 + (o >> 1)] = 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FU2; ++u) {
+                const int q = q0 + u * mstep;
+                const bool any = (unsigned)(__ballot(v[u] != 0) >> (tid & 32)) != 0u;
+                if (any) {
+                    const int i = __float2int_rz(((float)q + 0.5f) * rb1); // exact: q < 2^14, i * b1 <= q
+                    const int j = q - i * b1;
+                    const unsigned g = ((unsigned)(l0 + i) * (unsigned)A.G.nb1 + (unsigned)(l1 + j)) * (unsigned)A.G.nb2 * kBrickFloats + zpart;
+                    if (A.gtouched && o < 2) A.gtouched[g >> 5] = 1; // lanes 0 and 1: the brick of z0 and the brick of z1
+                    if (v[u] != 0 && wz != 0.f) atomicAdd(A.gvol + g, (float)v[u] * unscale);
+                }
+            }
+        }
+        STAMP(5);
+#ifdef DIFFUS_STAMP
+        if (threadIdx.x == 0 && g_stamps) {
+            g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)nt;
+            g_stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)nsub;
+        }
+#endif
+        if (sp + 1 < nsub) __syncthreads();
+        continue;
+    }
     // tile index = ex(i) + ey(j) + ez(k): three separable parts, each evaluated for the two
     // coordinates of its axis only (6 small computations per sample instead of 8 full ones)
     auto part = [&](int v, int axis) -> int {

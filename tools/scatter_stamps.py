@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["DIFFUS_LIB"] = os.path.abspath(sys.argv[1])
-from bench import HotPath
+from diffus_amd import CapturedStep as HotPath
 from diffus_amd import _lib
 from diffus_amd.phantom import phantom, pose_ring
 lib = _lib.load()

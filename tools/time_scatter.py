@@ -4,11 +4,13 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["DIFFUS_LIB"] = os.path.abspath(sys.argv[1])
 import torch
-from bench import HotPath, time_events
+from diffus_amd import CapturedStep as HotPath
+from bench import time_events
 from diffus_amd import _lib
 from diffus_amd.phantom import phantom, pose_ring
 vol = torch.from_numpy(phantom(256)).cuda()
-src, dirs = pose_ring(256, 32, 256)
+P = int(os.environ.get("POSES", "32"))
+src, dirs = pose_ring(256, P, 256)
 hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), 512, 1e-4, "trilinear")
 hp.fwd(); hp.loss_and_grad(); hp.zero_grad(); hp.bwd(_lib.BWD_SCAN)
 for _ in range(3):
@@ -17,4 +19,4 @@ f = time_events(hp.fwd, 30)["median"]
 b = time_events(lambda: hp.bwd(_lib.BWD_SCAN), 30)["median"]
 s = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), 30, pre=hp.finish_grad)["median"]
 u = time_events(hp.finish_grad, 30, pre=lambda: hp.bwd(_lib.BWD_SCATTER))["median"]
-print("%-34s fwd %.1f us  bwd-scan %.1f us  scatter %.1f us  flush %.1f us" % (os.path.basename(sys.argv[1]), f * 1e3, b * 1e3, s * 1e3, u * 1e3))
+print("P=%d " % P + "%-34s fwd %.1f us  bwd-scan %.1f us  scatter %.1f us  flush %.1f us" % (os.path.basename(sys.argv[1]), f * 1e3, b * 1e3, s * 1e3, u * 1e3))
