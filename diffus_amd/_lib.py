@@ -24,6 +24,7 @@ DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
 BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
+BWD_KEEP_MEDIAN = 4         # start > 0: the workspace still holds the forward's median (include/diffus_hip.h)
 MAX_SAMPLES = 1024          # cropped samples per launch; longer rays run as chained segments
 MAX_SEGMENTS = 64
 

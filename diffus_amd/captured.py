@@ -167,9 +167,11 @@ class CapturedStep:
         self.fwd()
 
     def backward(self):
-        """`self.gframe` (dL/dframe, written by the caller or by loss_and_grad) -> gvol, gsrc, gdirs."""
+        """`self.gframe` (dL/dframe, written by the caller or by loss_and_grad) -> gvol, gsrc, gdirs.
+        Must follow `forward()` on the same inputs: with start > 0 it reuses the per-pose median the forward left in
+        this object's own workspace (DIFFUS_BWD_KEEP_MEDIAN) instead of launching the median kernel again."""
         self.zero_grad()
-        self.bwd()
+        self.bwd(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self.start > 0 else 0))
         self.finish_grad()
 
     def step(self):

@@ -491,7 +491,8 @@ struct Args {
     float *uout;       // backward, nullable (P*R,4): adjoint carry leaving towards the previous segment
     const float *zcin; // backward, nullable (P*R): d L/d imp contribution to this segment's LAST sample
     float *zcout;      // backward, nullable (P*R): contribution of this segment's first r to sample seg0-1
-    float *gsrc_out;   // scatter launch only, nullable (P,3): its P extra blocks sum gsrc_part over rays into it
+    float *gsrc_out;   // pose_finish_block, nullable (P,3): the per-pose sum of gsrc_part over rays goes here
+    int finish_in_scatter; // the scatter launch carries P extra blocks that run pose_finish_block
     int accum_pose;    // backward: add to (instead of overwrite) the per-ray pose-gradient partials
     float neg_alpha;     // -alpha
     float neg_alpha_l2e; // -alpha * log2(e): attenuation = exp2(neg_alpha_l2e * n), one multiply in front of v_exp_f32
@@ -508,7 +509,9 @@ struct Args {
     // start>0 coupling
     float *med;  // (P) median of r[:,start] over rays
     int *who;    // (P) ray that supplied it
-    float *gmed; // (P) accumulated d/d median
+    float *gmed; // (P) accumulated d/d median; zero between backward passes (median_kernel and pose_finish_block reset it)
+    float *medinfo; // (P,8) of the ray that supplied the median: its two impedance samples (steps start, start+1) and,
+                    // trilinear, their spatial gradients -- all the backward needs to route d/d median (no re-sampling)
 };
 } // namespace diffus
 using diffus::Args;
@@ -524,10 +527,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     return base + (b >> 3);
 }
 
-// gsrc[pose,:] = sum over rays of part[pose,:,:] in a fixed order (deterministic): one block of kBlock threads,
-// sm = 3*kBlock floats of LDS.  Used by reduce_gsrc_kernel and by the tail blocks of the scatter launch.
+// gsrc[pose,:] = extra + sum over rays of part[pose,:,:] in a fixed order (deterministic): one block of >= kBlock
+// threads, sm = 3*kBlock floats of LDS.
 __device__ __forceinline__ void reduce_gsrc_block(const float *__restrict__ part, float *__restrict__ gsrc, int R, int pose,
-                                                  float *sm)
+                                                  float *sm, float ex0 = 0.f, float ex1 = 0.f, float ex2 = 0.f)
 {
     // the first kBlock threads of the block do the work; a larger block only has to reach the barriers
     const bool act = threadIdx.x < kBlock;
@@ -549,7 +552,7 @@ __device__ __forceinline__ void reduce_gsrc_block(const float *__restrict__ part
         }
         __syncthreads();
     }
-    if (threadIdx.x < 3) gsrc[pose * 3 + threadIdx.x] = sm[threadIdx.x * kBlock];
+    if (threadIdx.x < 3) gsrc[pose * 3 + threadIdx.x] = sm[threadIdx.x * kBlock] + (threadIdx.x == 0 ? ex0 : (threadIdx.x == 1 ? ex1 : ex2));
 }
 
 // ----------------------------------------------------------------------------
@@ -718,6 +721,9 @@ __device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, in
                     float2 q00 = make_float2(__uint_as_float(x0 + y0 + z0), 1.f), q01 = make_float2(__uint_as_float(x0 + y1 + z0), 1.f);
                     float2 q10 = make_float2(__uint_as_float(x1 + y0 + z0), 1.f), q11 = make_float2(__uint_as_float(x1 + y1 + z0), 1.f);
 #else
+                    // (Tried: skipping the columns whose weight is 0 for all 64 lanes -- rays that have left the volume --
+                    // behind wave-uniform branches: 1/3 fewer wave-loads at config 3, but hipcc then waits for the
+                    // loads at every branch merge: forward 19.9 -> 24.1 us.  The four loads stay unconditional.)
                     float2 q00 = ldb_f32x2(vol, x0 + y0 + z0);
                     float2 q01 = ldb_f32x2(vol, x0 + y1 + z0);
                     float2 q10 = ldb_f32x2(vol, x1 + y0 + z0);
@@ -925,6 +931,67 @@ __device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
         f(c.i1[0], c.i1[1], c.i0[2], w11 * wc0);
         f(c.i1[0], c.i1[1], c.i1[2], w11 * wc1);
     }
+}
+
+
+// What is left of a pose's backward once every ray's adjoint scan has run (one block per pose; the tail blocks of the
+// scatter launch, or pose_finish_kernel when there is no scatter):
+//   * start > 0: the first kept reflection coefficient of every ray was replaced by the per-pose median (reference
+//     src/renderer.py:243-244), so their gradients were summed into gmed[pose]; torch.median routes that sum to the
+//     ray that supplied the median.  Its two samples and their spatial gradients wait in medinfo (median_kernel), so
+//     nothing is sampled again: d r / d Z -> volume gradient (8 corner atomics per sample), d/d source and d/d direction
+//     of that ray;
+//   * d/d source[pose] = fixed-order sum over rays of the per-ray partials (+ the median ray's extra term).
+// GLAYOUT is the GRADIENT layout.  sm: 3*kBlock floats.
+template <int SAMPLER, int GLAYOUT>
+__device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float *sm)
+{
+    __shared__ float s_extra[3];
+    if (threadIdx.x == 0) {
+        float gs[3] = {0.f, 0.f, 0.f};
+        if (A.start > 0) {
+            const int i = A.who[pose];
+            const float gm = A.gmed[pose];
+            A.gmed[pose] = 0.f; // consumed: the next backward starts from zero
+            if (i >= 0 && gm != 0.f && finitef(gm)) {
+                const long w = (long)pose * A.R + i;
+                Pose ps;
+                load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+                const float *mi = A.medinfo + (long)pose * 8;
+                const float z0 = mi[0], z1 = mi[1];
+                const float inv = __fdiv_rn(1.f, z0 + z1);
+                const float zb[2] = {gm * (-2.f * z1 * inv * inv), gm * (2.f * z0 * inv * inv)}; // d r / d Z (reference :33)
+                float gd[3] = {0.f, 0.f, 0.f};
+                for (int q = 0; q < 2; ++q) {
+                    if (!finitef(zb[q]) || zb[q] == 0.f) continue;
+                    const int k = A.start + q;
+                    if (A.gvol) {
+                        Cell c = cell_of<SAMPLER>(A, ps, k);
+                        for_each_corner<SAMPLER>(c, zb[q], [&](int a, int b, int cc, float v) {
+                            if (v != 0.f) {
+                                unsigned g = vox_off<GLAYOUT>(A.G, a, b, cc);
+                                atomicAdd(A.gvol + g, v);
+                                if (GLAYOUT == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
+                            }
+                        });
+                    }
+                    if (SAMPLER == DIFFUS_TRILINEAR) {
+                        const float kf = (float)k;
+                        for (int c = 0; c < 3; ++c) {
+                            const float t = zb[q] * mi[2 + 3 * q + c];
+                            gs[c] += t;
+                            gd[c] += kf * t;
+                        }
+                    }
+                }
+                if (SAMPLER == DIFFUS_TRILINEAR && A.gdirs)
+                    for (int c = 0; c < 3; ++c) A.gdirs[w * 3 + c] += gd[c]; // this block is the only writer now
+            }
+        }
+        s_extra[0] = gs[0]; s_extra[1] = gs[1]; s_extra[2] = gs[2];
+    }
+    __syncthreads();
+    if (A.gsrc_out) reduce_gsrc_block(A.gsrc_part, A.gsrc_out, A.R, pose, sm, s_extra[0], s_extra[1], s_extra[2]);
 }
 
 } // namespace

@@ -50,6 +50,7 @@ struct Workspace {
     float *med;
     int *who;
     float *gmed;
+    float *medinfo;
     float *gsrc_part;
     float *zbar;
     float *carry;  // (nseg-1, P*R, 5) per-segment carry-in of long rays
@@ -67,6 +68,7 @@ Workspace carve(void *base, int P, int R, int N1)
     ws.med = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
     ws.who = (int *)(p + o);   o += align256(sizeof(int) * (size_t)P);
     ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
+    ws.medinfo = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * 8);
     ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
     ws.zbar = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * (N1 > 0 ? N1 : 0));
     ws.nseg = N1 > 0 ? (N1 + DIFFUS_MAX_SAMPLES - 1) / DIFFUS_MAX_SAMPLES : 1;
@@ -123,7 +125,7 @@ Args make_args(const float *vol, int d0, int d1, int d2, int layout, const void 
     A.seg0 = 0; A.segN = A.N1; // one launch covers the ray unless the caller loops over segments
     A.neg_alpha = -alpha;
     A.neg_alpha_l2e = (float)(-(double)alpha * 1.4426950408889634);
-    A.med = ws.med; A.who = ws.who; A.gmed = ws.gmed;
+    A.med = ws.med; A.who = ws.who; A.gmed = ws.gmed; A.medinfo = ws.medinfo;
     return A;
 }
 
@@ -150,7 +152,7 @@ int dispatch_sl(int sampler, int layout, F &&f)
 
 // ----------------------------------------------------------------------------
 // start > 0: median over rays of r[:, start] (reference :243), one block per pose.
-// Lower median like torch.median; NaN if any NaN.  Also zeroes gmed[p].
+// Lower median like torch.median; NaN if any NaN.  Also zeroes gmed[p] and leaves the median ray's samples in medinfo.
 template <int SAMPLER, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
 {
@@ -198,6 +200,24 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
             A.med[pose] = v;
             A.who[pose] = i;
             A.gmed[pose] = 0.f;
+            // what the backward needs to route d/d median to this ray (pose_finish_block): its two samples and, for
+            // the pose gradient, their spatial gradients
+            Pose ps;
+            load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, (long)pose * A.R + i);
+            float *mi = A.medinfo + (long)pose * 8;
+            for (int q = 0; q < 2; ++q) {
+                int k = A.start + q;
+                float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+                if (SAMPLER == DIFFUS_NEAREST) {
+                    int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+                    mi[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
+                    mi[2 + 3 * q] = mi[3 + 3 * q] = mi[4 + 3 * q] = 0.f;
+                } else {
+                    TriSample sm = tri_sample<LAYOUT, true>(A.vol, A.G, p0, p1, p2);
+                    mi[q] = sm.v;
+                    mi[2 + 3 * q] = sm.g0; mi[3 + 3 * q] = sm.g1; mi[4 + 3 * q] = sm.g2;
+                }
+            }
         }
     }
 }

@@ -328,70 +328,12 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     }
 }
 
-// start > 0, backward: route gmed[p] to the ray that supplied the median
-// (torch.median's backward).  One thread per pose; runs after render_bwd_kernel.
-template <int SAMPLER, int LAYOUT>
-__global__ void median_bwd_kernel(Args A)
-{
-    const int pose = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pose >= A.P) return;
-    const int i = A.who[pose];
-    const float gm = A.gmed[pose];
-    if (i < 0 || gm == 0.f || !finitef(gm)) return;
-    const long w = (long)pose * A.R + i;
-    Pose ps;
-    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
-    float zz[2], g0[2], g1[2], g2[2];
-    for (int q = 0; q < 2; ++q) {
-        int k = A.start + q;
-        float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
-        if (SAMPLER == DIFFUS_NEAREST) {
-            int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
-            zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
-            g0[q] = g1[q] = g2[q] = 0.f;
-        } else {
-            TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, p0, p1, p2);
-            zz[q] = s.v; g0[q] = s.g0; g1[q] = s.g1; g2[q] = s.g2;
-        }
-    }
-    float s = zz[0] + zz[1];
-    float inv = __fdiv_rn(1.f, s);
-    float zb[2] = {gm * (-2.f * zz[1] * inv * inv), gm * (2.f * zz[0] * inv * inv)};
-    for (int q = 0; q < 2; ++q) {
-        if (!finitef(zb[q]) || zb[q] == 0.f) continue;
-        int k = A.start + q;
-        if (A.gvol) {
-            Cell c = cell_of<SAMPLER>(A, ps, k);
-            for_each_corner<SAMPLER>(c, zb[q], [&](int a, int b, int cc, float v) {
-                if (v != 0.f) {
-                    unsigned g = vox_off<GradLayout<LAYOUT>::value>(A.G, a, b, cc);
-                    atomicAdd(A.gvol + g, v);
-                    if (GradLayout<LAYOUT>::value == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
-                }
-            });
-        }
-        if (SAMPLER == DIFFUS_TRILINEAR) {
-            float kf = (float)k;
-            if (A.gsrc_part) {
-                A.gsrc_part[w * 3 + 0] += zb[q] * g0[q];
-                A.gsrc_part[w * 3 + 1] += zb[q] * g1[q];
-                A.gsrc_part[w * 3 + 2] += zb[q] * g2[q];
-            }
-            if (A.gdirs) {
-                A.gdirs[w * 3 + 0] += kf * zb[q] * g0[q];
-                A.gdirs[w * 3 + 1] += kf * zb[q] * g1[q];
-                A.gdirs[w * 3 + 2] += kf * zb[q] * g2[q];
-            }
-        }
-    }
-}
-
-// gsrc[p,:] = sum over rays of gsrc_part[p,:,:], fixed order => deterministic.
-__global__ __launch_bounds__(kBlock) void reduce_gsrc_kernel(const float *__restrict__ part, float *__restrict__ gsrc,
-                                                             int R)
+// One block per pose: what pose_finish_block does, as a launch of its own (no scatter launch to ride on).
+template <int SAMPLER, int GLAYOUT>
+__global__ __launch_bounds__(kBlock) void pose_finish_kernel(Args A)
 {
     __shared__ float sm[3 * kBlock];
-    reduce_gsrc_block(part, gsrc, R, blockIdx.x, sm);
+    pose_finish_block<SAMPLER, GLAYOUT>(A, blockIdx.x, sm);
 }
 
 template <int SM, int LY, bool GPOSE, int PM>
@@ -444,7 +386,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
     if (!gframe) return DIFFUS_EINVAL;
-    if (stages < 1 || stages > DIFFUS_BWD_ALL) return DIFFUS_EINVAL;
+    if (stages < 1 || stages > (DIFFUS_BWD_ALL | DIFFUS_BWD_KEEP_MEDIAN) || !(stages & DIFFUS_BWD_ALL)) return DIFFUS_EINVAL;
     if (!gvol && !gsrc && !gdirs) return DIFFUS_OK;
     const bool do_scan = stages & DIFFUS_BWD_SCAN, do_scatter = stages & DIFFUS_BWD_SCATTER;
     Workspace ws = carve(workspace, P, R, S - start);
@@ -464,7 +406,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
     A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
     A.gdirs = pose ? gdirs : nullptr;
     if (do_scan) {
-        if (start > 0) { // recompute the median (and zero gmed)
+        if (start > 0 && !(stages & DIFFUS_BWD_KEEP_MEDIAN)) { // recompute the median (and zero gmed)
             rc = launch_median(A, sampler, layout, st);
             if (rc) return rc;
         }
@@ -502,25 +444,24 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
             }
         }
     }
-    // with start == 0 nothing touches the d/dsource partials after the scan, so their per-pose sum rides along
-    // as P extra blocks of the scatter launch instead of a launch of its own
-    const bool fold_gsrc = pose && gsrc && do_scan && gvol && do_scatter && start == 0;
+    // Per-pose epilogue (pose_finish_block): the median's gradient goes to the ray that supplied it (start > 0) and the
+    // per-ray d/dsource partials are summed.  It rides along as P extra blocks of the scatter launch when that launch
+    // follows in this call, else it is one launch of its own.
+    const bool finish = do_scan && (start > 0 || (pose && gsrc));
+    A.gsrc_out = (pose && gsrc) ? gsrc : nullptr;
+    A.finish_in_scatter = finish && gvol && do_scatter;
     if (gvol && do_scatter) {
-        A.gsrc_out = fold_gsrc ? gsrc : nullptr;
         rc = diffus::launch_scatter(A, sampler, layout, st);
         if (rc) return rc;
     }
-    if (start > 0 && do_scan) {
-        const unsigned nb = (unsigned)((P + 63) / 64);
-        rc = dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
-            hipLaunchKernelGGL((median_bwd_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nb), dim3(64), 0, st, A);
+    if (finish && !A.finish_in_scatter) {
+        const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout;
+        rc = dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
+            constexpr int GL = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
+            hipLaunchKernelGGL((pose_finish_kernel<decltype(S_)::value, GL>), dim3(P), dim3(kBlock), 0, st, A);
             return last_launch();
         });
         if (rc) return rc;
-    }
-    if (pose && gsrc && do_scan && !fold_gsrc) {
-        hipLaunchKernelGGL(reduce_gsrc_kernel, dim3(P), dim3(kBlock), 0, st, ws.gsrc_part, gsrc, R);
-        if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
     }
     return DIFFUS_OK;
 }

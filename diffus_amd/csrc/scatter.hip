@@ -62,8 +62,8 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
     constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED) && (SAMPLER == DIFFUS_TRILINEAR);
     constexpr int UNIT2 = 16; // tile entries per brick column in planar mode
 
-    if (blockIdx.x >= npatch) { // tail blocks of the launch: d/dsource[pose] = fixed-order sum of the per-ray partials
-        reduce_gsrc_block(A.gsrc_part, A.gsrc_out, A.R, (int)(blockIdx.x - npatch), reinterpret_cast<float *>(tile));
+    if (blockIdx.x >= npatch) { // tail blocks of the launch, one per pose: median routing (start > 0) and d/dsource
+        pose_finish_block<SAMPLER, LAYOUT>(A, (int)(blockIdx.x - npatch), reinterpret_cast<float *>(tile));
         return;
     }
     // patch -> (step group, pose, ray group), step group SLOWEST: the blocks in flight at any time are then the same
@@ -398,7 +398,7 @@ int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
 {
     const int rgs = (A.R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
     const unsigned np = (unsigned)((long)A.P * rgs * sgs);
-    const unsigned nb = np + (A.gsrc_out ? (unsigned)A.P : 0u);
+    const unsigned nb = np + (A.finish_in_scatter ? (unsigned)A.P : 0u);
     const bool f32 = !A.src_f64 && !A.dir_f64;
     const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout; // the scatter only sees the gradient
     return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {

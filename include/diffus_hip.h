@@ -167,10 +167,16 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
  * DIFFUS_BWD_SCATTER (workspace -> gvol through LDS tiles), or DIFFUS_BWD_ALL.
  * Running them as two calls with the same workspace equals one ALL call; it
  * exists so the scatter can be timed / overlapped on its own.
+ * DIFFUS_BWD_KEEP_MEDIAN (start > 0 only, OR-ed into `stages`): the workspace still holds the per-pose median
+ * (reference src/renderer.py:243) that diffus_render_fwd left there for the SAME problem -- nothing else has used the
+ * workspace since -- so the backward does not recompute it.  A start > 0 backward is then the same two launches as a
+ * start = 0 one: the median's gradient is routed to the ray that supplied it, and d/dsource reduced, by extra
+ * blocks of the scatter launch.
  */
 #define DIFFUS_BWD_SCAN    1
 #define DIFFUS_BWD_SCATTER 2
 #define DIFFUS_BWD_ALL     3
+#define DIFFUS_BWD_KEEP_MEDIAN 4
 int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout,
                       const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype,

@@ -144,3 +144,38 @@ def test_step_is_hipgraph_capturable_and_replays_on_new_inputs(hot):
     assert torch.equal(got[2] != 0, ref.gvol != 0)
     assert float((got[2] - ref.gvol).abs().max()) <= 1e-5 * float(ref.gvol.abs().max())
     assert float(ref.gvol.abs().max()) > 0 and float(ref.frame.abs().max()) > 0
+
+
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
+def test_start_crop_backward_reuses_the_forwards_median(hot, sampler):
+    """start > 0: the captured step's backward keeps the median of its own forward (DIFFUS_BWD_KEEP_MEDIAN) and routes the
+    median's gradient in extra blocks of the scatter launch; same result as the self-contained backward of the autograd
+    path (median recomputed, routing and d/dsource reduction as a launch of their own when there is no scatter)."""
+    import diffus_amd as da
+    n, P, R, S, start, alpha = 64, 5, 40, 150, 37, 2e-3
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, P, R)
+    s = torch.from_numpy(src).cuda()
+    d = torch.from_numpy(dirs).cuda()
+    hp = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False)
+    hp.step()
+    hp.step()                                           # a second pass: gmed was reset by the first one
+    v = vol.clone().requires_grad_(True)
+    sa = s.clone().requires_grad_(True)
+    dd = d.clone().requires_grad_(True)
+    f = da.render_poses(v, sa, dd, S, alpha, start=start, sampler=sampler, layout="paired")
+    (f ** 2).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(f.detach(), hp.frame)
+    assert float(hp.gvol.abs().max()) > 0
+    assert float((hp.gvol - v.grad).abs().max()) <= 2e-5 * float(v.grad.abs().max())
+    if sampler == "trilinear":
+        assert float((hp.gsrc - sa.grad).abs().max()) <= 1e-5 * float(sa.grad.abs().max())
+        assert float((hp.gdirs - dd.grad).abs().max()) <= 1e-5 * float(dd.grad.abs().max())
+    # pose-gradient-only backward (no scatter launch to carry the per-pose epilogue)
+    if sampler == "trilinear":
+        hq = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, want_gvol=False)
+        hq.step()
+        torch.cuda.synchronize()
+        assert float((hq.gsrc - sa.grad).abs().max()) <= 1e-5 * float(sa.grad.abs().max())
+        assert float((hq.gdirs - dd.grad).abs().max()) <= 1e-5 * float(dd.grad.abs().max())
