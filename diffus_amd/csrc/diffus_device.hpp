@@ -509,7 +509,8 @@ struct Args {
     // start>0 coupling
     float *med;  // (P) median of r[:,start] over rays
     int *who;    // (P) ray that supplied it
-    float *gmed; // (P) accumulated d/d median; zero between backward passes (median_kernel and pose_finish_block reset it)
+    float *gmed; // (P,R) per-ray d/d (first kept coefficient) = each ray's share of d/d median, written by the adjoint scan
+                 // (one plain store per ray: 256 float atomics on one address per pose took 50 us), summed by pose_finish_block
     float *medinfo; // (P,8) of the ray that supplied the median: its two impedance samples (steps start, start+1) and,
                     // trilinear, their spatial gradients -- all the backward needs to route d/d median (no re-sampling)
 };
@@ -947,12 +948,25 @@ template <int SAMPLER, int GLAYOUT>
 __device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float *sm)
 {
     __shared__ float s_extra[3];
+    __shared__ float s_gm;
+    if (A.start > 0) { // d/d median = fixed-order sum of the rays' shares (deterministic)
+        float a = 0.f;
+        if (threadIdx.x < kBlock)
+            for (int i = threadIdx.x; i < A.R; i += kBlock) a += A.gmed[(long)pose * A.R + i];
+        if (threadIdx.x < kBlock) sm[threadIdx.x] = a;
+        __syncthreads();
+        for (int s = kBlock / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) s_gm = sm[0];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         float gs[3] = {0.f, 0.f, 0.f};
         if (A.start > 0) {
             const int i = A.who[pose];
-            const float gm = A.gmed[pose];
-            A.gmed[pose] = 0.f; // consumed: the next backward starts from zero
+            const float gm = s_gm;
             if (i >= 0 && gm != 0.f && finitef(gm)) {
                 const long w = (long)pose * A.R + i;
                 Pose ps;

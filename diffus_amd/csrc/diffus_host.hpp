@@ -67,7 +67,7 @@ Workspace carve(void *base, int P, int R, int N1)
     size_t o = 0;
     ws.med = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
     ws.who = (int *)(p + o);   o += align256(sizeof(int) * (size_t)P);
-    ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P);
+    ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R);
     ws.medinfo = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * 8);
     ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
     ws.zbar = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * (N1 > 0 ? N1 : 0));
@@ -152,11 +152,11 @@ int dispatch_sl(int sampler, int layout, F &&f)
 
 // ----------------------------------------------------------------------------
 // start > 0: median over rays of r[:, start] (reference :243), one block per pose.
-// Lower median like torch.median; NaN if any NaN.  Also zeroes gmed[p] and leaves the median ray's samples in medinfo.
+// Lower median like torch.median; NaN if any NaN.  Leaves the median ray's samples in medinfo for the backward.
 template <int SAMPLER, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
 {
-    extern __shared__ float vals[];
+    extern __shared__ __attribute__((aligned(16))) float vals[];
     __shared__ int s_nan;
     const int pose = blockIdx.x;
     if (threadIdx.x == 0) s_nan = 0;
@@ -184,7 +184,6 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
         if (threadIdx.x == 0) {
             A.med[pose] = __builtin_nanf("");
             A.who[pose] = -1;
-            A.gmed[pose] = 0.f;
         }
         return;
     }
@@ -192,14 +191,21 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
     for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
         float v = vals[i];
         int rank = 0;
-        for (int j = 0; j < A.R; ++j) {
+        int j = 0;
+        for (; j + 4 <= A.R; j += 4) { // vals is 16-byte aligned dynamic LDS: one ds_read_b128 (a broadcast) per 4 values
+            const float4 u = *reinterpret_cast<const float4 *>(vals + j);
+            rank += (u.x < v) || (u.x == v && j < i);
+            rank += (u.y < v) || (u.y == v && j + 1 < i);
+            rank += (u.z < v) || (u.z == v && j + 2 < i);
+            rank += (u.w < v) || (u.w == v && j + 3 < i);
+        }
+        for (; j < A.R; ++j) {
             float u = vals[j];
             rank += (u < v) || (u == v && j < i);
         }
         if (rank == target) { // exactly one i satisfies this
             A.med[pose] = v;
             A.who[pose] = i;
-            A.gmed[pose] = 0.f;
             // what the backward needs to route d/d median to this ray (pose_finish_block): its two samples and, for
             // the pose gradient, their spatial gradients
             Pose ps;

@@ -265,7 +265,8 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
                 if (j == last % C) zbar[j] += zc;
         }
     }
-    if (gmed_lane != 0.f) atomicAdd(&A.gmed[pose], gmed_lane);
+    // this ray's share of d/d median: sample 1 lives in lane 0 (C >= 2) of the first segment
+    if (A.start > 0 && seg0 == 0 && lane == 0) A.gmed[w] = gmed_lane;
 
     // ---- back to INTERLEAVED: hand zbar to the scatter kernel, reduce the pose gradient ----
     // The volume scatter is a separate launch (scatter_patch_kernel): its thread <-> sample
