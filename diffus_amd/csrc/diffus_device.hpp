@@ -829,9 +829,14 @@ __device__ __forceinline__ void reflect_chunk(const Args &A, int seg0, int segN,
 // dense solves of reference src/renderer.py:367-457).  r[j] is the reflection
 // coefficient entering sample n = lane*C + j (0 where there is none); e[j] gets
 // echo_n = (P_n)01/(P_n)11 with NaN -> 0 (reference :408).
-template <int C, bool FAST = false>
+struct NoScanHook {
+    __device__ __forceinline__ bool operator()(const Mat &, Mat &) const { return false; }
+};
+// after_scan(Lincl, carry): called once between the wave scan and the sweep with this lane's INCLUSIVE prefix; it may
+// return true and a matrix that precedes the whole wave (the SPLIT kernels exchange the first half's total there).
+template <int C, bool FAST = false, typename Hook = NoScanHook>
 __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float (&e)[C], const Mat *carry_in = nullptr,
-                                           int last = -1, Mat *carry_out = nullptr)
+                                           int last = -1, Mat *carry_out = nullptr, Hook &&after_scan = Hook())
 {
     // local product of the chunk, then inclusive scan over lanes (lower lanes on the left)
     // FAST (the render kernel): rescale every 4th step only.  The ratio b/d does not depend on the scale and one
@@ -856,8 +861,10 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
 #undef DIFFUS_ROUND
     }
     Mat Pm = mat_lane_prev(L, mat_identity()); // exclusive prefix; lane 0: identity
-    if (carry_in) { // segment > 0: everything is preceded by the product of the earlier segments
-        Pm = mat_mul(*carry_in, Pm);
+    Mat hooked;
+    const bool has_hooked = after_scan(L, hooked);
+    if (carry_in || has_hooked) { // segment > 0: everything is preceded by the product of the earlier segments
+        Pm = mat_mul(carry_in ? *carry_in : hooked, Pm);
         mat_renorm(Pm);
     }
 #pragma unroll

@@ -16,21 +16,38 @@ namespace {
 #ifndef DIFFUS_BWD_MIN_WAVES
 #define DIFFUS_BWD_MIN_WAVES 1
 #endif
+#ifndef DIFFUS_SPLIT_MIN_WAVES // SPLIT kernels: 4 waves per SIMD = 128 VGPRs (13 dwords of scratch) against 3 at 133
+#define DIFFUS_SPLIT_MIN_WAVES 4
+#endif
 // SEG = true: one 1024-sample segment of a longer ray (see diffus_render_bwd); only instantiated for C = 16.
-template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM, bool SEG = false>
-__global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) void render_bwd_kernel(Args A)
+// SPLIT = 2: the two waves of a 128-thread block take the two halves of ONE ray (64*C samples each) and exchange
+// through LDS what the segmented launches exchange through the workspace -- the forward carry (P', last impedance
+// sample) from the first half to the second, the adjoint carry (U', boundary term of zbar) back.  Used for
+// 512 < N1 <= 1024 instead of one wave with 16 samples per lane: that kernel needs ~250 VGPRs (2 waves per SIMD) and
+// a lane's serial sweeps are twice as long; two C = 8 waves need 126 each (4 per SIMD) and overlap their gathers,
+// local products, scans and epilogues -- only the second half's adjoint has to finish before the first half's.
+template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM, bool SEG = false, int SPLIT = 1>
+__global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1))) void render_bwd_kernel(Args A)
 {
-    const int seg0 = SEG ? A.seg0 : 0, segN = SEG ? A.segN : A.N1;
-    const float *const cin = SEG ? A.cin : nullptr, *const cnext = SEG ? A.cnext : nullptr;
-    const float *const uin = SEG ? A.uin : nullptr, *const zcin = SEG ? A.zcin : nullptr;
-    float *const uout = SEG ? A.uout : nullptr, *const zcout = SEG ? A.zcout : nullptr;
+    static_assert(SPLIT == 1 || (SPLIT == 2 && WPB == 2 && !SEG), "SPLIT: one ray per block of two waves");
+    __shared__ float s_c[5], s_u[4], s_zc, s_pg[6]; // SPLIT exchange: forward carry, adjoint carry, zbar boundary term, pose-gradient partials
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: ray-derived addresses stay scalar
+    const int part = (SPLIT > 1) ? wib : 0; // which half of the ray
+    const long w = (SPLIT > 1) ? (long)xcd_remap(blockIdx.x, gridDim.x) : (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
+    if (w >= (long)A.P * A.R) return; // SPLIT: both waves of the block leave together
+    const int seg0 = SEG ? A.seg0 : part * (kWave * C);
+    const int segN = SEG ? A.segN : ((SPLIT > 1) ? min(A.N1 - seg0, kWave * C) : A.N1);
+    // carries: per-ray records in the workspace (SEG) or the block's LDS records (SPLIT)
+    const float *const cin = SEG ? A.cin + (A.cin ? w * 5 : 0) : ((SPLIT > 1 && part == 1) ? s_c : nullptr);
+    const float *const cnext = SEG ? A.cnext + (A.cnext ? w * 5 : 0) : ((SPLIT > 1 && part == 0) ? s_c : nullptr);
+    const float *const uin = SEG ? A.uin + (A.uin ? w * 4 : 0) : ((SPLIT > 1 && part == 0) ? s_u : nullptr);
+    const float *const zcin = SEG ? A.zcin + (A.zcin ? w : 0) : ((SPLIT > 1 && part == 0) ? &s_zc : nullptr);
+    float *const uout = SEG ? A.uout + (A.uout ? w * 4 : 0) : ((SPLIT > 1 && part == 1) ? s_u : nullptr);
+    float *const zcout = SEG ? A.zcout + (A.zcout ? w : 0) : ((SPLIT > 1 && part == 1) ? &s_zc : nullptr);
     const bool accum_pose = SEG && A.accum_pose;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 12 KiB more LDS per wave
     __shared__ float stash[KEEP_GRAD ? WPB : 1][KEEP_GRAD ? 3 * kWave * C : 1];
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: ray-derived addresses stay scalar
-    const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
-    if (w >= (long)A.P * A.R) return;
     const int lane = threadIdx.x & 63;
     const long pose = w / A.R;
     const int n0 = lane * C;
@@ -67,7 +84,11 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         to_chunked<C>(wb, lane, zi, gb);
     }
     float zprev = lane_prev(z[C - 1], z[C - 1]);
-    if (cin && lane == 0) zprev = cin[w * 5 + 4]; // last sample of the previous segment
+    if (SPLIT > 1) { // the second half's first coefficient couples to the first half's last sample
+        if (part == 0 && lane == kWave - 1) s_c[4] = z[C - 1];
+        __syncthreads();
+    }
+    if (cin && lane == 0) zprev = cin[4]; // last sample of the previous segment
     const float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r);
 
@@ -98,8 +119,14 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     }
     Mat Pm = mat_lane_prev(L, mat_identity()); // exclusive prefix (lane 0: identity) ...
     int eps = lane_prev0(iota);                // ... and its exponent
+    if (SPLIT > 1) { // the first half's total product (its inclusive scan in lane 63, normalised) is the second half's carry
+        if (part == 0 && lane == kWave - 1) {
+            s_c[0] = L.a; s_c[1] = L.b; s_c[2] = L.c; s_c[3] = L.d;
+        }
+        __syncthreads();
+    }
     if (cin) { // segment > 0: P'_{seg0-1} of the carry-only forward pass precedes everything (its scale is exponent 0)
-        Pm = mat_mul(Mat{cin[w * 5 + 0], cin[w * 5 + 1], cin[w * 5 + 2], cin[w * 5 + 3]}, Pm);
+        Pm = mat_mul(Mat{cin[0], cin[1], cin[2], cin[3]}, Pm);
         eps -= mat_renorm(Pm);
     }
 
@@ -196,16 +223,17 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         }
     }
     Mat Uin = mat_lane_next0(Aacc); // lane 63: nothing enters from above (0)
+    if (SPLIT > 1 && part == 0) __syncthreads(); // the second half has published its adjoint carry (it arrives at the matching barrier below)
     if (uin) {
         // Adjoint entering from the next segment.  It was written relative to the scale of that segment's
         // carry-in P' (cnext); lane 63's final P' is the same matrix up to a power of two (idle samples
         // multiply by the identity), so the ratio of their largest entries gives the exact exponent hop.
-        Mat Kn{cnext[w * 5 + 0], cnext[w * 5 + 1], cnext[w * 5 + 2], cnext[w * 5 + 3]};
+        Mat Kn{cnext[0], cnext[1], cnext[2], cnext[3]};
         float mk = fmaxf(fmaxf(fabsf(Kn.a), fabsf(Kn.b)), fmaxf(fabsf(Kn.c), fabsf(Kn.d)));
         float mp = fmaxf(fmaxf(fabsf(Pm.a), fabsf(Pm.b)), fmaxf(fabsf(Pm.c), fabsf(Pm.d)));
         mp = lane_bcast(mp, kWave - 1);
         float ratio = mk / mp;
-        Mat Uc{uin[w * 4 + 0], uin[w * 4 + 1], uin[w * 4 + 2], uin[w * 4 + 3]};
+        Mat Uc{uin[0], uin[1], uin[2], uin[3]};
         if (finitef(ratio) && ratio > 0.f && mat_finite(Uc))
             Uc = mat_scale(Uc, (int)rintf(log2f(ratio)));
         else
@@ -222,7 +250,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     float rbar[C];
     const Mat Uout = sweep(Uin, rbar);
     if (uout && lane == 0) { // relative to the scale of this segment's carry-in P'
-        uout[w * 4 + 0] = Uout.a; uout[w * 4 + 1] = Uout.b; uout[w * 4 + 2] = Uout.c; uout[w * 4 + 3] = Uout.d;
+        uout[0] = Uout.a; uout[1] = Uout.b; uout[2] = Uout.c; uout[3] = Uout.d;
     }
 
     // ---- rbar -> zbar (d r / d Z of reference :33) ----
@@ -255,10 +283,11 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
     }
     const float cnb = lane_next0(carry);
     if (lane != kWave - 1) zbar[C - 1] += cnb;
-    if (zcout && lane == 0) zcout[w] = carry; // belongs to the last sample of the previous segment
+    if (zcout && lane == 0) zcout[0] = carry; // belongs to the last sample of the previous segment
+    if (SPLIT > 1 && part == 1) __syncthreads(); // adjoint carry and boundary term are out: releases the first half
     if (zcin) {
         const int last = segN - 1;
-        const float zc = zcin[w];
+        const float zc = zcin[0];
         if (lane == last / C) {
 #pragma unroll
             for (int j = 0; j < C; ++j)
@@ -306,6 +335,14 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1)) vo
         }
         gs0 = wave_sum_to_lane63(gs0); gs1 = wave_sum_to_lane63(gs1); gs2 = wave_sum_to_lane63(gs2);
         gd0 = wave_sum_to_lane63(gd0); gd1 = wave_sum_to_lane63(gd1); gd2 = wave_sum_to_lane63(gd2);
+        if (SPLIT > 1) { // one ray, two waves: the second half hands its partial sums to the first
+            if (part == 1 && lane == kWave - 1) {
+                s_pg[0] = gs0; s_pg[1] = gs1; s_pg[2] = gs2; s_pg[3] = gd0; s_pg[4] = gd1; s_pg[5] = gd2;
+            }
+            __syncthreads();
+            if (part == 1) return;
+            gs0 += s_pg[0]; gs1 += s_pg[1]; gs2 += s_pg[2]; gd0 += s_pg[3]; gd1 += s_pg[4]; gd2 += s_pg[5];
+        }
         if (lane == kWave - 1) { // the DPP ladder leaves the wave's total in its last lane
             if (accum_pose) { // later-processed segment of a long ray: add to the partial sums
                 if (A.gsrc_part) {
@@ -349,9 +386,11 @@ int launch_bwd_p(const Args &A, hipStream_t st)
     switch (chunk_for(A.N1)) {
     case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
     case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    // (256 < N1 <= 512 as two waves of 4 samples per lane was measured too: 46.5 against 37 us at config 3 -- the split
+    // pays only where it lifts the single wave out of the 2-waves-per-SIMD register regime)
     case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    default: // 16 samples per lane need ~300 registers: one wave per block so the whole 512-entry file is available
-        hipLaunchKernelGGL((render_bwd_kernel<16, SM, LY, GPOSE, 1, PM>), dim3((unsigned)waves), dim3(kWave), 0, st, A);
+    default: // 512 < N1 <= 1024: two waves of 8 samples per lane share a ray (SPLIT), one ray per 128-thread block
+        hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, 2, PM, false, 2>), dim3((unsigned)waves), dim3(2 * kWave), 0, st, A);
         break;
     }
     return last_launch();

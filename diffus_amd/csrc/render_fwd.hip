@@ -22,16 +22,22 @@ __device__ unsigned long long *g_fwd_stamps = nullptr;
 #endif
 // SEG = true: the launch covers one 1024-sample segment of a longer ray (carries in the workspace); only
 // instantiated for C = 16.  SEG = false compiles every carry path away.
-template <int C, int SAMPLER, int LAYOUT, int WPB, int PM, bool SEG = false>
+// SPLIT = 2: the two waves of a 128-thread block take the two halves of one ray (see render_bwd_kernel); the first
+// half hands its last impedance sample and its total transfer-matrix product to the second through LDS.
+template <int C, int SAMPLER, int LAYOUT, int WPB, int PM, bool SEG = false, int SPLIT = 1>
 __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) void render_fwd_kernel(Args A)
 {
-    const int seg0 = SEG ? A.seg0 : 0, segN = SEG ? A.segN : A.N1;
+    static_assert(SPLIT == 1 || (SPLIT == 2 && WPB == 2 && !SEG), "SPLIT: one ray per block of two waves");
+    __shared__ float s_c[5]; // SPLIT exchange: total product of the first half (4) + its last sample
     const float *const cin = SEG ? A.cin : nullptr;
     float *const cout = SEG ? A.cout : nullptr;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: ray-derived addresses stay scalar
-    const long w = (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
-    if (w >= (long)A.P * A.R) return; // wave-uniform; no block-level barrier below
+    const int part = (SPLIT > 1) ? wib : 0;
+    const long w = (SPLIT > 1) ? (long)xcd_remap(blockIdx.x, gridDim.x) : (long)xcd_remap(blockIdx.x, gridDim.x) * WPB + wib;
+    if (w >= (long)A.P * A.R) return; // wave-uniform; SPLIT: both waves of the block leave together
+    const int seg0 = SEG ? A.seg0 : part * (kWave * C);
+    const int segN = SEG ? A.segN : ((SPLIT > 1) ? min(A.N1 - seg0, kWave * C) : A.N1);
     const int lane = threadIdx.x & 63;
     const long pose = w / A.R;
     const int n0 = lane * C;
@@ -57,6 +63,11 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #endif
     STAMPW(2);
     float zprev = lane_prev(z[C - 1], z[C - 1]); // last sample of the lane below (lane 0: unused unless a carry comes in)
+    if (SPLIT > 1) {
+        if (part == 0 && lane == kWave - 1) s_c[4] = z[C - 1];
+        __syncthreads();
+        if (part == 1 && lane == 0) zprev = s_c[4];
+    }
     Mat K = mat_identity(), Klast = mat_identity();
     if (cin) { // carry of the earlier segments: running product and the sample just before this segment
         K = Mat{cin[w * 5 + 0], cin[w * 5 + 1], cin[w * 5 + 2], cin[w * 5 + 3]};
@@ -69,7 +80,20 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
 #pragma unroll
     for (int j = 0; j < C; ++j) e[j] = r[j];
 #else
-    echo_chunk<C, true>(r, lane, e, cin ? &K : nullptr, segN - 1, cout ? &Klast : nullptr);
+    if (SPLIT > 1) {
+        auto exchange = [&](const Mat &Lincl, Mat &carry) -> bool {
+            if (part == 0 && lane == kWave - 1) {
+                s_c[0] = Lincl.a; s_c[1] = Lincl.b; s_c[2] = Lincl.c; s_c[3] = Lincl.d;
+            }
+            __syncthreads();
+            if (part == 0) return false;
+            carry = Mat{s_c[0], s_c[1], s_c[2], s_c[3]};
+            return true;
+        };
+        echo_chunk<C, true>(r, lane, e, nullptr, -1, nullptr, exchange);
+    } else {
+        echo_chunk<C, true>(r, lane, e, cin ? &K : nullptr, segN - 1, cout ? &Klast : nullptr);
+    }
 #endif
     if (cout) { // hand the running product and the last impedance sample to the next segment
         const int last = segN - 1;
@@ -219,7 +243,14 @@ int launch_fwd_t(const Args &A, hipStream_t st)
     case 2: hipLaunchKernelGGL((render_fwd_kernel<2, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
     case 4: hipLaunchKernelGGL((render_fwd_kernel<4, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
     case 8: hipLaunchKernelGGL((render_fwd_kernel<8, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
-    default: hipLaunchKernelGGL((render_fwd_kernel<16, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    default: // 512 < N1 <= 1024: one wave with 16 samples per lane (100 VGPRs).  The two-wave SPLIT form that pays for
+             // the backward (render_bwd.hip) does not here: 31.4 against 21.9 us at 8 poses x 512 rays x 1024 steps
+#ifdef DIFFUS_FWD_SPLIT
+        hipLaunchKernelGGL((render_fwd_kernel<8, SM, LY, 2, PM, false, 2>), dim3((unsigned)waves), dim3(2 * kWave), 0, st, A);
+#else
+        hipLaunchKernelGGL((render_fwd_kernel<16, SM, LY, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A);
+#endif
+        break;
     }
     return last_launch();
 }

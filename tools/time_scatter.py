@@ -8,10 +8,11 @@ from diffus_amd import CapturedStep as HotPath
 from bench import time_events
 from diffus_amd import _lib
 from diffus_amd.phantom import phantom, pose_ring
-vol = torch.from_numpy(phantom(256)).cuda()
+N = int(os.environ.get("N", "256")); RAYS = int(os.environ.get("RAYS", "256")); SAMPLES = int(os.environ.get("SAMPLES", "512"))
+vol = torch.from_numpy(phantom(N)).cuda()
 P = int(os.environ.get("POSES", "32"))
-src, dirs = pose_ring(256, P, 256)
-hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), 512, 1e-4, "trilinear")
+src, dirs = pose_ring(N, P, RAYS)
+hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), SAMPLES, 1e-4, "trilinear")
 hp.fwd(); hp.loss_and_grad(); hp.zero_grad(); hp.bwd(_lib.BWD_SCAN)
 for _ in range(3):
     hp.step()
