@@ -18,7 +18,8 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
            "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd",
            "diffus_artifacts_workspace_bytes", "diffus_artifacts",
            "diffus_mlp_fwd", "diffus_mlp_workspace_bytes", "diffus_mlp_bwd", "diffus_brain_mask_workspace_bytes",
-           "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats", "diffus_rows_conv1d")
+           "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats", "diffus_rows_conv1d",
+           "diffus_prop_single_ray", "diffus_propagate_rays", "diffus_sample_points")
 
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
@@ -103,6 +104,12 @@ def load():
     lib.diffus_masked_stats.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     lib.diffus_rows_conv1d.restype = i
     lib.diffus_rows_conv1d.argtypes = [vp, i, i, vp, i, i, vp, vp]
+    lib.diffus_prop_single_ray.restype = i
+    lib.diffus_prop_single_ray.argtypes = [vp, i, i, i, vp, vp]
+    lib.diffus_propagate_rays.restype = i
+    lib.diffus_propagate_rays.argtypes = [vp, i, i, vp, vp]
+    lib.diffus_sample_points.restype = i
+    lib.diffus_sample_points.argtypes = [vp, i, i, i, i, vp, C.c_long, i, vp, vp, vp]
     if lib.diffus_abi_version() != 1:
         raise DiffusError("libdiffus_hip.so ABI version mismatch")
     _lib = lib

@@ -234,6 +234,77 @@ __global__ __launch_bounds__(kBlock) void rows_conv1d_kernel(const float *__rest
     }
 }
 
+// prop_single_ray (reference src/renderer.py:367-410) in closed form: the full solution w = [g0,d0,...,gN,dN] of the
+// 2(N+1) x 2(N+1) system that the reference builds and hands to torch.linalg.solve, one thread per ray, O(N).
+// With rho_k = d_k / g_k (what interface k reflects of what reaches it; rho_N = 0 because d_N = 0) the two rows
+// per interface (:397-405 with :380-382) give
+//     rho_k   = (r_k + (1 - 2 r_k^2) rho_{k+1}) / (1 - r_k rho_{k+1})          k = N-1 .. 0
+//     g_{k+1} = (1 + r_k) g_k / (1 - r_k rho_{k+1}),  d_k = rho_k g_k,  g_0 = 1   k = 0 .. N-1
+// A non-finite coefficient anywhere makes the reference's whole solution NaN, which nan_to_num (:408) turns into
+// zeros: reproduced as an all-zero row.  Remaining NaNs (0/0 of a singular system) become 0 like there.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void prop_single_ray_kernel(const T *__restrict__ rin, T *__restrict__ w, int B, int N)
+{
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const T *r = rin + (long)b * N;
+    T *o = w + (long)b * (2 * N + 2);
+    bool ok = true;
+    for (int k = 0; k < N; ++k) ok = ok && (r[k] - r[k] == T(0)); // finite
+    if (!ok) {
+        for (int k = 0; k < 2 * N + 2; ++k) o[k] = T(0);
+        return;
+    }
+    T rho = T(0);
+    o[2 * N + 1] = T(0);
+    for (int k = N - 1; k >= 0; --k) { // rho_k parked in the d_k slot
+        const T rk = r[k];
+        rho = (rk + (T(1) - T(2) * rk * rk) * rho) / (T(1) - rk * rho);
+        o[2 * k + 1] = rho;
+    }
+    T g = T(1);
+    o[0] = g;
+    for (int k = 0; k < N; ++k) {
+        const T rho_k = o[2 * k + 1], rho_n = o[2 * k + 3];
+        o[2 * k + 1] = rho_k * g;
+        g = (T(1) + r[k]) * g / (T(1) - r[k] * rho_n);
+        o[2 * k + 2] = g;
+    }
+    // d_N = rho_N g_N = 0 stays
+    for (int k = 0; k < 2 * N + 2; ++k)
+        if (o[k] != o[k]) o[k] = T(0);
+}
+
+// running sum along each row, in place: the cumsum of propagate_full_rays_batched (reference :435)
+__global__ __launch_bounds__(kBlock) void rows_cumsum_kernel(float *__restrict__ a, int B, int M)
+{
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    float *row = a + (long)b * M;
+    float acc = 0.f;
+    for (int k = 0; k < M; ++k) {
+        acc += row[k];
+        row[k] = acc;
+    }
+}
+
+// custom_nearest_sampler (reference src/renderer.py:741-759) at ARBITRARY points: round half to even, clamp, gather.
+template <int SAMPLER, int LAYOUT>
+__global__ __launch_bounds__(kBlock) void sample_points_kernel(const float *__restrict__ vol, Geom G, const float *__restrict__ pts,
+                                                               long n, float *__restrict__ val, long long *__restrict__ idx)
+{
+    for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long)gridDim.x * kBlock) {
+        const float p0 = pts[t * 3], p1 = pts[t * 3 + 1], p2 = pts[t * 3 + 2];
+        const int i0 = nearest_index(p0, G.d0), i1 = nearest_index(p1, G.d1), i2 = nearest_index(p2, G.d2);
+        if (idx) {
+            idx[t] = i0;
+            idx[n + t] = i1;
+            idx[2 * n + t] = i2;
+        }
+        if (val) val[t] = (SAMPLER == DIFFUS_NEAREST) ? vol[vox_off<LAYOUT>(G, i0, i1, i2)] : tri_sample<LAYOUT, false>(vol, G, p0, p1, p2).v;
+    }
+}
+
 template <int SM, int LY, int PM>
 int launch_fwd_t(const Args &A, hipStream_t st)
 {
@@ -371,6 +442,44 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stre
     default: hipLaunchKernelGGL(echo_traces_kernel<16>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
     }
     return last_launch();
+}
+
+int diffus_prop_single_ray(const void *refl, int dtype, int B, int N, void *w, diffus_stream_t stream)
+{
+    if (!w || B <= 0 || N < 0 || (!refl && N > 0)) return DIFFUS_EINVAL;
+    if (dtype != DIFFUS_F32 && dtype != DIFFUS_F64) return DIFFUS_EINVAL;
+    const unsigned nb = (unsigned)((B + kBlock - 1) / kBlock);
+    if (dtype == DIFFUS_F32)
+        hipLaunchKernelGGL(prop_single_ray_kernel<float>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, (const float *)refl, (float *)w, B, N);
+    else
+        hipLaunchKernelGGL(prop_single_ray_kernel<double>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, (const double *)refl, (double *)w, B, N);
+    return last_launch();
+}
+
+int diffus_propagate_rays(const float *refl, int B, int N, float *d0_cum, diffus_stream_t stream)
+{
+    int rc = diffus_echo_traces(refl, B, N, d0_cum, stream); // d0^(n) per truncation depth (d0^(0) = 0)
+    if (rc) return rc;
+    hipLaunchKernelGGL(rows_cumsum_kernel, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, d0_cum, B, N + 1);
+    return last_launch();
+}
+
+int diffus_sample_points(const float *vol, int d0, int d1, int d2, int layout, const float *points, long n, int sampler,
+                         float *values, int64_t *idx, diffus_stream_t stream)
+{
+    if (!vol || !points || n <= 0 || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    if (sampler != DIFFUS_NEAREST && sampler != DIFFUS_TRILINEAR) return DIFFUS_EINVAL;
+    if (layout != DIFFUS_CANONICAL && layout != DIFFUS_BRICKED && layout != DIFFUS_PAIRED) return DIFFUS_EINVAL;
+    if (d0 > (1 << 24) || d1 > (1 << 24) || d2 > (1 << 24) || bricked_floats(d0, d1, d2) >= ((size_t)1 << 30)) return DIFFUS_EUNSUPPORTED;
+    if (!values && !idx) return DIFFUS_OK;
+    const Geom G = make_geom(d0, d1, d2, layout);
+    unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
+    if (nb > 256u * 16u) nb = 256u * 16u;
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        hipLaunchKernelGGL((sample_points_kernel<decltype(S_)::value, decltype(L_)::value>), dim3(nb), dim3(kBlock), 0,
+                           (hipStream_t)stream, vol, G, points, n, values, (long long *)idx);
+        return last_launch();
+    });
 }
 
 int diffus_rows_conv1d(const float *in, int B, int N, const float *kernel, int L, int pad, float *out,

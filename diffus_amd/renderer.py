@@ -4,7 +4,7 @@
 argument meaning, return tuple and error behaviour of the reference
 (src/renderer.py:18-25, :201-275), so `from diffus_amd import *` is a drop-in for
 `from src.renderer import *` on this path.  All arithmetic happens in
-libdiffus_hip.so (diffus_amd/csrc/diffus_kernels.hip); PyTorch only provides
+libdiffus_hip.so (diffus_amd/csrc/*.hip); PyTorch only provides
 device memory, the current HIP stream and autograd plumbing.  There is no CPU
 fallback: without the built library every entry point raises DiffusError.
 
@@ -384,12 +384,80 @@ def compute_echo_traces(refLR: torch.Tensor, spacing: float = 1.0, c: float = 1.
     return echo.to(device=refLR.device, dtype=refLR.dtype if refLR.is_floating_point() else torch.float32), delays_us
 
 
+def prop_single_ray(refLR: torch.Tensor, traLR: torch.Tensor = None, traRL: torch.Tensor = None) -> torch.Tensor:
+    """Mirror of reference src/renderer.py:367-410: refLR (B,N) -> w (B, 2(N+1)) = [g0,d0,...,gN,dN], the solution of
+    the dense interface system of every ray -- evaluated in closed form on the GPU (diffus_prop_single_ray) instead of
+    torch.linalg.solve.  `traLR` / `traRL` are accepted and ignored, as in the reference (:380-381 overwrite them)."""
+    lib = _lib.load()
+    if refLR.dim() != 2:
+        raise ValueError("not enough values to unpack (expected 2, got %d)" % refLR.dim())  # B, N = refLR.shape
+    dev = _device_for(refLR)
+    dt = torch.float64 if refLR.dtype == torch.float64 else torch.float32
+    r = _as(refLR, dev, dt)
+    B, N = r.shape
+    with torch.cuda.device(dev):
+        w = torch.empty((B, 2 * (N + 1)), dtype=dt, device=dev)
+        if B:
+            rc = lib.diffus_prop_single_ray(_ptr(r) if N else None, _lib.DIFFUS_F64 if dt == torch.float64 else _lib.DIFFUS_F32,
+                                            B, N, _ptr(w), _stream(dev))
+            _lib.check(rc, "diffus_prop_single_ray")
+    return w.to(device=refLR.device, dtype=refLR.dtype if refLR.is_floating_point() else torch.float32)
+
+
+def propagate_full_rays_batched(refLR: torch.Tensor) -> torch.Tensor:
+    """Mirror of reference src/renderer.py:412-436: refLR (B,N) -> (B,N+1), the surface return d0 of every truncation
+    depth, cumulated along the depth (diffus_propagate_rays: the O(N) echo series + a running sum)."""
+    lib = _lib.load()
+    if refLR.dim() != 2:
+        raise ValueError("not enough values to unpack (expected 2, got %d)" % refLR.dim())
+    dev = _device_for(refLR)
+    r = _as(refLR, dev, torch.float32)
+    B, N = r.shape
+    with torch.cuda.device(dev):
+        out = torch.empty((B, N + 1), dtype=torch.float32, device=dev)
+        if B:
+            _lib.check(lib.diffus_propagate_rays(_ptr(r) if N else None, B, N, _ptr(out), _stream(dev)), "diffus_propagate_rays")
+    return out.to(device=refLR.device, dtype=refLR.dtype if refLR.is_floating_point() else torch.float32)
+
+
+def custom_nearest_sampler(Z: torch.Tensor, points: torch.Tensor, visualize: bool = True, sampler: str = "prop",
+                           start: int = 100):
+    """Mirror of reference src/renderer.py:741-819 for the default sampler 'prop': points (batch, num_samples, 3) in
+    voxel coordinates -> (x, y, z, ray_values), each (batch, num_samples); indices are rounded half to even and
+    clamped into the volume (:754-756).  `visualize` and `start` only drive the reference's matplotlib figure
+    (:762-801), which is not reproduced: they are accepted and ignored."""
+    lib = _lib.load()
+    if sampler not in _SAMPLERS:
+        raise ValueError(f"unknown sampler {sampler!r}")
+    if Z.dim() != 3:
+        raise ValueError("not enough values to unpack (expected 3, got %d)" % Z.dim())       # D, H, W = Z.shape
+    if points.dim() != 3 or points.shape[-1] != 3:
+        raise ValueError(f"points must be (batch, num_samples, 3); got {tuple(points.shape)}")
+    dev = _device_for(Z)
+    vol = _as(Z, dev, torch.float32)
+    pts = _as(points, dev, torch.float32)            # the reference's `points.float()` (:751)
+    b, ns, _ = pts.shape
+    n = b * ns
+    d0, d1, d2 = vol.shape
+    with torch.cuda.device(dev):
+        val = torch.empty((b, ns), dtype=torch.float32, device=dev)
+        idx = torch.empty((3, b, ns), dtype=torch.int64, device=dev)
+        if n:
+            rc = lib.diffus_sample_points(_ptr(vol), d0, d1, d2, _lib.CANONICAL, _ptr(pts), n, _SAMPLERS[sampler], _ptr(val),
+                                          _ptr(idx), _stream(dev))
+            _lib.check(rc, "diffus_sample_points")
+    out_dev = Z.device
+    vals = val.to(device=out_dev, dtype=Z.dtype if Z.is_floating_point() else torch.float32)
+    return idx[0].to(out_dev), idx[1].to(out_dev), idx[2].to(out_dev), vals
+
+
 def gaussian_pulse(length: int, sigma: float):
-    """1-D Gaussian pulse, peak 1 (reference src/renderer.py:481-496; NumPy, host side)."""
+    """Gaussian pulse of `length` taps on the grid linspace(-length // 2, length // 2), peak normalised to 1
+    (what reference src/renderer.py:481-496 returns; NumPy float64, host side)."""
     import numpy as np
-    t = np.linspace(-length // 2, length // 2, length)
-    pulse = np.exp(-0.5 * (t / sigma) ** 2)
-    return pulse / pulse.max()
+    grid = np.linspace(-length // 2, length // 2, length)
+    g = np.exp(-0.5 * (grid / sigma) ** 2)
+    return g / g.max()
 
 
 def compute_gaussian_pulse(refLR: torch.Tensor, spacing: float = 1.0, c: float = 1.54e3, length: int = 10,
@@ -432,8 +500,10 @@ class UltrasoundRenderer:
         return (Z2 - Z1) / (Z1 + Z2)
 
     @staticmethod
-    def trace_ray(volume, source, directions, num_samples, start=0, *, sampler="nearest"):
-        """reference :90-180 -> (x, y, z, ray_values), each (n_rays, num_samples)."""
+    def trace_ray(volume, source, directions, num_samples: int, start: int, *, sampler="nearest"):
+        """reference :90-180 -> (x, y, z, ray_values), each (n_rays, num_samples): the voxel indices of every sample
+        point and the impedance there.  `start` is a required argument like in the reference, where it only reaches
+        the visualisation (:178 -> :741): it does not change what is returned."""
         out = trace_rays(volume, source, directions, num_samples, sampler, want=("imp", "idx"))
         dev = volume.device
         idx = out["idx"][:, 0].to(dev)
@@ -441,7 +511,9 @@ class UltrasoundRenderer:
 
     def simulate_rays(self, volume, source, directions, num_samples: int = 0, MRI: bool = False, start=0, *,
                       sampler="nearest"):
-        """reference :35-71 -> (x, y, z, R) with R (n_rays, num_samples-1), or Z1 when MRI."""
+        """reference :35-71 -> (x, y, z, R) with R (n_rays, num_samples-1) the reflection coefficients between
+        consecutive samples -- squeezed to 1-D for a single ray like the reference's `R.squeeze(0)` --, or just the
+        impedances Z1 (n_rays, num_samples-1) when MRI.  `start` is passed on to trace_ray (no effect on values)."""
         if num_samples == 0:
             num_samples = self.num_samples
         out = trace_rays(volume, source, directions, num_samples, sampler, want=("imp", "refl", "idx"))

@@ -213,6 +213,22 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo,
                        diffus_stream_t stream);
 
 /*
+ * The remaining module functions `from src.renderer import *` gives the notebooks:
+ *   diffus_prop_single_ray  replaces prop_single_ray (reference src/renderer.py:367-410): refl (B,N), float32 or
+ *                           float64 like the caller's tensor -> w (B, 2N+2) = [g0,d0,...,gN,dN], the full solution of
+ *                           the dense system, in closed form (O(N) per ray); a ray with a non-finite coefficient gives
+ *                           all zeros, as linalg.solve + nan_to_num (:407-408) do.
+ *   diffus_propagate_rays   replaces propagate_full_rays_batched (:412-436): refl (B,N) -> (B,N+1), the surface
+ *                           return d0 per truncation depth, cumulated along the depth (:435).
+ *   diffus_sample_points    replaces custom_nearest_sampler (:741-759) for ARBITRARY points (n,3) float32 (the
+ *                           reference casts to float32 at :751): values (n) and, nullable, idx (3,n) int64.
+ */
+int diffus_prop_single_ray(const void *refl, int dtype, int B, int N, void *w, diffus_stream_t stream);
+int diffus_propagate_rays(const float *refl, int B, int N, float *d0_cum, diffus_stream_t stream);
+int diffus_sample_points(const float *vol, int d0, int d1, int d2, int layout, const float *points, long n, int sampler,
+                         float *values, int64_t *idx, diffus_stream_t stream);
+
+/*
  * The pulse stage of compute_gaussian_pulse (reference src/renderer.py:459-479, the F.conv1d at :477): every row of
  * `in` (B,N) correlated with `kernel` (L taps, no flip) with `pad` zeros on both sides -> out (B, N + 2*pad - L + 1).
  */

@@ -84,9 +84,20 @@ def echo_scan(r):
     return torch.stack(out, dim=1)
 
 
-def render(vol, source, directions, S, alpha, start=0, sampler="trilinear"):
-    """Differentiable plot_beam_frame (artifacts=False): -> frame (R, S-start)."""
-    pts = ray_points(source, directions, S)
+def ray_points_f32(source, directions, S):
+    """The sample points AS THE REFERENCE ROUNDS THEM for float32 poses -- float32 multiply, float32 add
+    (src/renderer.py:119-124) -- carried in the dtype of the inputs, with the exact derivatives d p / d source = I,
+    d p / d direction = k (straight-through: the value is the rounded point, the gradient that of the formula)."""
+    steps32 = torch.arange(S, dtype=torch.float32).view(1, S, 1)
+    p32 = source.detach().float().view(1, 1, 3) + steps32 * directions.detach().float().unsqueeze(1)
+    exact = ray_points(source, directions, S)
+    return p32.to(exact.dtype) + (exact - exact.detach())
+
+
+def render(vol, source, directions, S, alpha, start=0, sampler="trilinear", points="exact"):
+    """Differentiable plot_beam_frame (artifacts=False): -> frame (R, S-start).
+    points="f32": sample where the float32 march of the reference lands (ray_points_f32)."""
+    pts = ray_points_f32(source, directions, S) if points == "f32" else ray_points(source, directions, S)
     if sampler == "nearest":
         imp, _ = sample_nearest(vol, pts)
     else:

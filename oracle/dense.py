@@ -50,6 +50,13 @@ def solve_truncated(r: torch.Tensor) -> torch.Tensor:
     return torch.nan_to_num(torch.linalg.solve(A, b), nan=0.0)
 
 
+def propagate_dense(r: torch.Tensor) -> torch.Tensor:
+    """propagate_full_rays_batched (src/renderer.py:412-436): d0 of every truncated system, cumulated (:435)."""
+    B, N = r.shape
+    d0 = torch.stack([solve_truncated(r[:, :n])[:, 1] for n in range(N + 1)], dim=1)
+    return torch.cumsum(d0, dim=1)
+
+
 def echo_dense(r: torch.Tensor) -> torch.Tensor:
     """compute_echo_traces (src/renderer.py:412-457): r (B,N) -> echo (B,N+1)."""
     B, N = r.shape

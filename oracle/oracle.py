@@ -114,6 +114,15 @@ def prop_single_ray_dense(r):
     return w
 
 
+def sample_points_nearest(vol, pts):
+    """custom_nearest_sampler (src/renderer.py:751-759) at arbitrary points: cast to float32, round half to even,
+    clamp, gather.  vol (d0,d1,d2), pts (...,3) -> x, y, z (int64) and values, each of shape pts.shape[:-1]."""
+    vol = np.asarray(vol)
+    p = np.asarray(pts, dtype=np.float32)
+    idx = [np.clip(np.rint(p[..., c]).astype(np.int64), 0, vol.shape[c] - 1) for c in range(3)]
+    return idx[0], idx[1], idx[2], vol[idx[0], idx[1], idx[2]]
+
+
 def attenuate(echo, alpha):
     echo = np.ascontiguousarray(echo, dtype=np.float32)
     B, N1 = echo.shape

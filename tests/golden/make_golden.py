@@ -394,6 +394,43 @@ def main():
         out["mri"] = mri
         save("g15_impedance", **out)
 
+    # ---- G16: the other functions `from src.renderer import *` hands to the notebooks --------------------------
+    # prop_single_ray (full w vector), propagate_full_rays_batched (cumulated series), custom_nearest_sampler on
+    # arbitrary points, and the simulate_rays / trace_ray methods themselves
+    if want("g16"):
+        g = torch.Generator().manual_seed(16)
+        out = {}
+        r = (torch.rand(7, 23, generator=g) - 0.5) * 1.2
+        r[2, 5] = float("nan")                       # a NaN anywhere: the whole solution of that ray is zeroed
+        r[3, 4] = 1.0; r[3, 9] = -1.0                # air interfaces
+        r[4] = 0.0
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            rr = r.to(dt)
+            out["w_" + tag] = ref.prop_single_ray(rr).numpy()
+            out["cum_" + tag] = ref.propagate_full_rays_batched(rr).numpy()
+        out["r"] = r.numpy()
+        out["w_empty"] = ref.prop_single_ray(torch.zeros(3, 0)).numpy()
+        vol = torch.rand(9, 11, 13, generator=g) * 1e6 + 1e6
+        pts = torch.rand(5, 17, 3, generator=g) * torch.tensor([12.0, 14.0, 16.0]) - 2.0     # inside and outside
+        pts[0, :6, 0] = torch.tensor([0.5, 1.5, 2.5, 3.5, -0.5, 8.5])                      # ties: round half to even
+        with quiet():
+            x, y, z, v = ref.custom_nearest_sampler(vol, pts, visualize=False)
+            x64, y64, z64, v64 = ref.custom_nearest_sampler(vol, pts.double(), visualize=False)
+        out.update(vol=vol.numpy(), pts=pts.numpy(), sx=x.numpy(), sy=y.numpy(), sz=z.numpy(), sv=v.numpy())
+        assert torch.equal(x, x64) and torch.equal(v, v64)
+        v32 = torch.from_numpy(phantom(32))
+        s, d = pose_ring(32, 4, 12)
+        rrn = ref.UltrasoundRenderer(num_samples=40, attenuation_coeff=1e-3)
+        with quiet():
+            tx, ty, tz, tv = ref.UltrasoundRenderer.trace_ray(v32, torch.from_numpy(s[1]), torch.from_numpy(d[1]), 40, 0)
+            qx, qy, qz, qr = rrn.simulate_rays(v32, torch.from_numpy(s[1]), torch.from_numpy(d[1]), start=7)
+            z1 = rrn.simulate_rays(v32, torch.from_numpy(s[1]), torch.from_numpy(d[1]), num_samples=25, MRI=True)
+        import matplotlib.pyplot as plt
+        plt.close("all")
+        out.update(pose_src=s[1], pose_dirs=d[1], tr_x=tx.numpy(), tr_y=ty.numpy(), tr_z=tz.numpy(), tr_v=tv.numpy(),
+                   sim_x=qx.numpy(), sim_y=qy.numpy(), sim_z=qz.numpy(), sim_r=qr.numpy(), sim_mri=z1.numpy())
+        save("g16_api_functions", **out)
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

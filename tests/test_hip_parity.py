@@ -431,6 +431,45 @@ def test_config5_shape_512_volume_vs_oracle_and_backward(da, oracle):
         assert maxnorm_rel((-2 * a).cpu().numpy(), b.cpu().numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("n,ring,R,S,pose", [(256, 32, 256, 512, 3), (512, 8, 512, 1024, 5)])
+def test_full_size_one_pose_gradient_values_vs_float64_autograd(da, n, ring, R, S, pose):
+    """VALUES, not just properties, at the BASELINE shapes: one config-2 pose (256 rays x 512 steps, 256^3) and one
+    config-5 pose (512 rays x 1024 steps, 512^3): frame, d/dvolume, d/dsource and d/ddirections of sum(frame^2) against
+    torch autograd over the float64 restatement (oracle/autograd_ref.py), max-norm-relative <= 1e-3."""
+    from oracle import autograd_ref as ar
+    alpha = 1e-4
+    v = phantom(n, variant=1 if n == 512 else 0)
+    src, dirs = pose_ring(n, ring, R)
+    vol = cuda(v).requires_grad_(True)
+    s = torch.from_numpy(src[pose:pose + 1]).cuda().requires_grad_(True)
+    d = torch.from_numpy(dirs[pose:pose + 1]).cuda().requires_grad_(True)
+    f = da.render_poses(vol, s, d, S, alpha, sampler="trilinear")
+    (f ** 2).sum().backward()
+    got = (f.detach()[0].cpu().numpy(), s.grad[0].cpu().numpy(), d.grad[0].cpu().numpy())
+    gv = vol.grad.cpu()
+    del vol, f
+    torch.cuda.empty_cache()
+    v64 = torch.from_numpy(v).double().requires_grad_(True)
+    s64 = torch.from_numpy(src[pose]).double().requires_grad_(True)
+    d64 = torch.from_numpy(dirs[pose]).double().requires_grad_(True)
+    # float64 arithmetic at the sample points the float32 march of the reference lands on (:119-124; ray_points_f32):
+    # marching in float64 instead moves every point ~1e-5 voxel, next to bone/air steps of 6e6 per voxel -- 1e-4 on the
+    # frame and more on d/dsource, a sum of half a million signed terms -- which would measure the poses' dtype, not
+    # the kernels
+    fr = ar.render(v64, s64, d64, S, alpha, 0, "trilinear", points="f32")
+    (fr ** 2).sum().backward()
+    assert maxnorm_rel(got[0], fr.detach().numpy()) < 2e-5
+    assert maxnorm_rel(got[1], s64.grad.numpy()) < 1e-3
+    assert maxnorm_rel(got[2], d64.grad.numpy()) < 1e-3
+    gref = v64.grad
+    den = float(gref.abs().max())
+    err = 0.0
+    for i0 in range(0, n, 64):                                     # slab by slab: no GiB-sized temporaries
+        err = max(err, float((gv[i0:i0 + 64].double() - gref[i0:i0 + 64]).abs().max()))
+    assert den > 0 and err / den < 1e-3, err / den
+    assert int((gv != 0).sum()) > 0.5 * int((gref != 0).sum())      # the support is there, not just the peak
+
+
 # ----------------------------------------------------------------------------- bricked layout
 @pytest.mark.parametrize("shape", [(4, 4, 2), (5, 7, 3), (64, 64, 64), (33, 70, 129), (1, 1, 1), (3, 2, 131)])
 def test_brick_roundtrip(da, shape):
