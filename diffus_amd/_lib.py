@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so")
 
-EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes",
+EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "diffus_workspace_zbar_offset",
            "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume", "diffus_paired_floats",
            "diffus_pair_volume", "diffus_brick_count", "diffus_gradbuf_flush",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_trace_rays", "diffus_echo_traces",
@@ -52,6 +52,8 @@ def load():
     lib.diffus_strerror.argtypes = [i]
     lib.diffus_workspace_bytes.restype = sz
     lib.diffus_workspace_bytes.argtypes = [i, i, i, i]
+    lib.diffus_workspace_zbar_offset.restype = sz
+    lib.diffus_workspace_zbar_offset.argtypes = [i, i, i, i]
     common = [vp, i, i, i, i, vp, i, vp, i, i, i, i, i, f, i]
     lib.diffus_render_fwd.restype = i
     lib.diffus_render_fwd.argtypes = common + [vp, vp, vp, sz, vp]

@@ -371,6 +371,13 @@ size_t diffus_workspace_bytes(int P, int R, int S, int start)
     return carve(nullptr, P, R, S - start).bytes;
 }
 
+size_t diffus_workspace_zbar_offset(int P, int R, int S, int start)
+{
+    if (P <= 0 || R <= 0 || S <= 0 || start < 0 || start >= S) return 0;
+    Workspace ws = carve(nullptr, P, R, S - start);
+    return (size_t)((char *)ws.zbar - (char *)nullptr);
+}
+
 int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
                       float *frame, int64_t *idx, void *workspace, size_t workspace_bytes, diffus_stream_t stream)

@@ -61,6 +61,13 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
     // (z0 odd) of the tile entries, and the two depth weights are applied once per entry in the flush.
     constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED) && (SAMPLER == DIFFUS_TRILINEAR);
     constexpr int UNIT2 = 16; // tile entries per brick column in planar mode
+    // Planar tiles are so much smaller (at config 3: 551 entries on average, 2304 at most, of 6144) that their entries
+    // can be 64-BIT: the quantum is 2^-61 of the patch's sum of |zbar| instead of 2^-29, so a contribution 2^-37 below
+    // the patch's largest still has full float precision.  It matters for strongly attenuated frames: with the
+    // reference's default attenuation_coeff = 0.5 the upstream gradient falls by 2^-46 across the 32 steps of a patch
+    // and a 32-bit accumulator rounds the deep end of every patch to exactly zero.
+    constexpr int kCap2 = kTileCap / 2; // 64-bit entries in the tile
+    long long *tile64 = reinterpret_cast<long long *>(tile);
 
     if (blockIdx.x >= npatch) { // tail blocks of the launch, one per pose: median routing (start > 0) and d/dsource
         pose_finish_block<SAMPLER, LAYOUT>(A, (int)(blockIdx.x - npatch), reinterpret_cast<float *>(tile));
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
             const unsigned e = (a == 2 && planar) ? 1u : (unsigned)min(max(b[a], 0), 0x7fff);
             v = min(v, (unsigned)kTileCap + 1u) * e;
         }
+        if (planar && v > (unsigned)kCap2) v = (unsigned)kTileCap + 1u; // 64-bit entries: half as many fit
         return empty ? 0 : (int)min(v, (unsigned)kTileCap + 1u);
     };
     static_assert(kSW == 4 || kSW == 8, "wave grouping below: 1, 2 or 4 groups of waves");
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
     float ztot = 0.f; // >= every single |zbar| of the patch (a float sum of non-negative terms is monotone)
 #pragma unroll
     for (int wv = 0; wv < kSW; ++wv) ztot += __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_sum[wv])));
-    const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
+    const int fx = (planar ? 61 : 29) - __builtin_amdgcn_frexp_expf(ztot); // planar: (sum) * 2^fx in [2^60, 2^61)
     const int wpg = kSW / nsub; // waves per group
 #pragma unroll 1
     for (int sp = 0; sp < nsub; ++sp) { // block-uniform trip count and branches
@@ -239,9 +247,17 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
                 const float sc = ldexpf(zb[q], fx);
                 const int ex0 = part2(c.i0[0], 0), ex1 = part2(c.i1[0], 0), ey0 = part2(c.i0[1], 1), ey1 = part2(c.i1[1], 1);
                 const float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1;
-                auto add = [&](int e, float v) {
-                    int qi = __float2int_rn(v);
-                    if (qi != 0) atomicAdd(&tile[e], qi);
+                auto add = [&](int e, float v) { // |v| < 2^62: round to a 64-bit integer as (hi, lo) words
+                    const float m = fabsf(v);
+                    if (m >= 0.5f) {
+                        // magnitude first: a float >= 2^32 is a multiple of 2^9, so both words below are exact
+                        const float mh = floorf(m * 0x1p-32f);                  // high word, < 2^30
+                        const float ml = __builtin_fmaf(mh, -0x1p32f, m);       // m - mh 2^32 in [0, 2^32), exact
+                        const unsigned lo = (unsigned)fminf(rintf(ml), 4294967040.f);
+                        long long qi = ((long long)(unsigned)mh << 32) + (long long)lo;
+                        if (v < 0.f) qi = -qi;
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&tile64[e]), (unsigned long long)qi);
+                    }
                 };
                 add(ex0 + ey0, sc * wa0 * wb0);
                 add(ex0 + ey1, sc * wa0 * wb1);
@@ -261,20 +277,19 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
         const int zz = (o & 1) ? iz1 : iz0;
         const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
         const unsigned zpart = (unsigned)(zz >> 1) * kBrickFloats + (unsigned)((o >> 1) << 1) + (unsigned)(zz & 1);
-        const float unscale = ldexpf(wz, -fx);
         constexpr int FU2 = 4;
         for (int q0 = msub; q0 < ncols; q0 += mstep * FU2) {
-            int v[FU2];
+            long long v[FU2];
 #pragma unroll
             for (int u = 0; u < FU2; ++u) {
                 const int q = q0 + u * mstep;
-                v[u] = (q < ncols) ? tile[q * UNIT2 + (o >> 1)] : 0;
+                v[u] = (q < ncols) ? tile64[q * UNIT2 + (o >> 1)] : 0ll;
             }
             if (nsub > 1) { // leave the tile clean for the next group (after both lanes of a pair have read their entry)
 #pragma unroll
                 for (int u = 0; u < FU2; ++u) {
                     const int q = q0 + u * mstep;
-                    if (v[u] != 0 && !(o & 1)) tile[q * UNIT2 + (o >> 1)] = 0;
+                    if (v[u] != 0 && !(o & 1)) tile64[q * UNIT2 + (o >> 1)] = 0ll;
                 }
             }
 #pragma unroll
@@ -286,7 +301,8 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
                     const int j = q - i * b1;
                     const unsigned g = ((unsigned)(l0 + i) * (unsigned)A.G.nb1 + (unsigned)(l1 + j)) * (unsigned)A.G.nb2 * kBrickFloats + zpart;
                     if (A.gtouched && o < 2) A.gtouched[g >> 5] = 1; // lanes 0 and 1: the brick of z0 and the brick of z1
-                    if (v[u] != 0 && wz != 0.f) atomicAdd(A.gvol + g, (float)v[u] * unscale);
+                    // back to the natural scale first (2^-fx alone may underflow a float), then the depth weight
+                    if (v[u] != 0 && wz != 0.f) atomicAdd(A.gvol + g, ldexpf(__ll2float_rn(v[u]), -fx) * wz);
                 }
             }
         }

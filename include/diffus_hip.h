@@ -79,6 +79,10 @@ const char *diffus_strerror(int code);
 /* Scratch the calls below need for a given problem (bytes; 256-B aligned device
  * memory supplied by the caller, reusable across calls on one stream). */
 size_t diffus_workspace_bytes(int P, int R, int S, int start);
+/* Byte offset, inside that workspace, of zbar (P,R,S-start) float32 = dL/d(impedance sample): what DIFFUS_BWD_SCAN
+ * leaves for DIFFUS_BWD_SCATTER (see diffus_render_bwd).  A caller that runs the two stages as separate calls may read
+ * it (per-sample impedance gradients) or add its own terms to it in between. */
+size_t diffus_workspace_zbar_offset(int P, int R, int S, int start);
 
 /*
  * Data layout in HBM.  The reference indexes a dense (d0,d1,d2) tensor with dim 2

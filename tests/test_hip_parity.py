@@ -470,6 +470,47 @@ def test_full_size_one_pose_gradient_values_vs_float64_autograd(da, n, ring, R, 
     assert int((gv != 0).sum()) > 0.5 * int((gref != 0).sum())      # the support is there, not just the peak
 
 
+@pytest.mark.parametrize("alpha", [1e-4, 0.5])
+def test_fixed_point_scatter_error_bound_per_voxel(da, alpha):
+    """The scatter accumulates a patch (32 rays x 32 steps) in integer fixed point with ONE power-of-two scale per
+    patch.  With the reference's default attenuation_coeff = 0.5 the upstream gradient falls by e per step, 2^-46 over a
+    patch: a 32-bit accumulator rounds the deep end of every patch to zero -- invisible in the max norm,
+    fatal for per-element-normalised optimisers.  Planar patches therefore accumulate in 64 bits (quantum 2^-61 of the
+    patch's sum of |zbar|).  The bound is asserted on the scatter ALONE: the kernel's own zbar (read back from the
+    workspace between the two backward stages) is scattered exactly, in float64, on the CPU; per voxel, relative to
+    the voxel's mass m_v = sum_s |zbar_s| w_sv (float32 atomics cannot beat a rounding error of that):
+        |g_v - exact_v| <= 4e-6 m_v + 2^-40 max m."""
+    from diffus_amd import CapturedStep, _lib
+    from oracle import autograd_ref as ar
+    n, R, S = 64, 64, 96
+    v = phantom(n)
+    src, dirs = pose_ring(n, 8, R)
+    hp = CapturedStep(cuda(v), torch.from_numpy(src[2:3]).cuda(), torch.from_numpy(dirs[2:3]).cuda(), S, alpha, "trilinear",
+                      persistent=False)
+    hp.fwd(); hp.loss_and_grad(); hp.zero_grad()
+    hp.bwd(_lib.BWD_SCAN)
+    torch.cuda.synchronize()
+    off = _lib.load().diffus_workspace_zbar_offset(1, R, S, 0)
+    zbar = hp.ws[off:off + 4 * R * S].view(torch.float32).reshape(R, S).cpu().double()
+    hp.bwd(_lib.BWD_SCATTER); hp.finish_grad()
+    torch.cuda.synchronize()
+    g = hp.gvol.cpu().double()
+    pts = ar.ray_points_f32(torch.from_numpy(src[2]).double(), torch.from_numpy(dirs[2]).double(), S)
+    ve = torch.from_numpy(v).double().requires_grad_(True)
+    (zbar * ar.sample_trilinear(ve, pts)).sum().backward()
+    vm = torch.from_numpy(v).double().requires_grad_(True)
+    (zbar.abs() * ar.sample_trilinear(vm, pts)).sum().backward()
+    exact, mass = ve.grad, vm.grad
+    tol = 4e-6 * mass + 2.0 ** -40 * float(mass.max())
+    worst = float(((g - exact).abs() / tol).max())
+    assert worst <= 1.0, worst
+    # the deep end is really there: voxels whose mass is 2^-30 .. 2^-38 of the largest carry their gradient
+    deep = (mass < 2.0 ** -30 * float(mass.max())) & (mass > 2.0 ** -38 * float(mass.max()))
+    if alpha == 0.5:
+        assert int(deep.sum()) > 50
+        assert int((g[deep] != 0).sum()) > 0.9 * int(deep.sum())
+
+
 # ----------------------------------------------------------------------------- bricked layout
 @pytest.mark.parametrize("shape", [(4, 4, 2), (5, 7, 3), (64, 64, 64), (33, 70, 129), (1, 1, 1), (3, 2, 131)])
 def test_brick_roundtrip(da, shape):
