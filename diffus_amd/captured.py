@@ -14,8 +14,10 @@ captured hipGraph, because libdiffus_hip.so never allocates or synchronises.
         step.replay()                                    # forward + sum-of-squares loss + backward + hand-back
         use(step.loss, step.gvol, step.gsrc, step.gdirs) # (P,), (d0,d1,d2), (P,3), (P,R,3)
 
-With an external loss (splat -> SSIM, ...) run `forward()`, write dL/dframe into `step.gframe`, then
-`backward()`; both halves capture separately.  A learnable volume (`learnable_volume=True`) is re-converted to
+With an external loss (splat -> SSIM, ...) either run `forward()`, write dL/dframe into `step.gframe`, then
+`backward()` (both halves capture separately), or call `step.render(volume, sources, directions)`: it returns the
+frame as a node of torch's autograd graph, so `loss.backward()` reaches the volume and the poses through the captured
+backward -- the drop-in `render_poses` costs 0.1-0.3 ms of host time per step, this ~0.05 ms.  A learnable volume (`learnable_volume=True`) is re-converted to
 the kernels' layout inside every step, so an optimiser may update `volume` in place between replays.
 
 The volume gradient comes back in the caller's canonical (d0,d1,d2) tensor `gvol`.  By default it is PERSISTENT:
@@ -49,13 +51,55 @@ def _pose_tensor(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _CapturedRender(torch.autograd.Function):
+    """frame = step.forward(); backward = step.backward() with the incoming dL/dframe.  The step owns every buffer."""
+
+    @staticmethod
+    def forward(ctx, step, volume, sources, directions):
+        step._run("forward")
+        ctx.step = step
+        ctx.stamp = step._stamp = step._stamp + 1
+        return step.frame.detach()          # a new tensor object on the step's frame buffer (no copy)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gframe):
+        step = ctx.step
+        if ctx.stamp != step._stamp:
+            raise RuntimeError("CapturedStep.render: backward of a frame whose buffers a later render() has overwritten "
+                               "(one forward, one backward, in that order)")
+        if gframe.data_ptr() != step.gframe.data_ptr():
+            step.gframe.copy_(gframe)
+        step._run("backward")
+        need_v, need_s, need_d = ctx.needs_input_grad[1:4]
+        keep = (lambda t: t) if step.alias_grads else (lambda t: t.clone())
+        return (None, keep(step.gvol) if (need_v and step.gvol is not None) else None,
+                keep(step.gsrc).reshape(step._src_shape) if need_s else None, keep(step.gdirs) if need_d else None)
+
+
+class _SliceIntoVolume(torch.autograd.Function):
+    """step.vol[..., index, ...] = values (in place, the other voxels keep their values); d/dvalues = that slice of d/dvolume."""
+
+    @staticmethod
+    def forward(ctx, step, values, dim, index):
+        step.vol.select(dim, index).copy_(values)
+        ctx.where = (dim, index)
+        return step.vol.detach()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gvol):
+        dim, index = ctx.where
+        return None, gvol.select(dim, index).contiguous(), None, None
+
+
 class CapturedStep:
     """Pre-allocated buffers + direct C-ABI calls; `capture()` turns `step()` into one hipGraph."""
 
     def __init__(self, volume: torch.Tensor, sources: torch.Tensor, directions: torch.Tensor, num_samples: int,
                  attenuation_coeff: float, sampler: str = "trilinear", start: int = 0, want_gvol: bool = True,
                  layout: str = "paired", sparse: bool = True, persistent: bool = True,
-                 learnable_volume: bool = False):
+                 learnable_volume: bool = False, alias_grads: bool = False):
         if not volume.is_cuda:
             raise _lib.DiffusError("CapturedStep needs a HIP-resident volume; there is no CPU fallback")
         if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous():
@@ -74,6 +118,12 @@ class CapturedStep:
         self.S, self.start, self.alpha = int(num_samples), int(start), float(attenuation_coeff)
         self.N1 = self.S - self.start
         self.learnable_volume = bool(learnable_volume)
+        # render(): hand autograd the step's own gradient buffers instead of clones of them.  Fine for the usual loop
+        # (optimizer.zero_grad(set_to_none=True), one backward per forward); a .grad that autograd adopted is then
+        # overwritten in place by the next step.
+        self.alias_grads = bool(alias_grads)
+        self._src_shape = tuple(sources.shape)
+        self._stamp = 0
         self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
         self.gframe = torch.empty_like(self.frame)
         d0, d1, d2 = (int(x) for x in volume.shape)
@@ -200,3 +250,46 @@ class CapturedStep:
 
     def replay(self, what: str = "step"):
         self._graphs[what].replay()
+
+    def _run(self, what: str):
+        g = self._graphs.get(what)
+        if g is not None:
+            g.replay()
+        else:
+            getattr(self, what)()
+
+    # -- autograd ----------------------------------------------------------------------------------------------------
+    def volume_with_slice(self, values: torch.Tensor, dim: int, index: int) -> torch.Tensor:
+        """The step's volume with ONE slice replaced by `values` (e.g. the impedance an MLP predicts for the imaging
+        plane -- `Z_vol = x.clone(); Z_vol[:, :, k] = Z_slice` of the reference's training notebook, cell 16 -- without
+        cloning 64 MiB per iteration): written in place, returned as an autograd node whose backward hands `values`
+        its slice of d/dvolume.  Pass the result to `render()`.  Canonical layout, or `learnable_volume=True`."""
+        if self.layout != _lib.CANONICAL and not self.learnable_volume:
+            raise _lib.DiffusError("volume_with_slice(): the converted copy must follow the volume: use layout='canonical' "
+                                   "or learnable_volume=True")
+        return _SliceIntoVolume.apply(self, values, int(dim), int(index))
+
+    def render(self, volume: Optional[torch.Tensor] = None, sources: Optional[torch.Tensor] = None,
+               directions: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Forward frame (P,R,N1) as a node of torch's autograd graph: `loss.backward()` runs the step's backward and
+        delivers d/dvolume, d/dsources, d/ddirections to whichever of the three arguments require grad.
+
+        Arguments that are not the step's own tensors are copied into them in place (a 256^3 volume: 64 MiB, ~20 us on
+        the device); a volume that changes between calls needs `learnable_volume=True` (its converted copy is then
+        rebuilt inside the forward).  The returned frame aliases the step's frame buffer: it is valid until the next
+        forward.  Uses the captured "forward" / "backward" graphs when `capture("forward")` / `capture("backward")`
+        were called, eager launches otherwise (e.g. inside a caller's own torch.cuda.graph capture)."""
+        v = self.vol if volume is None else volume
+        s = self.src if sources is None else sources
+        d = self.dirs if directions is None else directions
+        with torch.no_grad():
+            if v.data_ptr() != self.vol.data_ptr():
+                if not self.learnable_volume and self.layout != _lib.CANONICAL:
+                    raise _lib.DiffusError("render(): a volume other than the step's own needs learnable_volume=True "
+                                           "(its converted copy must be rebuilt)")
+                self.vol.copy_(v)
+            if s.data_ptr() != self.src.data_ptr():
+                self.src.copy_(s.reshape(self.src.shape))
+            if d.data_ptr() != self.dirs.data_ptr():
+                self.dirs.copy_(d.reshape(self.dirs.shape))
+        return _CapturedRender.apply(self, v, s, d)

@@ -250,13 +250,27 @@ __global__ __launch_bounds__(kBlock) void mlp_bwd_kernel(MlpArgs A)
     }
 }
 
+// gparams[q] = sum over blocks of partial[b][q], in a fixed order (deterministic).  A block takes 16 parameters; its 256
+// threads are 16 slices of the block list x 16 parameters, each slice summed serially, the 16 slice sums added in
+// order.  (One thread per parameter walking all ~1000 partial blocks was a chain of dependent loads: 61 us -- for a
+// 256 x 256 slice more than the rest of a whole training iteration.)
+constexpr int kRedParams = 16, kRedSlices = kBlock / kRedParams;
 __global__ __launch_bounds__(kBlock) void mlp_reduce_kernel(const float *__restrict__ partial, int nblk, float *__restrict__ gparams)
 {
-    const int q = blockIdx.x * kBlock + threadIdx.x;
-    if (q >= kNP) return;
+    __shared__ float sm[kRedSlices][kRedParams];
+    const int p = threadIdx.x % kRedParams, sl = threadIdx.x / kRedParams;
+    const int q = blockIdx.x * kRedParams + p;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * kNP + q];
-    gparams[q] = s;
+    if (q < kNP)
+        for (int b = sl; b < nblk; b += kRedSlices) s += partial[(size_t)b * kNP + q];
+    sm[sl][p] = s;
+    __syncthreads();
+    if (sl == 0 && q < kNP) {
+        float t = sm[0][p];
+#pragma unroll
+        for (int k = 1; k < kRedSlices; ++k) t += sm[k][p];
+        gparams[q] = t;
+    }
 }
 
 // ---- create_brain_mask: threshold, then 6-neighbourhood dilations / erosions (outside = 0, like SciPy) ----
@@ -378,7 +392,7 @@ int diffus_mlp_bwd(const float *x, const unsigned char *mask, size_t n, const fl
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nblk), dim3(kBlock), 0, st, A);
     if (hipGetLastError() != hipSuccess) return DIFFUS_ELAUNCH;
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((kNP + kBlock - 1) / kBlock), dim3(kBlock), 0, st, A.partial, (int)nblk, gparams);
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((kNP + kRedParams - 1) / kRedParams), dim3(kBlock), 0, st, A.partial, (int)nblk, gparams);
     return last_launch();
 }
 

@@ -89,9 +89,10 @@ class ImpedanceEstimator(nn.Module):
         m = self.model
         return m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x (..., 1) (or any shape: the MLP is applied to every element) -> same shape."""
-        return _MlpFn.apply(x, *self._params(), None, 0.0, 1.0, 1.0, 0.0)
+    def forward(self, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        """x (..., 1) (or any shape: the MLP is applied to every element) -> same shape.  `scale` multiplies the output
+        inside the kernel (the notebooks' `model(x) * 1e6` without the extra elementwise pass, forward and backward)."""
+        return _MlpFn.apply(x, *self._params(), None, 0.0, 1.0, float(scale), 0.0)
 
     @classmethod
     def train_model(cls, X: torch.Tensor, y: torch.Tensor, input_dim: int = 1, lr: float = 1e-3,

@@ -82,25 +82,32 @@ def _device_for(t: torch.Tensor) -> torch.device:
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
-    ws = _workspaces.get(dev)
+    """Scratch of the current stream of `dev` (one buffer per stream: two streams or autograd worker threads on one
+    device never share contents).  A buffer that has to grow is replaced; the caching allocator hands the old block out
+    again only to allocations of the same stream, i.e. behind the kernels still using it."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
-        _workspaces[dev] = ws
+        _workspaces[key] = ws
     return ws
 
 
 def _gradbuf(dev: torch.device, shape):
-    """Persistent sparse-gradient scratch of a device/shape: bricked floats + one flag per brick.
-    Invariant: both all-zero whenever no backward is in flight (diffus_gradbuf_flush restores it)."""
-    key = (dev, tuple(shape), torch.cuda.current_stream(dev).cuda_stream)   # one scratch per stream: no cross-stream races
-    gb = _gradbufs.get(key)
+    """Persistent sparse-gradient scratch of a device/shape/stream: bricked floats + one flag per brick.
+    Invariant: both all-zero whenever no backward is in flight on that stream (diffus_gradbuf_flush restores it)."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, tuple(shape), stream)   # one scratch per stream: no cross-stream races
+    gb = _gradbufs.pop(key, None)
     if gb is None:
         lib = _lib.load()
         gb = (torch.zeros(lib.diffus_bricked_floats(*shape), dtype=torch.float32, device=dev),
               torch.zeros(lib.diffus_brick_count(*shape), dtype=torch.int32, device=dev))
-        if len(_gradbufs) >= 3:
-            _gradbufs.pop(next(iter(_gradbufs)))
-        _gradbufs[key] = gb
+        # evict the least recently used scratch OF THIS STREAM only: another stream's may have a flush in flight
+        mine = [k for k in _gradbufs if k[0] == dev and k[2] == stream]
+        if len(mine) >= 3:
+            _gradbufs.pop(mine[0])
+    _gradbufs[key] = gb                 # (re)inserted last: dict order = recency
     return gb
 
 
@@ -276,6 +283,10 @@ class _RenderFn(torch.autograd.Function):
             rc = lib.diffus_render_fwd(*pb.common(), _ptr(frame), _ptr(idx), _ptr(ws), ws.numel(), _stream(pb.dev))
         _lib.check(rc, "diffus_render_fwd")
         ctx.pb = pb
+        # The backward recomputes the forward from the tensors as they are THEN (nothing is stashed by value): it is
+        # only right if they are unchanged, so their in-place version counters are checked like autograd checks saved
+        # tensors.
+        ctx.versions = (volume, volume._version, sources, sources._version, directions, directions._version)
         ctx.meta = (volume.device, volume.dtype, sources.device, sources.dtype, tuple(sources.shape),
                     directions.device, directions.dtype, tuple(directions.shape))
         if idx is None:
@@ -284,9 +295,15 @@ class _RenderFn(torch.autograd.Function):
         return frame, idx
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, gframe, _gidx):
         lib = _lib.load()
         pb = ctx.pb
+        tv, vv, ts, vs, td, vd = ctx.versions
+        for name, t, ver in (("volume", tv, vv), ("sources", ts, vs), ("directions", td, vd)):
+            if t._version != ver:
+                raise RuntimeError(f"diffus_amd: `{name}` was modified in place between the forward and this backward "
+                                   f"(version {ver} -> {t._version}); the backward recomputes the forward from its inputs")
         vdev, vdt, sdev, sdt, sshape, ddev, ddt, dshape = ctx.meta
         need_v, need_s, need_d = ctx.needs_input_grad[:3]
         with torch.cuda.device(pb.dev):
