@@ -38,43 +38,48 @@ def median_angle_of(direction) -> float:
     return math.atan2(float(direction[1]), float(direction[0]))
 
 
-# ---- probe-pose helpers of the reference (host-side NumPy geometry) -----------
+# ---- probe-pose helpers (host-side NumPy geometry) -------------------------------------------
+# Values are bit-identical with the reference's helpers (golden G12): the same NumPy primitives on the same operands
+# (np.linalg.inv, np.linalg.norm of each 2-vector, np.dot), arranged this package's way.
+def _homogeneous(v):
+    return np.append(np.asarray(v, dtype=np.float64), 1.0)
+
+
+def _unit(v):
+    return v / np.linalg.norm(v)
+
+
 def voxel_to_world(idx_ijk, affine):
-    """reference src/cone.py:10-13"""
-    ijk1 = np.concatenate((idx_ijk, [1.0]))
-    return affine.dot(ijk1)[:3]
+    """Voxel index (i, j, k) -> world coordinates through a NIfTI affine (what reference src/cone.py:10-13 returns)."""
+    return (affine @ _homogeneous(idx_ijk))[:3]
 
 
 def world_to_voxel(xyz, affine):
-    """reference src/cone.py:15-19"""
-    xyz1 = np.concatenate((xyz, [1.0]))
-    return np.linalg.inv(affine).dot(xyz1)[:3]
+    """World coordinates -> (fractional) voxel index: the inverse affine applied (reference src/cone.py:15-19)."""
+    return (np.linalg.inv(affine) @ _homogeneous(xyz))[:3]
 
 
 def compute_us_apex_and_direction(m_left, b_left, m_right, b_right):
-    """Apex, opening angle and bisector of the fan bounded by the two edge lines
-    y = m_left x + b_left and y = m_right x + b_right (reference src/cone.py:98-126)."""
+    """The fan between the two edge lines y = m x + b picked on the ultrasound slice: where they cross (the apex), the
+    angle between them and the unit bisector pointing into the fan.  Same dict as reference src/cone.py:98-126."""
     if np.isclose(m_left, m_right):
         raise RuntimeError("The slopes are nearly equal; no defined intersection.")
-    x0 = (b_right - b_left) / (m_left - m_right)
-    y0 = m_left * x0 + b_left
-    v_left = np.array([-1, -m_left])
-    v_right = np.array([1, m_right])
-    u_left = v_left / np.linalg.norm(v_left)
-    u_right = v_right / np.linalg.norm(v_right)
-    opening_angle = np.arccos(np.clip(np.dot(u_left, u_right), -1.0, 1.0))
-    bisector = u_left + u_right
-    bisector = bisector / np.linalg.norm(bisector)
-    return {"apex": (x0, y0), "opening_angle": opening_angle, "direction_vector": bisector}
+    apex_x = (b_right - b_left) / (m_left - m_right)
+    apex = (apex_x, m_left * apex_x + b_left)
+    # unit vectors along the two edges, away from the apex into the fan (left edge: towards -x, right edge: towards +x)
+    edge_l, edge_r = _unit(np.array([-1, -m_left])), _unit(np.array([1, m_right]))
+    spread = np.arccos(np.clip(np.dot(edge_l, edge_r), -1.0, 1.0))
+    return {"apex": apex, "opening_angle": spread, "direction_vector": _unit(edge_l + edge_r)}
 
 
 def cone_us_to_mri_world(apex_us_vox, direction_vec_us_2d, US_affine, T1_affine):
-    """US-voxel apex and in-plane direction -> MRI voxel apex and unit in-plane direction
-    (reference src/cone.py:187-209)."""
-    apex_t1_vox = world_to_voxel(voxel_to_world(apex_us_vox, US_affine), T1_affine)
-    direction_vec_3d = np.append(direction_vec_us_2d, 0)
-    direction_vec_t1 = T1_affine[:3, :3] @ (np.linalg.inv(US_affine[:3, :3]) @ direction_vec_3d)
-    return apex_t1_vox, direction_vec_t1[:2] / np.linalg.norm(direction_vec_t1[:2])
+    """Carry a fan from ultrasound-voxel to MRI-voxel coordinates: the apex goes through world space (both affines),
+    the in-plane direction through the linear parts only, then back to a unit 2-vector.  Same pair as reference
+    src/cone.py:187-209: (apex in MRI voxels (3,), unit direction (2,))."""
+    apex_mri = world_to_voxel(voxel_to_world(apex_us_vox, US_affine), T1_affine)
+    lin_us, lin_mri = US_affine[:3, :3], T1_affine[:3, :3]
+    heading = lin_mri @ (np.linalg.inv(lin_us) @ np.append(direction_vec_us_2d, 0))
+    return apex_mri, _unit(heading[:2])
 
 
 class FanPose(torch.nn.Module):

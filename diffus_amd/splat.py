@@ -19,11 +19,13 @@ log = logging.getLogger("diffus_amd")
 
 
 def plot_axes(x, y, z):
-    """The two axes with the highest variance (reference :702-707; ties keep axis order).
-    Uses .item() host syncs like the reference does."""
-    variances = [c.float().var().item() for c in (x, y, z)]
-    axis0, axis1 = sorted(range(3), key=lambda i: -variances[i])[:2]
-    return axis0, axis1
+    """The image plane = the two coordinate axes along which the samples spread most (largest variance first; equal
+    variances keep the axis order) -- the choice the reference makes at src/renderer.py:702-707.  One host sync for the
+    three variances instead of three."""
+    import numpy as np
+    spread = torch.stack([c.float().var() for c in (x, y, z)]).tolist()
+    first, second = np.argsort(-np.asarray(spread), kind="stable")[:2]
+    return int(first), int(second)
 
 
 class _SplatFn(torch.autograd.Function):
@@ -86,19 +88,13 @@ def differentiable_splat(x, y, z, intensities, H=256, W=256, sigma=2.0):
 
 
 def rotate_around_apex(x, z, apex, median):
-    """
-    Rotate points (x, z) around the apex point to align the median direction with the [0, 1]
-    vector (reference src/renderer.py:655-692; host-side geometry, plain torch like the reference).
-    x, z: 1D arrays of coordinates; apex: (x0, y0); median: (dx, dy).
-    """
-    device = x.device
-    x_shifted = x - 128
-    z_shifted = z
-    median_vec = torch.tensor(median, dtype=torch.float32, device=device)
-    median_vec = median_vec / median_vec.norm()
-    angle = torch.atan2(median_vec[0], median_vec[1])
-    cos_a, sin_a = torch.cos(angle), torch.sin(angle)
-    R = torch.stack([torch.stack([cos_a, -sin_a]), torch.stack([sin_a, cos_a])])
-    coords = torch.stack((x_shifted, z_shifted), dim=0)
-    rotated = R @ coords
-    return rotated[0] + apex[0], rotated[1] + apex[1]
+    """Turn the fan so that its median direction points along +z of the image and put its apex at `apex`: every point
+    (x - 128, z) is rotated by the angle between (0, 1) and `median`, then shifted.  Host-side geometry on the sample
+    coordinates in plain torch, with the values of reference src/renderer.py:655-692 (the 128 is the reference's too).
+    x, z: 1-D coordinate tensors; apex: (x0, z0); median: (dx, dz)."""
+    heading = torch.as_tensor(median, dtype=torch.float32, device=x.device)
+    heading = heading / heading.norm()
+    turn = torch.atan2(heading[0], heading[1])
+    c, s = torch.cos(turn), torch.sin(turn)
+    moved = torch.stack((torch.stack((c, -s)), torch.stack((s, c)))) @ torch.stack((x - 128, z))
+    return moved[0] + apex[0], moved[1] + apex[1]
