@@ -161,21 +161,36 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
     const int pose = blockIdx.x;
     if (threadIdx.x == 0) s_nan = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
+    // the two samples (steps start, start + 1) of a ray and, trilinear, their spatial gradients: mi[8] as in medinfo
+    auto sample_ray = [&](int i, float (&mi)[8]) {
         Pose ps;
         load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, (long)pose * A.R + i);
-        float zz[2];
+#pragma unroll
         for (int q = 0; q < 2; ++q) {
-            int k = A.start + q;
-            float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+            const int k = A.start + q;
+            const float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
             if (SAMPLER == DIFFUS_NEAREST) {
-                int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
-                zz[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
+                const int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
+                mi[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
+                mi[2 + 3 * q] = mi[3 + 3 * q] = mi[4 + 3 * q] = 0.f;
             } else {
-                zz[q] = tri_sample<LAYOUT, false>(A.vol, A.G, p0, p1, p2).v;
+                const TriSample sm = tri_sample<LAYOUT, true>(A.vol, A.G, p0, p1, p2);
+                mi[q] = sm.v;
+                mi[2 + 3 * q] = sm.g0; mi[3 + 3 * q] = sm.g1; mi[4 + 3 * q] = sm.g2;
             }
         }
-        float v = reflect(zz[0], zz[1]);
+    };
+    // The first ray of a thread (every ray when R <= 256) keeps its samples in registers: the thread that turns out to
+    // hold the median writes them out without a second round trip to memory.
+    float mine[8];
+    for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
+        float mi[8];
+        sample_ray(i, mi);
+        if (i == (int)threadIdx.x) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mine[q] = mi[q];
+        }
+        const float v = reflect(mi[0], mi[1]);
         vals[i] = v;
         if (v != v) atomicOr(&s_nan, 1);
     }
@@ -189,9 +204,10 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
     }
     const int target = (A.R - 1) / 2;
     for (int i = threadIdx.x; i < A.R; i += blockDim.x) {
-        float v = vals[i];
+        const float v = vals[i];
         int rank = 0;
         int j = 0;
+#pragma unroll 4
         for (; j + 4 <= A.R; j += 4) { // vals is 16-byte aligned dynamic LDS: one ds_read_b128 (a broadcast) per 4 values
             const float4 u = *reinterpret_cast<const float4 *>(vals + j);
             rank += (u.x < v) || (u.x == v && j < i);
@@ -200,30 +216,23 @@ __global__ __launch_bounds__(kBlock) void median_kernel(Args A)
             rank += (u.w < v) || (u.w == v && j + 3 < i);
         }
         for (; j < A.R; ++j) {
-            float u = vals[j];
+            const float u = vals[j];
             rank += (u < v) || (u == v && j < i);
         }
         if (rank == target) { // exactly one i satisfies this
             A.med[pose] = v;
             A.who[pose] = i;
-            // what the backward needs to route d/d median to this ray (pose_finish_block): its two samples and, for
-            // the pose gradient, their spatial gradients
-            Pose ps;
-            load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, (long)pose * A.R + i);
-            float *mi = A.medinfo + (long)pose * 8;
-            for (int q = 0; q < 2; ++q) {
-                int k = A.start + q;
-                float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
-                if (SAMPLER == DIFFUS_NEAREST) {
-                    int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
-                    mi[q] = A.vol[vox_off<LAYOUT>(A.G, i0, i1, i2)];
-                    mi[2 + 3 * q] = mi[3 + 3 * q] = mi[4 + 3 * q] = 0.f;
-                } else {
-                    TriSample sm = tri_sample<LAYOUT, true>(A.vol, A.G, p0, p1, p2);
-                    mi[q] = sm.v;
-                    mi[2 + 3 * q] = sm.g0; mi[3 + 3 * q] = sm.g1; mi[4 + 3 * q] = sm.g2;
-                }
+            // what the backward needs to route d/d median to this ray (pose_finish_block)
+            float mi[8];
+            if (i == (int)threadIdx.x) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mi[q] = mine[q];
+            } else {
+                sample_ray(i, mi);
             }
+            float *out = A.medinfo + (long)pose * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] = mi[q];
         }
     }
 }
