@@ -240,7 +240,7 @@ def find_pmc_summary(key):
             pm = json.load(open(f))
         except Exception:
             continue
-        if pm.get("workload") == key:
+        if pm.get("workload") == key and not pm.get("superseded_by"):   # before/after pairs of one round carry that key
             best = (os.path.relpath(f, ROOT), pm)          # names sort by round: the last match is the newest
     return best
 

@@ -44,7 +44,10 @@ struct MlpArgs {
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 // y = mask ? out_scale * mlp((x - shift) / div) : fill.   One wave = 64 consecutive voxels = two tiles per trip.
-__global__ __launch_bounds__(kBlock, 4) void mlp_fwd_kernel(MlpArgs A)
+#ifndef DIFFUS_MLP_FWD_WAVES // 3 waves per SIMD: 134 VGPRs, no scratch, 0.363 ms at 256^3; 4 forced 128 VGPRs + 28 B of scratch: 0.382 ms
+#define DIFFUS_MLP_FWD_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, DIFFUS_MLP_FWD_WAVES) void mlp_fwd_kernel(MlpArgs A)
 {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const float *P = A.params;
