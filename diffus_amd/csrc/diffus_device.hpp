@@ -324,10 +324,16 @@ __device__ __forceinline__ int nearest_index(float p, int dim)
 //              and neighbouring steps/rays land in the same line.
 constexpr int kBrickFloats = 32;
 
-//   PAIRED:    (volume only) 4x4 columns x ONE depth z, each voxel stored as the float2
-//              (v[z], v[min(z+1, d2-1)]): every trilinear column is one aligned 8-byte load whatever
-//              the parity of z, and a fan sheet uses all 128 bytes of each line it touches.  Twice
-//              the memory of the volume; the gradient of a PAIRED volume is BRICKED.
+//   PAIRED:    (volume only) one record per (4 x 4 column block, depth z): 4 rows of dim 0 x FIVE columns of dim 1
+//              x the float2 (v[z], v[min(z+1, d2-1)]) = 40 floats = 160 bytes.  The fifth column repeats the first
+//              column of the next block (clamped at the volume's edge), so the two dim-1 neighbours of ANY sample are
+//              adjacent: one trilinear sample = TWO 16-byte loads (row x0, row x1), each
+//              (v[y0][z0], v[y0][z1], v[y1][z0], v[y1][z1]) with y1 = min(y0+1, d1-1), z1 = min(z0+1, d2-1) --
+//              against 8 dword loads canonically and 4 eight-byte loads without the extra column.  The gather
+//              runs at the texture addresser's rate, 16 cycles per wave-load whatever it fetches
+//              (tools/lds_stage_probe.hip: 13.6 -> 9.9 us for the 4.19 M samples of config 3).  2.5x the
+//              memory of the volume; the gradient of a PAIRED volume is BRICKED.
+constexpr int kPairFloats = 40;
 } // namespace
 namespace diffus { // types that cross translation units need linkage
 struct Geom {
@@ -356,7 +362,7 @@ __device__ __forceinline__ unsigned vox_off(const Geom &G, int x, int y, int z)
         return ((unsigned)x * (unsigned)G.d1 + (unsigned)y) * (unsigned)G.d2 + (unsigned)z;
     } else if (LAYOUT == DIFFUS_PAIRED) { // index of the .x half of the pair at (x,y,z)
         unsigned col = ((unsigned)(x >> 2) * (unsigned)G.nb1 + (unsigned)(y >> 2)) * (unsigned)G.d2 + (unsigned)z;
-        return col * kBrickFloats + (unsigned)(((x & 3) << 3) | ((y & 3) << 1));
+        return col * kPairFloats + (unsigned)((x & 3) * 10 + ((y & 3) << 1));
     } else {
         unsigned brick = ((unsigned)(x >> 2) * (unsigned)G.nb1 + (unsigned)(y >> 2)) * (unsigned)G.nb2 + (unsigned)(z >> 1);
         return brick * kBrickFloats + (unsigned)(((x & 3) << 3) | ((y & 3) << 1) | (z & 1));
@@ -619,6 +625,7 @@ template <int LAYOUT>
 __device__ __forceinline__ unsigned part_x(const Geom &G, int x)
 {
     if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)x * G.sxB;
+    if (LAYOUT == DIFFUS_PAIRED) return __umul24((unsigned)x >> 2, G.sxB) + __umul24((unsigned)x & 3u, 40u); // 5 columns x 8 B per row
     return __umul24((unsigned)x >> 2, G.sxB) + (((unsigned)x & 3u) << 5);
 }
 template <int LAYOUT>
@@ -631,7 +638,7 @@ template <int LAYOUT>
 __device__ __forceinline__ unsigned part_z(int z)
 {
     if (LAYOUT == DIFFUS_CANONICAL) return (unsigned)z << 2;
-    if (LAYOUT == DIFFUS_PAIRED) return (unsigned)z << 7;
+    if (LAYOUT == DIFFUS_PAIRED) return __umul24((unsigned)z, (unsigned)kPairFloats * 4u); // one 160-byte record per depth
     return (((unsigned)z >> 1) << 7) | (((unsigned)z & 1u) << 2);
 }
 
@@ -675,6 +682,13 @@ __device__ __forceinline__ float2 ldb_f32x2(const float *base, unsigned byte_off
 {
     return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
 }
+struct __attribute__((aligned(8))) F4a8 { // a float4 that is only 8-byte aligned (a PAIRED row at an odd column)
+    float x, y, z, w;
+};
+__device__ __forceinline__ F4a8 ldb_f32x4(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const F4a8 *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
+}
 
 #ifndef DIFFUS_GATHER_GROUP
 #define DIFFUS_GATHER_GROUP 8
@@ -717,21 +731,20 @@ __device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, in
                 const unsigned x0 = part_x<LAYOUT>(A.G, a.i0), x1 = part_x<LAYOUT>(A.G, a.i1);
                 const unsigned y0 = part_y<LAYOUT>(A.G, b.i0), y1 = part_y<LAYOUT>(A.G, b.i1);
                 const unsigned z0 = part_z<LAYOUT>(c.i0);
-                if constexpr (LAYOUT == DIFFUS_PAIRED) { // 4 aligned 8-byte loads: (z0, z0+1) of each column
+                if constexpr (LAYOUT == DIFFUS_PAIRED) { // TWO 16-byte loads: rows x0 and x1, each (y0, y1) x (z0, z1)
 #ifdef DIFFUS_ABLATE_LOADS // timing probe (tools/): the addresses are computed, nothing is loaded
-                    float2 q00 = make_float2(__uint_as_float(x0 + y0 + z0), 1.f), q01 = make_float2(__uint_as_float(x0 + y1 + z0), 1.f);
-                    float2 q10 = make_float2(__uint_as_float(x1 + y0 + z0), 1.f), q11 = make_float2(__uint_as_float(x1 + y1 + z0), 1.f);
+                    F4a8 q0{__uint_as_float(x0 + y0 + z0), 1.f, __uint_as_float(y1), 1.f}, q1{__uint_as_float(x1 + y0 + z0), 1.f, 1.f, 1.f};
 #else
-                    // (Tried: skipping the columns whose weight is 0 for all 64 lanes -- rays that have left the volume --
-                    // behind wave-uniform branches: 1/3 fewer wave-loads at config 3, but hipcc then waits for the
-                    // loads at every branch merge: forward 19.9 -> 24.1 us.  The four loads stay unconditional.)
-                    float2 q00 = ldb_f32x2(vol, x0 + y0 + z0);
-                    float2 q01 = ldb_f32x2(vol, x0 + y1 + z0);
-                    float2 q10 = ldb_f32x2(vol, x1 + y0 + z0);
-                    float2 q11 = ldb_f32x2(vol, x1 + y1 + z0);
+                    // (Tried: skipping loads whose weight is 0 for all 64 lanes -- rays that have left the volume --
+                    // behind wave-uniform branches, and fetching the second column by an exec-masked extra load
+                    // instead of storing it twice: hipcc then waits for the loads at every branch merge, 19.9 -> 24.1
+                    // and 13.6 -> 21.2 us.  The loads stay unconditional.)
+                    const F4a8 q0 = ldb_f32x4(vol, x0 + y0 + z0);
+                    const F4a8 q1 = ldb_f32x4(vol, x1 + y0 + z0);
+                    (void)y1;
 #endif
-                    raw[jj][0] = q00.x; raw[jj][1] = q00.y; raw[jj][2] = q01.x; raw[jj][3] = q01.y;
-                    raw[jj][4] = q10.x; raw[jj][5] = q10.y; raw[jj][6] = q11.x; raw[jj][7] = q11.y;
+                    raw[jj][0] = q0.x; raw[jj][1] = q0.y; raw[jj][2] = q0.z; raw[jj][3] = q0.w;
+                    raw[jj][4] = q1.x; raw[jj][5] = q1.y; raw[jj][6] = q1.z; raw[jj][7] = q1.w;
                 } else {
                     const unsigned z1 = part_z<LAYOUT>(c.i1);
                     const unsigned c00 = x0 + y0, c01 = x0 + y1, c10 = x1 + y0, c11 = x1 + y1;

@@ -15,12 +15,12 @@ size_t stride_x_bytes(int layout, int d1, int d2)
 {
     const size_t nb1 = (size_t)(d1 + 3) / 4, nb2 = (size_t)(d2 + 1) / 2;
     if (layout == DIFFUS_CANONICAL) return (size_t)d1 * d2 * 4;
-    return layout == DIFFUS_PAIRED ? nb1 * d2 * 128 : nb1 * nb2 * 128;
+    return layout == DIFFUS_PAIRED ? nb1 * d2 * (kPairFloats * 4) : nb1 * nb2 * 128;
 }
 size_t stride_y_bytes(int layout, int d2)
 {
     if (layout == DIFFUS_CANONICAL) return (size_t)d2 * 4;
-    return layout == DIFFUS_PAIRED ? (size_t)d2 * 128 : (size_t)((d2 + 1) / 2) * 128;
+    return layout == DIFFUS_PAIRED ? (size_t)d2 * (kPairFloats * 4) : (size_t)((d2 + 1) / 2) * 128;
 }
 
 Geom make_geom(int d0, int d1, int d2, int layout = DIFFUS_CANONICAL)
@@ -43,7 +43,7 @@ size_t bricked_floats(int d0, int d1, int d2)
 size_t paired_floats(int d0, int d1, int d2)
 {
     Geom G = make_geom(d0, d1, d2);
-    return (size_t)((d0 + 3) / 4) * G.nb1 * d2 * kBrickFloats;
+    return (size_t)((d0 + 3) / 4) * G.nb1 * d2 * kPairFloats;
 }
 
 struct Workspace {

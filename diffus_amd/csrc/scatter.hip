@@ -526,24 +526,25 @@ __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict
     }
 }
 
-// canonical -> PAIRED: a block writes 4 x 4 columns x 32 depths (4 KiB contiguous) from 16 canonical
-// rows of 33 floats, through LDS.
+// canonical -> PAIRED: a block writes the records of one 4 x 4 column block for 32 depths (32 x 160 B contiguous) from
+// 4 x 5 canonical rows of 33 floats (the fifth column and the 33rd depth are the neighbours the records repeat,
+// clamped at the volume's edge), through LDS so that both sides are coalesced.
 __global__ __launch_bounds__(kBlock) void pair_convert_kernel(const float *__restrict__ in, float *__restrict__ out, Geom G)
 {
-    __shared__ float t[16][34];
+    __shared__ float t[20][34];
     const int z0 = blockIdx.x * 32;
     const int by = blockIdx.y, bx = blockIdx.z;
     const int tid = threadIdx.x;
-    for (int e = tid; e < 16 * 33; e += kBlock) {
-        int row = e / 33, zz = e - row * 33;
-        int x = min(bx * 4 + (row >> 2), G.d0 - 1), y = min(by * 4 + (row & 3), G.d1 - 1), z = min(z0 + zz, G.d2 - 1);
+    for (int e = tid; e < 20 * 33; e += kBlock) {
+        int row = e / 33, zz = e - row * 33; // row = (x & 3) * 5 + column 0..4
+        int x = min(bx * 4 + row / 5, G.d0 - 1), y = min(by * 4 + row % 5, G.d1 - 1), z = min(z0 + zz, G.d2 - 1);
         t[row][zz] = in[((long)x * G.d1 + y) * G.d2 + z];
     }
     __syncthreads();
     const long col0 = ((long)bx * G.nb1 + by) * G.d2 + z0;
-    for (int e = tid; e < 32 * kBrickFloats; e += kBlock) {
-        int zz = e >> 5, off = e & 31;
-        if (z0 + zz < G.d2) out[(col0 + zz) * kBrickFloats + off] = t[off >> 1][zz + (off & 1)];
+    for (int e = tid; e < 32 * kPairFloats; e += kBlock) {
+        int zz = e / kPairFloats, off = e - zz * kPairFloats; // off = ((x & 3) * 5 + column) * 2 + (0: z, 1: z + 1)
+        if (z0 + zz < G.d2) out[(col0 + zz) * kPairFloats + off] = t[off >> 1][zz + (off & 1)];
     }
 }
 

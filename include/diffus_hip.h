@@ -60,9 +60,11 @@ extern "C" {
 #define DIFFUS_CANONICAL 0 /* the caller's (d0,d1,d2) row-major tensor */
 #define DIFFUS_BRICKED   1 /* 4x4x2-voxel bricks of 32 floats (one 128-B line), row-major over
                               (ceil(d0/4), ceil(d1/4), ceil(d2/2)); made by diffus_brick_volume */
-#define DIFFUS_PAIRED    2 /* volume only: 4x4 columns x one depth z per 128-B line, each voxel stored as
-                              the pair (v[z], v[min(z+1,d2-1)]); made by diffus_pair_volume; twice the
-                              memory; the gradient that goes with it (gvol) is DIFFUS_BRICKED */
+#define DIFFUS_PAIRED    2 /* volume only: one 160-B record per (4x4 column block, depth z): 4 rows of dim 0 x 5
+                              columns of dim 1 (the fifth repeats the next block's first, clamped at the edge) x
+                              the pair (v[z], v[min(z+1,d2-1)]), so that a trilinear sample is two 16-byte loads;
+                              made by diffus_pair_volume; 2.5x the memory; the gradient that goes with it (gvol)
+                              is DIFFUS_BRICKED */
 
 /* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples, at most 16, so one launch
  * covers 1024 cropped samples.  Longer rays (N1 = S - start up to MAX_SAMPLES * MAX_SEGMENTS) are processed
@@ -90,7 +92,7 @@ size_t diffus_workspace_zbar_offset(int P, int R, int S, int start);
  * constant dim 2 (src/cone.py:258) -- the worst case for that layout.  The
  * kernels therefore also accept a bricked copy (DIFFUS_BRICKED).  These two calls
  * convert; both are coalesced streaming passes over the volume.
- *   diffus_paired_floats   number of floats of the paired buffer (about 2*d0*d1*d2)
+ *   diffus_paired_floats   number of floats of the paired buffer (about 2.5*d0*d1*d2)
  *   diffus_pair_volume     canonical -> paired
  *   diffus_bricked_floats  number of floats of the bricked buffer (>= d0*d1*d2)
  *   diffus_brick_volume    canonical -> bricked (padding voxels are written as 0)

@@ -258,6 +258,52 @@ __global__ __launch_bounds__(256) void k_patch_direct(const float *__restrict__ 
     *reinterpret_cast<float4 *>(&out[(size_t)w * S + n0]) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- E: direct gather with 16-byte ROW loads: (x, y0) and (x, y0 + 1) are adjacent 8-byte entries of a line unless
+// y0 & 3 == 3; those lanes (a quarter) fetch the second column with an extra, exec-masked 8-byte load.  Is a masked
+// load cheaper for the texture addresser than a full one?
+__device__ __forceinline__ float4 ldg4(const float *b, unsigned off)
+{
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(b) + (size_t)off);
+}
+template <bool FIX>
+__global__ __launch_bounds__(256) void k_row16(const float *__restrict__ vol, const float *__restrict__ src,
+                                               const float *__restrict__ dirs, float *__restrict__ out)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pose = w / R;
+    const float s0 = src[pose * 3], s1 = src[pose * 3 + 1], s2 = src[pose * 3 + 2];
+    const float d0 = dirs[w * 3], d1 = dirs[w * 3 + 1];
+    const Ax c = axis(s2, N);
+    const unsigned zoff = (unsigned)c.i0 << 7;
+    float v[S / 64];
+    float4 qa[S / 64], qb[S / 64];
+    float2 fa[S / 64], fb[S / 64];
+    Ax aa[S / 64], bb[S / 64];
+#pragma unroll
+    for (int j = 0; j < S / 64; ++j) {
+        const float kf = (float)(j * 64 + lane);
+        const Ax a = axis(s0 + kf * d0, N), b = axis(s1 + kf * d1, N);
+        aa[j] = a; bb[j] = b;
+        const unsigned x0 = px(a.i0), x1 = px(a.i1), y0 = py(b.i0) + zoff, y1 = py(b.i1) + zoff;
+        qa[j] = ldg4(vol, x0 + y0);
+        qb[j] = ldg4(vol, x1 + y0);
+        fa[j] = make_float2(0.f, 0.f); fb[j] = fa[j];
+        if (FIX && ((b.i0 & 3) == 3)) {
+            fa[j] = ldg2(vol, x0 + y1);
+            fb[j] = ldg2(vol, x1 + y1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < S / 64; ++j) {
+        const bool fix = FIX && ((bb[j].i0 & 3) == 3);
+        const float2 q00 = make_float2(qa[j].x, qa[j].y), q10 = make_float2(qb[j].x, qb[j].y);
+        const float2 q01 = fix ? fa[j] : make_float2(qa[j].z, qa[j].w), q11 = fix ? fb[j] : make_float2(qb[j].z, qb[j].w);
+        v[j] = lerp3(q00, q01, q10, q11, aa[j].t, bb[j].t, c.t);
+    }
+#pragma unroll
+    for (int j = 0; j < S / 64; ++j) out[(size_t)w * S + j * 64 + lane] = v[j];
+}
+
 template <typename F>
 static float time_us(F &&launch, int iters = 50)
 {
@@ -306,7 +352,7 @@ int main()
     float *vol, *src, *dirs, *oa, *ob;
     int *fb;
     const size_t nout = (size_t)P * R * S;
-    CHECK(hipMalloc(&vol, hv.size() * 4)); CHECK(hipMalloc(&src, hs.size() * 4)); CHECK(hipMalloc(&dirs, hd.size() * 4));
+    CHECK(hipMalloc(&vol, hv.size() * 4 + 64 /* E/F read 8 bytes past a line's last entry */)); CHECK(hipMalloc(&src, hs.size() * 4)); CHECK(hipMalloc(&dirs, hd.size() * 4));
     CHECK(hipMalloc(&oa, nout * 4)); CHECK(hipMalloc(&ob, nout * 4)); CHECK(hipMalloc(&fb, 4));
     CHECK(hipMemcpy(vol, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(src, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
@@ -343,5 +389,10 @@ int main()
     t = time_us([&] { hipLaunchKernelGGL(k_patch_direct, dim3(nb_patch), dim3(256), 0, 0, vol, src, dirs, ob); });
     printf("D patch mapping, direct gathers       %7.1f us\n", t);
     same("D");
+    t = time_us([&] { hipLaunchKernelGGL(k_row16<true>, dim3(nb_ray), dim3(256), 0, 0, vol, src, dirs, ob); });
+    printf("E 16-byte row loads + masked fix-ups  %7.1f us\n", t);
+    same("E");
+    t = time_us([&] { hipLaunchKernelGGL(k_row16<false>, dim3(nb_ray), dim3(256), 0, 0, vol, src, dirs, ob); });
+    printf("F 16-byte row loads only (wrong at y0 & 3 == 3: the floor of E)  %7.1f us\n", t);
     return 0;
 }
