@@ -616,6 +616,55 @@ __device__ __forceinline__ void to_interleaved(float *wb, int lane, const float 
     wave_lds_sync();
 }
 
+// ---- a lane's C consecutive samples of a row, straight from / to memory (CHUNKED mapping, no LDS transpose) ------
+// The texture addresser takes 16 cycles per wave-instruction whatever it moves: 8 dword accesses in the INTERLEAVED
+// mapping (256-B runs) cost four times the 2 sixteen-byte ones of the CHUNKED mapping (a lane's 32 contiguous bytes, a
+// wave's 2 KiB), and the transpose through LDS goes away with them.  Rows start at any float (N1 need not be a
+// multiple of 4), so the accesses are declared dword-aligned; lanes whose chunk straddles the end of the row go
+// element by element.
+struct __attribute__((aligned(4))) F4a4 {
+    float x, y, z, w;
+};
+struct __attribute__((aligned(4))) F2a4 {
+    float x, y;
+};
+template <int C>
+__device__ __forceinline__ void store_chunk(float *__restrict__ row, int n0, int segN, const float (&v)[C])
+{
+    if (n0 + C <= segN) {
+        if constexpr (C >= 4) {
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q)
+                *reinterpret_cast<F4a4 *>(row + n0 + 4 * q) = F4a4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        } else {
+            *reinterpret_cast<F2a4 *>(row + n0) = F2a4{v[0], v[1]};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j)
+            if (n0 + j < segN) row[n0 + j] = v[j];
+    }
+}
+template <int C>
+__device__ __forceinline__ void load_chunk(const float *__restrict__ row, int n0, int segN, float (&v)[C])
+{
+    if (n0 + C <= segN) {
+        if constexpr (C >= 4) {
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q) {
+                const F4a4 t = *reinterpret_cast<const F4a4 *>(row + n0 + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+        } else {
+            const F2a4 t = *reinterpret_cast<const F2a4 *>(row + n0);
+            v[0] = t.x; v[1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) v[j] = (n0 + j < segN) ? row[n0 + j] : 0.f;
+    }
+}
+
 // Byte offset of voxel (x,y,z) as three separable parts: off = part_x(x) + part_y(y) + part_z(z).  A trilinear
 // sample needs part_x and part_y for two coordinates each and sums them with v_add3_u32 -- 4 x (shift, 24-bit
 // multiply, and, shift-add) instead of the 4 x (two multiplies, one of them the quarter-rate v_mul_lo_u32, and ~8

@@ -74,14 +74,11 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     }
     to_chunked<C>(wb, lane, zi, z);
     {
-        // upstream gradient row, read as 256-B runs, attenuation folded in
-        const float *gin = A.gframe + w * A.N1 + seg0;
+        // upstream gradient row straight into the CHUNKED mapping (two 16-byte loads per lane, no transpose);
+        // attenuation folded in
+        load_chunk<C>(A.gframe + w * A.N1 + seg0, n0, segN, gb);
 #pragma unroll
-        for (int j = 0; j < C; ++j) {
-            int n = j * kWave + lane;
-            zi[j] = (n < segN) ? gin[n] * fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n)) : 0.f;
-        }
-        to_chunked<C>(wb, lane, zi, gb);
+        for (int j = 0; j < C; ++j) gb[j] *= fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
     }
     float zprev = lane_prev(z[C - 1], z[C - 1]);
     if (SPLIT > 1) { // the second half's first coefficient couples to the first half's last sample
@@ -297,36 +294,38 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     // this ray's share of d/d median: sample 1 lives in lane 0 (C >= 2) of the first segment
     if (A.start > 0 && seg0 == 0 && lane == 0) A.gmed[w] = gmed_lane;
 
-    // ---- back to INTERLEAVED: hand zbar to the scatter kernel, reduce the pose gradient ----
+    // ---- hand zbar to the scatter kernel, reduce the pose gradient: both from the CHUNKED mapping ----
     // The volume scatter is a separate launch (scatter_patch_kernel): its thread <-> sample
     // mapping is chosen for LDS privatisation, not for the scan.
-    to_interleaved<C>(wb, lane, zbar, zi);
-    if (A.zbar) {
-        float *zo = A.zbar + w * A.N1 + seg0;
-#pragma unroll
-        for (int j = 0; j < C; ++j) {
-            int n = j * kWave + lane;
-            if (n < segN) zo[n] = zi[j];
-        }
-    }
+    if (A.zbar) store_chunk<C>(A.zbar + w * A.N1 + seg0, n0, segN, zbar);
     if (GPOSE) {
         float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
+        // the spatial gradients parked in LDS by the gather: component c of sample n sits at gst[c * 64 C + n], so
+        // a lane's C consecutive samples are contiguous there (ds_read_b128)
+        float q0[C], q1[C], q2[C];
+        if (KEEP_GRAD) {
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                q0[j] = gst[0 * C * kWave + n0 + j]; q1[j] = gst[1 * C * kWave + n0 + j]; q2[j] = gst[2 * C * kWave + n0 + j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            int n = j * kWave + lane;
-            float zb = zi[j];
+            const int n = n0 + j;
+            const float zb = zbar[j];
             if (n < segN && zb != 0.f) {
-                int k = A.start + seg0 + n;
-                float q0, q1, q2;
+                const int k = A.start + seg0 + n;
+                float g0, g1, g2;
                 if (KEEP_GRAD) {
-                    q0 = gst[(0 * C + j) * kWave + lane]; q1 = gst[(1 * C + j) * kWave + lane]; q2 = gst[(2 * C + j) * kWave + lane];
+                    g0 = q0[j]; g1 = q1[j]; g2 = q2[j];
                 } else {
-                    TriSample s = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point<PM>(ps, 0, k), ray_point<PM>(ps, 1, k),
-                                                           ray_point<PM>(ps, 2, k));
-                    q0 = s.g0; q1 = s.g1; q2 = s.g2;
+                    TriSample sm = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point<PM>(ps, 0, k), ray_point<PM>(ps, 1, k),
+                                                            ray_point<PM>(ps, 2, k));
+                    g0 = sm.g0; g1 = sm.g1; g2 = sm.g2;
                 }
-                float kf = (float)k;
-                float a0 = zb * q0, a1 = zb * q1, a2 = zb * q2;
+                const float kf = (float)k;
+                const float a0 = zb * g0, a1 = zb * g1, a2 = zb * g2;
                 gs0 += a0; gs1 += a1; gs2 += a2;
                 gd0 = __builtin_fmaf(kf, a0, gd0);
                 gd1 = __builtin_fmaf(kf, a1, gd1);

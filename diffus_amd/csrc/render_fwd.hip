@@ -113,25 +113,17 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
         float att = fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
         e[j] = __fmul_rn(e[j], att);
     }
-#ifdef DIFFUS_ABLATE_TRANSPOSE
-#pragma unroll
-    for (int j = 0; j < C; ++j) zi[j] = e[j];
-#else
-    to_interleaved<C>(wb, lane, e, zi);
-#endif
     STAMPW(5);
+    // the frame row leaves from the CHUNKED mapping: two 16-byte stores per lane (a wave's 2 KiB contiguous) instead of
+    // an LDS transpose and eight dword stores
     float *out = A.frame + w * A.N1 + seg0;
 #ifdef DIFFUS_ABLATE_STORE
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < C; ++j) acc += zi[j];
+    for (int j = 0; j < C; ++j) acc += e[j];
     if (acc == 123.456f) out[lane] = acc;
 #else
-#pragma unroll
-    for (int j = 0; j < C; ++j) {
-        int n = j * kWave + lane;
-        if (n < segN) out[n] = zi[j];
-    }
+    store_chunk<C>(out, n0, segN, e);
 #endif
 
     STAMPW(6);
