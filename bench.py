@@ -13,8 +13,10 @@ process is one of them.  Rank 0 prints the one JSON line.
 Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays x
 512 steps.  One *step* = one pass of the hot path over one batch of poses:
   forward frame (diffus_render_fwd)
-  -> loss_p = sum(frame_p^2), dL/dframe = 2 frame (diffus_loss_sumsq)
-  -> backward (diffus_render_bwd: d/d volume, d/d source, d/d directions)
+  -> loss_p = sum(frame_p^2) and the backward of it (diffus_render_bwd_mse: dL/dframe = 2 frame is formed from the
+     frame while the adjoint scan loads the row, the per-pose loss is summed by the call's closing blocks;
+     --unfused-loss runs the separate loss kernel diffus_loss_sumsq + diffus_render_bwd instead):
+     d/d volume, d/d source, d/d directions
   -> touched bricks of the gradient scratch -> the caller's canonical (d0,d1,d2) volume-gradient tensor
      (diffus_gradbuf_flush, mode PERSISTENT: the tensor is kept across steps and bricks the previous step
      wrote but this one does not are cleared, so after every step it IS that step's dense gradient -- the
@@ -86,6 +88,8 @@ def parse_args(argv=None):
                          "(diffus_gradbuf_flush mode STORE instead of PERSISTENT)")
     ap.add_argument("--dense-grad", action="store_true",
                     help="hand the gradient back by a dense conversion instead of the touched-brick flush")
+    ap.add_argument("--unfused-loss", action="store_true",
+                    help="separate loss kernel (diffus_loss_sumsq) + diffus_render_bwd instead of the fused diffus_render_bwd_mse")
     ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the `callers` legs (demo shape, learnable volume, moving poses)")
@@ -419,7 +423,7 @@ def worker(args):
     def make_step(s, d, want_gvol=not args.no_gvol, learnable=args.learnable_volume):
         return CapturedStep(vol, s, d, args.samples, args.alpha, args.sampler, start=args.start, want_gvol=want_gvol,
                             layout=args.layout, sparse=not args.dense_grad, persistent=not args.memset_grad,
-                            learnable_volume=learnable)
+                            learnable_volume=learnable, fused_loss=not args.unfused_loss)
 
     hp = make_step(src, dirs)
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
@@ -601,6 +605,8 @@ def worker(args):
                              f"{args.rays} rays x {args.samples} steps through a {args.n}^3 analytic head phantom; "
                              f"{args.sampler} sampling; forward + sum-of-squares loss + backward ({grads}) "
                              f"+ canonical gradient + per-pose loss gather"),
+                "loss": ("separate kernel (diffus_loss_sumsq)" if args.unfused_loss else
+                         "fused: dL/dframe formed inside the backward, per-pose loss summed by its closing blocks (diffus_render_bwd_mse)"),
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": args.start, "alpha": args.alpha,
                 "layout": args.layout,

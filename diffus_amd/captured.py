@@ -99,7 +99,8 @@ class CapturedStep:
     def __init__(self, volume: torch.Tensor, sources: torch.Tensor, directions: torch.Tensor, num_samples: int,
                  attenuation_coeff: float, sampler: str = "trilinear", start: int = 0, want_gvol: bool = True,
                  layout: str = "paired", sparse: bool = True, persistent: bool = True,
-                 learnable_volume: bool = False, alias_grads: bool = False):
+                 learnable_volume: bool = False, alias_grads: bool = False, fused_loss: bool = True,
+                 target: Optional[torch.Tensor] = None, loss_scale: float = 1.0):
         if not volume.is_cuda:
             raise _lib.DiffusError("CapturedStep needs a HIP-resident volume; there is no CPU fallback")
         if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous():
@@ -124,6 +125,12 @@ class CapturedStep:
         self.alias_grads = bool(alias_grads)
         self._src_shape = tuple(sources.shape)
         self._stamp = 0
+        # step(): loss_p = loss_scale * sum((frame_p - target_p)^2) (target None: the frame's energy).  fused_loss: the
+        # backward forms dL/dframe from the frame on the fly and its closing per-pose blocks sum the loss
+        # (diffus_render_bwd_mse) -- no loss kernel, no gradient-of-frame buffer traffic
+        self.fused_loss = bool(fused_loss)
+        self.target = target
+        self.loss_scale = float(loss_scale)
         self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
         self.gframe = torch.empty_like(self.frame)
         d0, d1, d2 = (int(x) for x in volume.shape)
@@ -188,8 +195,15 @@ class CapturedStep:
                                               _vp(self.gsrc), _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(),
                                               self.stream()), "diffus_render_bwd")
 
+    def bwd_mse(self, stages=_lib.BWD_ALL):
+        """Backward of loss_p = loss_scale * sum((frame_p - target_p)^2), straight from `self.frame`; `self.loss` gets loss_p."""
+        _lib.check(self.lib.diffus_render_bwd_mse(*self.common, _vp(self.frame), _vp(self.target), self.loss_scale,
+                                                  _vp(self.loss), _vp(self.gvol_k), _vp(self.touched), _vp(self.gsrc),
+                                                  _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(), self.stream()),
+                   "diffus_render_bwd_mse")
+
     def loss_and_grad(self):
-        """loss_p = sum(frame_p^2), dL/dframe = 2 frame (one launch)."""
+        """loss_p = sum(frame_p^2), dL/dframe = 2 frame (one launch; the unfused form of step()'s loss)."""
         _lib.check(self.lib.diffus_loss_sumsq(_vp(self.frame), self.P, self.R * self.N1, _vp(self.loss),
                                               _vp(self.gframe), _vp(self.loss_ws), self.loss_ws.numel(), self.stream()),
                    "diffus_loss_sumsq")
@@ -228,8 +242,15 @@ class CapturedStep:
         # (a forked stream for zero_grad beside the forward was measured: the fork/join events cost
         # more than the 10 us they hide -- 0.217 vs 0.202 ms/step -- so the step stays on one stream)
         self.forward()
-        self.loss_and_grad()
-        self.backward()
+        if self.fused_loss:
+            self.zero_grad()
+            self.bwd_mse(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self.start > 0 else 0))
+            self.finish_grad()
+        else:
+            if self.target is not None or self.loss_scale != 1.0:
+                raise _lib.DiffusError("the unfused step() implements the sum-of-squares loss only (no target, scale 1)")
+            self.loss_and_grad()
+            self.backward()
 
     # -- hipGraph -------------------------------------------------------------------------------------------------
     def capture(self, what: str = "step", warmup: int = 2):

@@ -507,6 +507,13 @@ struct Args {
     long long *idx;
     // backward
     const float *gframe;
+    // fused loss (diffus_render_bwd_mse): L_p = loss_scale * sum((frame_p - target_p)^2); the backward then takes
+    // dL/dframe = 2 loss_scale (frame - target) on the fly from `gframe` (= the forward's frame) and `target`
+    const float *target;  // nullable: zeros
+    float loss_scale;
+    int mse;              // 0: gframe is dL/dframe; 1: gframe is the frame
+    float *loss_part;     // (P,R,2) per-ray sums of squares (two slots: the two waves of a SPLIT ray)
+    float *loss_out;      // nullable (P): pose_finish_block sums loss_part into it
     float *gvol;      // layout that goes with vol's (GradLayout)
     int *gtouched;    // nullable: one flag per gradient brick, set when a launch adds into it (bricked only)
     float *zbar;      // (P,R,N1) d L / d imp per sample, consumed by scatter_patch_kernel
@@ -1075,6 +1082,19 @@ __device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float
     }
     __syncthreads();
     if (A.gsrc_out) reduce_gsrc_block(A.gsrc_part, A.gsrc_out, A.R, pose, sm, s_extra[0], s_extra[1], s_extra[2]);
+    if (A.loss_out) { // fused loss: fixed-order sum of the rays' partial sums (deterministic)
+        __syncthreads();
+        float a = 0.f;
+        if (threadIdx.x < kBlock)
+            for (int i = threadIdx.x; i < 2 * A.R; i += kBlock) a += A.loss_part[(long)pose * 2 * A.R + i];
+        if (threadIdx.x < kBlock) sm[threadIdx.x] = a;
+        __syncthreads();
+        for (int s = kBlock / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) A.loss_out[pose] = sm[0];
+    }
 }
 
 } // namespace

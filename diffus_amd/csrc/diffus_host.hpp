@@ -51,6 +51,7 @@ struct Workspace {
     int *who;
     float *gmed;
     float *medinfo;
+    float *loss_part; // (P,R,2) fused-loss partial sums
     float *gsrc_part;
     float *zbar;
     float *carry;  // (nseg-1, P*R, 5) per-segment carry-in of long rays
@@ -69,6 +70,7 @@ Workspace carve(void *base, int P, int R, int N1)
     ws.who = (int *)(p + o);   o += align256(sizeof(int) * (size_t)P);
     ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R);
     ws.medinfo = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * 8);
+    ws.loss_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 2);
     ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
     ws.zbar = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * (N1 > 0 ? N1 : 0));
     ws.nseg = N1 > 0 ? (N1 + DIFFUS_MAX_SAMPLES - 1) / DIFFUS_MAX_SAMPLES : 1;

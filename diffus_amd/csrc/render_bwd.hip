@@ -77,6 +77,29 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         // upstream gradient row straight into the CHUNKED mapping (two 16-byte loads per lane, no transpose);
         // attenuation folded in
         load_chunk<C>(A.gframe + w * A.N1 + seg0, n0, segN, gb);
+        if (A.mse) { // fused loss: `gframe` is the forward's frame; dL/dframe = 2 s (frame - target), L += s (frame - target)^2
+            float tg[C];
+            if (A.target) {
+                load_chunk<C>(A.target + w * A.N1 + seg0, n0, segN, tg);
+            } else {
+#pragma unroll
+                for (int j = 0; j < C; ++j) tg[j] = 0.f;
+            }
+            float ssq = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const float dlt = gb[j] - tg[j]; // both 0 past the end of the row
+                ssq = __builtin_fmaf(dlt, dlt, ssq);
+                gb[j] = (2.f * A.loss_scale) * dlt;
+            }
+            ssq = wave_sum_to_lane63(ssq);
+            if (lane == kWave - 1) {
+                float *lp = A.loss_part + w * 2 + part;
+                const float v = A.loss_scale * ssq;
+                *lp = (SEG && A.accum_pose) ? *lp + v : v; // later-processed segments of a long ray add up
+                if (SPLIT == 1 && !(SEG && A.accum_pose)) lp[1] = 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < C; ++j) gb[j] *= fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
     }
@@ -413,20 +436,18 @@ int launch_bwd(const Args &A, int sampler, int layout, bool pose, hipStream_t st
     });
 }
 
-} // namespace
-
-extern "C" {
-
-int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
-                      const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
-                      const float *gframe, float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
-                      void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+// diffus_render_bwd (mse = false: `gframe` is dL/dframe) and diffus_render_bwd_mse (mse = true: `gframe` is the frame)
+int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                    const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                    const float *gframe, bool mse, const float *target, float loss_scale, float *loss,
+                    float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
+                    void *workspace, size_t workspace_bytes, diffus_stream_t stream)
 {
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
     if (!gframe) return DIFFUS_EINVAL;
     if (stages < 1 || stages > (DIFFUS_BWD_ALL | DIFFUS_BWD_KEEP_MEDIAN) || !(stages & DIFFUS_BWD_ALL)) return DIFFUS_EINVAL;
-    if (!gvol && !gsrc && !gdirs) return DIFFUS_OK;
+    if (!gvol && !gsrc && !gdirs && !(mse && loss)) return DIFFUS_OK;
     const bool do_scan = stages & DIFFUS_BWD_SCAN, do_scatter = stages & DIFFUS_BWD_SCATTER;
     Workspace ws = carve(workspace, P, R, S - start);
     if (!workspace || workspace_bytes < ws.bytes) return DIFFUS_EWORKSPACE;
@@ -436,9 +457,14 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
         if (gsrc && hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)P * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
         if (gdirs && hipMemsetAsync(gdirs, 0, sizeof(float) * (size_t)P * R * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
     }
-    if (sampler == DIFFUS_NEAREST && !gvol) return DIFFUS_OK;
+    if (sampler == DIFFUS_NEAREST && !gvol && !(mse && loss)) return DIFFUS_OK;
     Args A = make_args(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.gframe = gframe;
+    A.mse = mse;
+    A.target = target;
+    A.loss_scale = loss_scale;
+    A.loss_part = ws.loss_part;
+    A.loss_out = (mse && do_scan) ? loss : nullptr;
     A.gvol = gvol;
     A.gtouched = (gvol && layout != DIFFUS_CANONICAL) ? gvol_touched : nullptr;
     A.zbar = gvol ? ws.zbar : nullptr;
@@ -486,7 +512,7 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
     // Per-pose epilogue (pose_finish_block): the median's gradient goes to the ray that supplied it (start > 0) and the
     // per-ray d/dsource partials are summed.  It rides along as P extra blocks of the scatter launch when that launch
     // follows in this call, else it is one launch of its own.
-    const bool finish = do_scan && (start > 0 || (pose && gsrc));
+    const bool finish = do_scan && (start > 0 || (pose && gsrc) || A.loss_out);
     A.gsrc_out = (pose && gsrc) ? gsrc : nullptr;
     A.finish_in_scatter = finish && gvol && do_scatter;
     if (gvol && do_scatter) {
@@ -503,6 +529,31 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
         if (rc) return rc;
     }
     return DIFFUS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                      const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                      const float *gframe, float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
+                      void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    return render_bwd_impl(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler, gframe,
+                           false, nullptr, 0.f, nullptr, gvol, gvol_touched, gsrc, gdirs, stages, workspace, workspace_bytes,
+                           stream);
+}
+
+int diffus_render_bwd_mse(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                          const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                          const float *frame, const float *target, float loss_scale, float *loss, float *gvol,
+                          int *gvol_touched, float *gsrc, float *gdirs, int stages, void *workspace, size_t workspace_bytes,
+                          diffus_stream_t stream)
+{
+    return render_bwd_impl(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler, frame,
+                           true, target, loss_scale, loss, gvol, gvol_touched, gsrc, gdirs, stages, workspace, workspace_bytes,
+                           stream);
 }
 
 } // extern "C"

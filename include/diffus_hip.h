@@ -194,6 +194,24 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout,
                       diffus_stream_t stream);
 
 /*
+ * The same backward for the loss  L_p = loss_scale * sum over the frame of pose p of (frame - target)^2  (target NULL:
+ * zeros, i.e. the frame's energy), fused: `frame` is what diffus_render_fwd produced, dL/dframe = 2 loss_scale
+ * (frame - target) is formed on the fly while the row is loaded, and `loss` (nullable, (P) float32, overwritten) receives
+ * L_p, summed over rays in a fixed order by the per-pose blocks that end the call.  It replaces a separate loss kernel
+ * (one more pass over the frame, a (P,R,N1) gradient buffer, one more launch) in loops whose loss has this form -- the
+ * sum of squares bench.py and the examples use, an MSE against a target frame.  Everything else as diffus_render_bwd.
+ */
+int diffus_render_bwd_mse(const float *vol, int d0, int d1, int d2, int layout,
+                          const void *src, int src_dtype,
+                          const void *dirs, int dirs_dtype,
+                          int P, int R, int S, int start, float alpha, int sampler,
+                          const float *frame, const float *target, float loss_scale, float *loss,
+                          float *gvol, int *gvol_touched, float *gsrc, float *gdirs,
+                          int stages,
+                          void *workspace, size_t workspace_bytes,
+                          diffus_stream_t stream);
+
+/*
  * Stage 1 alone: replaces UltrasoundRenderer.trace_ray / simulate_rays
  * (reference src/renderer.py:90-180, :35-71) = custom_nearest_sampler
  * (:741-759) + compute_reflection_coeff (:27-33).  Any of the outputs may be

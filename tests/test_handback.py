@@ -179,3 +179,42 @@ def test_start_crop_backward_reuses_the_forwards_median(hot, sampler):
         torch.cuda.synchronize()
         assert float((hq.gsrc - sa.grad).abs().max()) <= 1e-5 * float(sa.grad.abs().max())
         assert float((hq.gdirs - dd.grad).abs().max()) <= 1e-5 * float(dd.grad.abs().max())
+
+
+@pytest.mark.parametrize("S,start,sampler", [(512, 0, "trilinear"), (700, 30, "trilinear"), (1100, 0, "trilinear"),
+                                             (150, 37, "nearest"), (96, 0, "trilinear")])
+def test_fused_mse_backward_equals_loss_kernel_plus_backward(hot, S, start, sampler):
+    """diffus_render_bwd_mse: loss = scale * sum((frame - target)^2) per pose and its backward, formed from the frame on
+    the fly (single launch pair, per-pose loss summed by the call's closing blocks) -- against the unfused sequence
+    (torch loss on the frame, diffus_render_bwd with the explicit dL/dframe).  Covers one wave per ray, two waves per ray
+    (512 < N1 <= 1024), segmented rays (N1 > 1024) and the start crop."""
+    n, P, R, alpha = 64, 3, 20, 1e-3
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, 8, R)
+    s = torch.from_numpy(src[:P]).cuda()
+    d = (torch.from_numpy(dirs[:P]) * (0.08 if S > 600 else 1.0)).cuda().contiguous()
+    g = torch.Generator().manual_seed(S)
+    target = (torch.randn(P, R, S - start, generator=g) * 0.05).cuda()
+    for tgt, scale in ((None, 1.0), (target, 0.37)):
+        fused = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale)
+        fused.step()
+        ref = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, fused_loss=False)
+        ref.fwd()
+        diff = ref.frame if tgt is None else ref.frame - tgt
+        ref.gframe.copy_(2 * scale * diff)
+        ref.backward()
+        torch.cuda.synchronize()
+        want_loss = scale * (diff.double() ** 2).sum((1, 2))
+        assert torch.equal(fused.frame, ref.frame)
+        assert torch.allclose(fused.loss.double(), want_loss, rtol=2e-6), (fused.loss, want_loss)
+        den = float(ref.gvol.abs().max())
+        assert den > 0 and float((fused.gvol - ref.gvol).abs().max()) <= 2e-5 * den
+        if sampler == "trilinear":
+            assert float((fused.gsrc - ref.gsrc).abs().max()) <= 1e-5 * float(ref.gsrc.abs().max())
+            assert float((fused.gdirs - ref.gdirs).abs().max()) <= 1e-5 * float(ref.gdirs.abs().max())
+    # pose-gradient-only and loss-only calls
+    if sampler == "trilinear":
+        only = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, want_gvol=False)
+        only.step()
+        torch.cuda.synchronize()
+        assert torch.allclose(only.loss.double(), (only.frame.double() ** 2).sum((1, 2)), rtol=2e-6)
