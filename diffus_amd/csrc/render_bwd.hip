@@ -3,6 +3,18 @@
 
 namespace {
 
+#ifdef DIFFUS_STAMP // diagnostic build only (tools/bwd_stamps.py): per-wave phase timestamps of the adjoint-scan kernel
+__device__ unsigned long long *g_bwd_stamps = nullptr;
+#define STAMPB(i)                                                                                                \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (g_bwd_stamps && lane == 0) g_bwd_stamps[((size_t)w * 2 + part) * 12 + (i)] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#else
+#define STAMPB(i) ((void)0)
+#endif
+
 // ----------------------------------------------------------------------------
 // BACKWARD.  Notation (indices in cropped coordinates):
 //   T_n = M(r'_{n-1}),  P_n = P_{n-1} T_n,  echo_n = b_n/d_n,  (b_n,d_n) = 2nd column of P_n
@@ -47,17 +59,28 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     const bool accum_pose = SEG && A.accum_pose;
     __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
     constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 12 KiB more LDS per wave
-    __shared__ float stash[KEEP_GRAD ? WPB : 1][KEEP_GRAD ? 3 * kWave * C : 1];
+    __shared__ __attribute__((aligned(16))) float stash[KEEP_GRAD ? WPB : 1][KEEP_GRAD ? 3 * kWave * C : 4];
     const int lane = threadIdx.x & 63;
     const long pose = w / A.R;
     const int n0 = lane * C;
     float *wb = lds[wib];
     float *gst = stash[KEEP_GRAD ? wib : 0];
 
+    STAMPB(0);
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
 
-    float zi[C], z[C], r[C], gb[C];
+    float zi[C], z[C], r[C], gb[C], tg[C];
+    // The upstream-gradient row (and the target row of the fused loss) are requested FIRST: two 16-byte loads per lane
+    // straight into the CHUNKED mapping, in flight while the gather computes its addresses -- loads complete in
+    // order, so they are there by the time the first impedance value is consumed.
+    load_chunk<C>(A.gframe + w * A.N1 + seg0, n0, segN, gb);
+    if (A.mse && A.target) {
+        load_chunk<C>(A.target + w * A.N1 + seg0, n0, segN, tg);
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) tg[j] = 0.f;
+    }
     {
         // The spatial gradient of every sample is needed once more, at the very end (pose gradient): it waits in LDS
         // (lane-private slots, conflict-free), not in 3C registers across the whole scan.
@@ -73,18 +96,10 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         }
     }
     to_chunked<C>(wb, lane, zi, z);
+    STAMPB(1);
     {
-        // upstream gradient row straight into the CHUNKED mapping (two 16-byte loads per lane, no transpose);
-        // attenuation folded in
-        load_chunk<C>(A.gframe + w * A.N1 + seg0, n0, segN, gb);
+        // upstream gradient (loaded above), attenuation folded in
         if (A.mse) { // fused loss: `gframe` is the forward's frame; dL/dframe = 2 s (frame - target), L += s (frame - target)^2
-            float tg[C];
-            if (A.target) {
-                load_chunk<C>(A.target + w * A.N1 + seg0, n0, segN, tg);
-            } else {
-#pragma unroll
-                for (int j = 0; j < C; ++j) tg[j] = 0.f;
-            }
             float ssq = 0.f;
 #pragma unroll
             for (int j = 0; j < C; ++j) {
@@ -111,6 +126,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     if (cin && lane == 0) zprev = cin[4]; // last sample of the previous segment
     const float medv = (A.start > 0) ? A.med[pose] : 0.f;
     reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r);
+    STAMPB(2);
 
     // ---- forward recompute with exponent tracking ----
     Mat L = mat_identity();
@@ -139,6 +155,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     }
     Mat Pm = mat_lane_prev(L, mat_identity()); // exclusive prefix (lane 0: identity) ...
     int eps = lane_prev0(iota);                // ... and its exponent
+    STAMPB(3);
     if (SPLIT > 1) { // the first half's total product (its inclusive scan in lane 63, normalised) is the second half's carry
         if (part == 0 && lane == kWave - 1) {
             s_c[0] = L.a; s_c[1] = L.b; s_c[2] = L.c; s_c[3] = L.d;
@@ -177,6 +194,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     const int elast = eps - esum;
     const int eps_next = lane_next0(eps);
     const int delta = (lane == kWave - 1) ? 0 : (eps_next - elast);
+    STAMPB(4);
 
     // ---- lane-local affine map: A-part = sweep from U = 0 ----
     float rr[C]; // r with non-finite steps cut (U is zero there anyway)
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         return U;
     };
     Mat Aacc = sweep(Mat{0.f, 0.f, 0.f, 0.f}, nullptr);
+    STAMPB(5);
     Mat Bn = Lloc;                    // normalised linear part
     int beta = delta - esum - lamloc; // B = Bn * 2^beta
     if (!mat_finite(Bn)) Bn = Mat{0.f, 0.f, 0.f, 0.f}; // a non-finite chunk passes nothing
@@ -243,6 +262,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         }
     }
     Mat Uin = mat_lane_next0(Aacc); // lane 63: nothing enters from above (0)
+    STAMPB(6);
     if (SPLIT > 1 && part == 0) __syncthreads(); // the second half has published its adjoint carry (it arrives at the matching barrier below)
     if (uin) {
         // Adjoint entering from the next segment.  It was written relative to the scale of that segment's
@@ -269,6 +289,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
 
     float rbar[C];
     const Mat Uout = sweep(Uin, rbar);
+    STAMPB(7);
     if (uout && lane == 0) { // relative to the scale of this segment's carry-in P'
         uout[0] = Uout.a; uout[1] = Uout.b; uout[2] = Uout.c; uout[3] = Uout.d;
     }
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     // The volume scatter is a separate launch (scatter_patch_kernel): its thread <-> sample
     // mapping is chosen for LDS privatisation, not for the scan.
     if (A.zbar) store_chunk<C>(A.zbar + w * A.N1 + seg0, n0, segN, zbar);
+    STAMPB(8);
     if (GPOSE) {
         float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
         // the spatial gradients parked in LDS by the gather: component c of sample n sits at gst[c * 64 C + n], so
@@ -328,32 +350,46 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         float q0[C], q1[C], q2[C];
         if (KEEP_GRAD) {
             wave_lds_sync();
+            auto read_row = [&](int c, float (&q)[C]) { // a lane's C consecutive floats: 16-byte LDS reads
+                if constexpr (C >= 4) {
+                    const float4 *v4 = reinterpret_cast<const float4 *>(gst + c * C * kWave + n0);
 #pragma unroll
-            for (int j = 0; j < C; ++j) {
-                q0[j] = gst[0 * C * kWave + n0 + j]; q1[j] = gst[1 * C * kWave + n0 + j]; q2[j] = gst[2 * C * kWave + n0 + j];
-            }
+                    for (int t = 0; t < C / 4; ++t) {
+                        const float4 v = v4[t];
+                        q[4 * t] = v.x; q[4 * t + 1] = v.y; q[4 * t + 2] = v.z; q[4 * t + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C; ++j) q[j] = gst[c * C * kWave + n0 + j];
+                }
+            };
+            read_row(0, q0); read_row(1, q1); read_row(2, q2);
         }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const int n = n0 + j;
-            const float zb = zbar[j];
-            if (n < segN && zb != 0.f) {
-                const int k = A.start + seg0 + n;
-                float g0, g1, g2;
-                if (KEEP_GRAD) {
-                    g0 = q0[j]; g1 = q1[j]; g2 = q2[j];
-                } else {
+            const int k = A.start + seg0 + n;
+            float g0, g1, g2;
+            if (KEEP_GRAD) {
+                g0 = q0[j]; g1 = q1[j]; g2 = q2[j];
+            } else {
+                g0 = g1 = g2 = 0.f;
+                if (n < segN && zbar[j] != 0.f) {
                     TriSample sm = tri_sample<LAYOUT, true>(A.vol, A.G, ray_point<PM>(ps, 0, k), ray_point<PM>(ps, 1, k),
                                                             ray_point<PM>(ps, 2, k));
                     g0 = sm.g0; g1 = sm.g1; g2 = sm.g2;
                 }
-                const float kf = (float)k;
-                const float a0 = zb * g0, a1 = zb * g1, a2 = zb * g2;
-                gs0 += a0; gs1 += a1; gs2 += a2;
-                gd0 = __builtin_fmaf(kf, a0, gd0);
-                gd1 = __builtin_fmaf(kf, a1, gd1);
-                gd2 = __builtin_fmaf(kf, a2, gd2);
             }
+            // branch-free (selects): nothing flows where zbar is 0 -- past the end of the row, and where the gradient
+            // was dropped, whatever the spatial gradient is there (it may be NaN next to NaN voxels)
+            const float zb = (n < segN) ? zbar[j] : 0.f;
+            const bool on = zb != 0.f;
+            const float kf = (float)k;
+            const float a0 = on ? zb * g0 : 0.f, a1 = on ? zb * g1 : 0.f, a2 = on ? zb * g2 : 0.f;
+            gs0 += a0; gs1 += a1; gs2 += a2;
+            gd0 = __builtin_fmaf(kf, a0, gd0);
+            gd1 = __builtin_fmaf(kf, a1, gd1);
+            gd2 = __builtin_fmaf(kf, a2, gd2);
         }
         gs0 = wave_sum_to_lane63(gs0); gs1 = wave_sum_to_lane63(gs1); gs2 = wave_sum_to_lane63(gs2);
         gd0 = wave_sum_to_lane63(gd0); gd1 = wave_sum_to_lane63(gd1); gd2 = wave_sum_to_lane63(gd2);
@@ -386,6 +422,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
             }
         }
     }
+    STAMPB(9);
 }
 
 // One block per pose: what pose_finish_block does, as a launch of its own (no scatter launch to ride on).
@@ -534,6 +571,13 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
 } // namespace
 
 extern "C" {
+
+#ifdef DIFFUS_STAMP
+int diffus_debug_set_bwd_stamps(unsigned long long *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,

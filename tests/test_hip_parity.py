@@ -233,7 +233,9 @@ def _autograd_case(vol_np, src, dirs, S, alpha, start, sampler, gseed=0):
     vol = torch.from_numpy(vol_np).double().requires_grad_(True)
     s = torch.from_numpy(src).double().requires_grad_(True)
     d = torch.from_numpy(dirs).double().requires_grad_(True)
-    f = ar.render(vol, s, d, S, alpha, start, sampler)
+    # float64 arithmetic at the points the float32 march of the reference lands on (the poses of these tests are
+    # float32): marching in float64 flips a nearest index here and there, i.e. moves whole contributions by a voxel
+    f = ar.render(vol, s, d, S, alpha, start, sampler, points="f32")
     g = torch.Generator().manual_seed(gseed)
     up = torch.randn(f.shape, generator=g, dtype=torch.float64)
     (f * up).sum().backward()
@@ -243,14 +245,16 @@ def _autograd_case(vol_np, src, dirs, S, alpha, start, sampler, gseed=0):
 
 @pytest.mark.parametrize("layout", ["canonical", "bricked", "paired"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
-@pytest.mark.parametrize("S,start", [(48, 0), (48, 7), (150, 0), (300, 12), (700, 0)])
+@pytest.mark.parametrize("S,start", [(48, 0), (48, 7), (150, 0), (300, 12), (513, 0), (700, 0), (1024, 0), (1027, 3)])
 def test_backward_vs_float64_autograd(da, vols, sampler, S, start, layout):
     n = 64
     src, dirs = pose_ring(n, 4, 6)
     src, dirs = src[1], dirs[1].copy()
     dirs[:, 2] = 0.21                                   # out of plane: all three lerps carry gradient
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
-    alpha = 3e-3
+    if S > 300:                                         # long rays: short steps keep the samples inside the 64^3 head
+        dirs *= np.float32(40.0 / S)                    # (hundreds of clamped samples piling signed terms on one border
+    alpha = 3e-3                                        # voxel measure float32 cancellation, not the kernels)
     f_ref, up, gv_ref, gs_ref, gd_ref = _autograd_case(vols[n], src, dirs, S, alpha, start, sampler)
     vol = cuda(vols[n]).requires_grad_(True)
     s = torch.from_numpy(src).cuda().requires_grad_(True)

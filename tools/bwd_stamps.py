@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: where an adjoint-scan wave spends its life (build with -DDIFFUS_STAMP): per-phase cycles from s_memtime
+stamps of lane 0 of every wave.  Shares, not absolute kernel time (the stamps and their fences cost cycles themselves)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["DIFFUS_LIB"] = os.path.abspath(sys.argv[1])
+from diffus_amd import CapturedStep, _lib
+from diffus_amd.phantom import phantom, pose_ring
+lib = _lib.load()
+P = int(os.environ.get("POSES", "32")); N = int(os.environ.get("N", "256")); R = int(os.environ.get("RAYS", "256")); S = int(os.environ.get("SAMPLES", "512"))
+vol = torch.from_numpy(phantom(N)).cuda()
+src, dirs = pose_ring(N, P, R)
+hp = CapturedStep(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), S, 1e-4, "trilinear", fused_loss=False)
+nw = P * R
+st = torch.zeros(nw * 2 * 12, dtype=torch.int64, device="cuda")
+lib.diffus_debug_set_bwd_stamps.argtypes = [C.c_void_p]
+assert lib.diffus_debug_set_bwd_stamps(C.c_void_p(st.data_ptr())) == 0
+hp.fwd(); hp.loss_and_grad()
+for _ in range(3):
+    st.zero_(); hp.bwd(_lib.BWD_SCAN)
+torch.cuda.synchronize()
+s = st.cpu().numpy().reshape(nw * 2, 12)[:, :10].astype(np.int64)
+s = s[s[:, 0] > 0]
+names = ["pose + gather + stash + -> chunked", "gframe load + reflect", "local product + forward scan", "P' / seeds loop",
+         "sweep from 0 (A part)", "reverse scan", "sweep with U_in + rbar", "zbar + store", "pose gradient"]
+d = np.diff(s, axis=1)
+life = s[:, 9] - s[:, 0]
+print("waves %d (P=%d R=%d S=%d); wave lifetime: mean %.0f median %.0f max %.0f cycles" % (len(s), P, R, S, life.mean(), np.median(life), life.max()))
+for i, n in enumerate(names):
+    print("  %-38s mean %8.0f  median %8.0f  share %5.1f %%" % (n, d[:, i].mean(), np.median(d[:, i]), 100 * d[:, i].sum() / life.sum()))
