@@ -11,8 +11,13 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
         if (g_bwd_stamps && lane == 0) g_bwd_stamps[((size_t)w * 2 + part) * 12 + (i)] = __builtin_readcyclecounter(); \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
     } while (0)
+#define STAMPRT(i)                                                                                               \
+    do {                                                                                                         \
+        if (g_bwd_stamps && lane == 0) g_bwd_stamps[((size_t)w * 2 + part) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define STAMPB(i) ((void)0)
+#define STAMPRT(i) ((void)0)
 #endif
 
 // ----------------------------------------------------------------------------
@@ -66,6 +71,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     float *wb = lds[wib];
     float *gst = stash[KEEP_GRAD ? wib : 0];
 
+    STAMPRT(10); // 100 MHz wall clock, the same on every XCD: when the wave started ...
     STAMPB(0);
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         }
     }
     STAMPB(9);
+    STAMPRT(11); // ... and ended
 }
 
 // One block per pose: what pose_finish_block does, as a launch of its own (no scatter launch to ride on).

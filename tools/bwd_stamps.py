@@ -20,8 +20,9 @@ hp.fwd(); hp.loss_and_grad()
 for _ in range(3):
     st.zero_(); hp.bwd(_lib.BWD_SCAN)
 torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(nw * 2, 12)[:, :10].astype(np.int64)
-s = s[s[:, 0] > 0]
+full = st.cpu().numpy().reshape(nw * 2, 12).astype(np.int64)
+full = full[full[:, 0] > 0]
+s = full[:, :10]
 names = ["pose + gather + stash + -> chunked", "gframe load + reflect", "local product + forward scan", "P' / seeds loop",
          "sweep from 0 (A part)", "reverse scan", "sweep with U_in + rbar", "zbar + store", "pose gradient"]
 d = np.diff(s, axis=1)
@@ -29,3 +30,13 @@ life = s[:, 9] - s[:, 0]
 print("waves %d (P=%d R=%d S=%d); wave lifetime: mean %.0f median %.0f max %.0f cycles" % (len(s), P, R, S, life.mean(), np.median(life), life.max()))
 for i, n in enumerate(names):
     print("  %-38s mean %8.0f  median %8.0f  share %5.1f %%" % (n, d[:, i].mean(), np.median(d[:, i]), 100 * d[:, i].sum() / life.sum()))
+rt0, rt1 = full[:, 10], full[:, 11]
+t0 = rt0.min()
+span = (rt1.max() - t0) / 100.0
+print("wall clock (s_memrealtime, 100 MHz): first wave start -> last wave end %.1f us; a wave lives %.1f us on average (=> %.2f GHz shader clock)"
+      % (span, (rt1 - rt0).mean() / 100.0, life.mean() / ((rt1 - rt0).mean() / 100.0) / 1e3))
+st_us = np.sort(rt0 - t0) / 100.0
+en_us = np.sort(rt1 - t0) / 100.0
+for q in (0.05, 0.25, 0.5, 0.55, 0.75, 0.95, 1.0):
+    i = int(q * len(st_us)) - 1
+    print("  %3.0f %% of the waves have started by %5.1f us, ended by %5.1f us" % (100 * q, st_us[i], en_us[i]))
