@@ -174,6 +174,22 @@ def unbrick_volume(bricked: torch.Tensor, shape, out: Optional[torch.Tensor] = N
     return out
 
 
+def layout_fits(kind: str, shape) -> bool:
+    """Whether a (d0,d1,d2) volume can be held in layout `kind` (include/diffus_hip.h, check_common): offsets are 32-bit
+    (fewer than 2^30 floats) and the bricked / paired brick-row stride is the 24-bit operand of a multiply."""
+    d0, d1, d2 = (int(x) for x in shape)
+    nb0, nb1, nb2 = (d0 + 3) // 4, (d1 + 3) // 4, (d2 + 1) // 2
+    if max(d0, d1, d2) > (1 << 24) or nb0 * nb1 * nb2 * 32 >= (1 << 30):
+        return False
+    if kind == "canonical":
+        return True
+    if kind == "bricked":
+        return nb1 * nb2 * 128 < (1 << 24)
+    if kind == "paired":
+        return nb1 * d2 * 160 < (1 << 24) and nb0 * nb1 * d2 * 40 < (1 << 30)
+    raise ValueError(f"unknown layout {kind!r}")
+
+
 def _converted_copy(vol: torch.Tensor, src_tensor: torch.Tensor, want: str, samples: int):
     """Return (cached converted copy, layout id) if the layout policy asks for one, else (None, CANONICAL).
 
@@ -183,6 +199,10 @@ def _converted_copy(vol: torch.Tensor, src_tensor: torch.Tensor, want: str, samp
     if want == "canonical":
         return None, _lib.CANONICAL
     kind = "bricked" if want == "bricked" else "paired"
+    if want == "auto" and not layout_fits(kind, vol.shape):     # very wide slices: fall back instead of failing
+        kind = "bricked" if layout_fits("bricked", vol.shape) else None
+        if kind is None:
+            return None, _lib.CANONICAL
     lid = _lib.BRICKED if kind == "bricked" else _lib.PAIRED
     ver = src_tensor._version
     _brick_cache[:] = [e for e in _brick_cache if e[0]() is not None]

@@ -515,6 +515,25 @@ def test_fixed_point_scatter_error_bound_per_voxel(da, alpha):
         assert int((g[deep] != 0).sum()) > 0.9 * int(deep.sum())
 
 
+def test_wide_slices_fall_back_to_a_layout_that_fits(da, oracle):
+    """Bricked / paired records address a brick row with a 24-bit multiply: slices wider than ~2^17 bricks do not fit.
+    `layout="auto"` then stays canonical (same frames), an explicit request is refused with the ABI's error."""
+    rng = np.random.default_rng(5)
+    v = (1.5e6 + 1e5 * rng.standard_normal((4, 1100, 1100))).astype(np.float32)
+    src = np.array([1.5, 20.0, 30.0], np.float32)
+    ang = np.linspace(0.2, 1.2, 5)
+    dirs = np.stack([np.zeros(5), np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    assert not da.renderer.layout_fits("paired", v.shape) and not da.renderer.layout_fits("bricked", v.shape)
+    vol = cuda(v)
+    for sampler in ("nearest", "trilinear"):
+        f = da.render_poses(vol, torch.from_numpy(src), torch.from_numpy(dirs), 300, 1e-3, sampler=sampler, layout="auto")
+        f = da.render_poses(vol, torch.from_numpy(src), torch.from_numpy(dirs), 300, 1e-3, sampler=sampler, layout="auto")
+        _, _, _, fo = oracle.plot_beam_frame(v, src, dirs, 300, 1e-3, 0, sampler=sampler)
+        assert maxnorm_rel(f[0].cpu().numpy(), fo) < 2e-5
+    with pytest.raises(da.DiffusError):
+        da.render_poses(vol, torch.from_numpy(src), torch.from_numpy(dirs), 300, 1e-3, sampler="trilinear", layout="paired")
+
+
 # ----------------------------------------------------------------------------- bricked layout
 @pytest.mark.parametrize("shape", [(4, 4, 2), (5, 7, 3), (64, 64, 64), (33, 70, 129), (1, 1, 1), (3, 2, 131)])
 def test_brick_roundtrip(da, shape):

@@ -93,3 +93,13 @@ def test_fan_pose_module():
     assert torch.allclose(dirs, ref, atol=2e-6) and src.shape == (3,)
     (dirs[:, 0].sum() + src.sum()).backward()
     assert fp.median_angle.grad is not None and fp.opening_angle.grad is not None and fp.apex.grad is not None
+
+
+def test_layout_fits_follows_the_abi_limits():
+    from diffus_amd.renderer import layout_fits
+    assert all(layout_fits(k, (256, 256, 256)) for k in ("canonical", "bricked", "paired"))
+    assert all(layout_fits(k, (512, 512, 512)) for k in ("canonical", "bricked", "paired"))
+    assert layout_fits("paired", (64, 640, 640)) and not layout_fits("paired", (8, 1024, 1024))      # brick-row stride >= 2^24 bytes
+    assert layout_fits("bricked", (8, 1024, 512)) and not layout_fits("bricked", (8, 2048, 1024))
+    assert layout_fits("canonical", (8, 2048, 1024))
+    assert not layout_fits("canonical", (1024, 1024, 1024))                                       # 2^30 floats: 32-bit offsets
