@@ -12,11 +12,11 @@ process is one of them.  Rank 0 prints the one JSON line.
 
 Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays x
 512 steps.  One *step* = one pass of the hot path over one batch of poses:
-  forward frame (diffus_render_fwd)
-  -> loss_p = sum(frame_p^2) and the backward of it (diffus_render_bwd_mse: dL/dframe = 2 frame is formed from the
-     frame while the adjoint scan loads the row, the per-pose loss is summed by the call's closing blocks;
-     --unfused-loss runs the separate loss kernel diffus_loss_sumsq + diffus_render_bwd instead):
-     d/d volume, d/d source, d/d directions
+  forward frame, loss_p = sum(frame_p^2) and the backward of it in ONE call (diffus_render_step_mse: the adjoint-scan
+     kernel recomputes the forward per ray anyway, so it also writes the frame and forms dL/dframe = 2 frame on the
+     spot; the per-pose loss is summed by the call's closing blocks.  --two-pass runs diffus_render_fwd +
+     diffus_render_bwd_mse, --unfused-loss diffus_render_fwd + the loss kernel diffus_loss_sumsq + diffus_render_bwd):
+     frame, loss, d/d volume, d/d source, d/d directions
   -> touched bricks of the gradient scratch -> the caller's canonical (d0,d1,d2) volume-gradient tensor
      (diffus_gradbuf_flush, mode PERSISTENT: the tensor is kept across steps and bricks the previous step
      wrote but this one does not are cleared, so after every step it IS that step's dense gradient -- the
@@ -60,6 +60,7 @@ sys.path.insert(0, ROOT)
 # Algorithmic bytes per ray-step, no-reuse model (SURVEY §8d / DESIGN.md §Roofline), per kernel:
 #   fwd      8 corner reads x 4 B + 4 B frame write                         = 36 (nearest: 4 + 4 = 8)
 #   bwd scan 4 B gframe read + 8 x 4 B corner re-reads                      = 36 (nearest: 8)
+#            (one-pass step: the 4 B are the frame write instead -- it has no dL/dframe to read -- same 36 / 8)
 #   scatter  8 corners x (4 B read + 4 B write) atomic RMW on the gradient  = 64 (nearest: 8)
 BYTES = {
     "trilinear": {"render_fwd_kernel": 36, "render_bwd_kernel": 36, "scatter_patch_kernel": 64},
@@ -90,6 +91,9 @@ def parse_args(argv=None):
                     help="hand the gradient back by a dense conversion instead of the touched-brick flush")
     ap.add_argument("--unfused-loss", action="store_true",
                     help="separate loss kernel (diffus_loss_sumsq) + diffus_render_bwd instead of the fused diffus_render_bwd_mse")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="separate forward launch (diffus_render_fwd + diffus_render_bwd_mse) instead of the one-pass "
+                         "diffus_render_step_mse")
     ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the `callers` legs (demo shape, learnable volume, moving poses)")
@@ -233,7 +237,8 @@ def cpu_baseline(budget_rays=64, budget_steps=256):
 def workload_key(args):
     """What a PMC summary must have been collected on to speak for this run."""
     return {"n": args.n, "poses": args.poses, "rays": args.rays, "samples": args.samples, "start": args.start,
-            "sampler": args.sampler, "layout": args.layout}
+            "sampler": args.sampler, "layout": args.layout,
+            "passes": 2 if (args.two_pass or args.unfused_loss) else 1}
 
 
 def find_pmc_summary(key):
@@ -423,7 +428,7 @@ def worker(args):
     def make_step(s, d, want_gvol=not args.no_gvol, learnable=args.learnable_volume):
         return CapturedStep(vol, s, d, args.samples, args.alpha, args.sampler, start=args.start, want_gvol=want_gvol,
                             layout=args.layout, sparse=not args.dense_grad, persistent=not args.memset_grad,
-                            learnable_volume=learnable, fused_loss=not args.unfused_loss)
+                            learnable_volume=learnable, fused_loss=not args.unfused_loss, one_pass=not args.two_pass)
 
     hp = make_step(src, dirs)
     losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
@@ -529,8 +534,13 @@ def worker(args):
     # --- per-kernel device time (HIP events on the launch stream), rank-local ---
     it = max(10, min(args.steps, 50))
     hp.fwd(); hp.loss_and_grad()
-    k_ms = {"render_fwd_kernel": time_events(hp.fwd, it),
-            "render_bwd_kernel": time_events(lambda: hp.bwd(_lib.BWD_SCAN), it)}
+    one_pass = hp.fused_loss and hp.one_pass
+    if one_pass:    # the step has no forward launch: its scan kernel writes the frame too
+        k_ms = {"render_bwd_kernel": time_events(lambda: hp.step_mse(_lib.BWD_SCAN), it)}
+    else:
+        k_ms = {"render_fwd_kernel": time_events(hp.fwd, it),
+                "render_bwd_kernel": time_events((lambda: hp.bwd_mse(_lib.BWD_SCAN)) if hp.fused_loss else
+                                                 (lambda: hp.bwd(_lib.BWD_SCAN)), it)}
     if not args.no_gvol:
         k_ms["scatter_patch_kernel"] = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), it,
                                                    pre=(hp.finish_grad if hp.touched is not None else hp.zero_grad))
@@ -606,7 +616,9 @@ def worker(args):
                              f"{args.sampler} sampling; forward + sum-of-squares loss + backward ({grads}) "
                              f"+ canonical gradient + per-pose loss gather"),
                 "loss": ("separate kernel (diffus_loss_sumsq)" if args.unfused_loss else
-                         "fused: dL/dframe formed inside the backward, per-pose loss summed by its closing blocks (diffus_render_bwd_mse)"),
+                         "fused: dL/dframe formed inside the backward, per-pose loss summed by its closing blocks"),
+                "passes": ("one (diffus_render_step_mse: the adjoint-scan kernel also writes the frame; no forward launch)"
+                           if one_pass else "two (diffus_render_fwd, then the backward)"),
                 "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": args.start, "alpha": args.alpha,
                 "layout": args.layout,

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so
 EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "diffus_workspace_zbar_offset",
            "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume", "diffus_paired_floats",
            "diffus_pair_volume", "diffus_brick_count", "diffus_gradbuf_flush",
-           "diffus_render_fwd", "diffus_render_bwd", "diffus_render_bwd_mse", "diffus_trace_rays", "diffus_echo_traces",
+           "diffus_render_fwd", "diffus_render_bwd", "diffus_render_bwd_mse", "diffus_render_step_mse", "diffus_trace_rays", "diffus_echo_traces",
            "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd",
            "diffus_artifacts_workspace_bytes", "diffus_artifacts",
            "diffus_mlp_fwd", "diffus_mlp_workspace_bytes", "diffus_mlp_bwd", "diffus_brain_mask_workspace_bytes",
@@ -61,6 +61,8 @@ def load():
     lib.diffus_render_bwd.argtypes = common + [vp, vp, vp, vp, vp, i, vp, sz, vp]
     lib.diffus_render_bwd_mse.restype = i
     lib.diffus_render_bwd_mse.argtypes = common + [vp, vp, f, vp, vp, vp, vp, vp, i, vp, sz, vp]
+    lib.diffus_render_step_mse.restype = i
+    lib.diffus_render_step_mse.argtypes = common + [vp, f, vp, vp, vp, vp, vp, vp, i, vp, sz, vp]
     lib.diffus_brick_count.restype = sz
     lib.diffus_brick_count.argtypes = [i, i, i]
     lib.diffus_gradbuf_flush.restype = i

@@ -100,7 +100,7 @@ class CapturedStep:
                  attenuation_coeff: float, sampler: str = "trilinear", start: int = 0, want_gvol: bool = True,
                  layout: str = "paired", sparse: bool = True, persistent: bool = True,
                  learnable_volume: bool = False, alias_grads: bool = False, fused_loss: bool = True,
-                 target: Optional[torch.Tensor] = None, loss_scale: float = 1.0):
+                 target: Optional[torch.Tensor] = None, loss_scale: float = 1.0, one_pass: bool = True):
         if not volume.is_cuda:
             raise _lib.DiffusError("CapturedStep needs a HIP-resident volume; there is no CPU fallback")
         if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous():
@@ -129,6 +129,9 @@ class CapturedStep:
         # backward forms dL/dframe from the frame on the fly and its closing per-pose blocks sum the loss
         # (diffus_render_bwd_mse) -- no loss kernel, no gradient-of-frame buffer traffic
         self.fused_loss = bool(fused_loss)
+        # ... and one_pass: the frame too comes out of that backward (diffus_render_step_mse): the adjoint scan
+        # recomputes the forward anyway, so step() needs no forward launch at all
+        self.one_pass = bool(one_pass)
         self.target = target
         self.loss_scale = float(loss_scale)
         self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
@@ -238,9 +241,23 @@ class CapturedStep:
         self.bwd(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self.start > 0 else 0))
         self.finish_grad()
 
+    def step_mse(self, stages: int = _lib.BWD_ALL):
+        """One pass: frame, loss = loss_scale * sum((frame - target)^2) per pose and gvol/gsrc/gdirs in one call."""
+        _lib.check(self.lib.diffus_render_step_mse(*self.common, _vp(self.target), self.loss_scale, _vp(self.frame),
+                                                   _vp(self.loss), _vp(self.gvol_k), _vp(self.touched), _vp(self.gsrc),
+                                                   _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(), self.stream()),
+                   "diffus_render_step_mse")
+
     def step(self):
         # (a forked stream for zero_grad beside the forward was measured: the fork/join events cost
         # more than the 10 us they hide -- 0.217 vs 0.202 ms/step -- so the step stays on one stream)
+        if self.fused_loss and self.one_pass:
+            if self.learnable_volume:
+                self.refresh_volume()
+            self.zero_grad()
+            self.step_mse(_lib.BWD_ALL)
+            self.finish_grad()
+            return
         self.forward()
         if self.fused_loss:
             self.zero_grad()

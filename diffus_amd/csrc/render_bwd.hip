@@ -80,7 +80,12 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     // The upstream-gradient row (and the target row of the fused loss) are requested FIRST: two 16-byte loads per lane
     // straight into the CHUNKED mapping, in flight while the gather computes its addresses -- loads complete in
     // order, so they are there by the time the first impedance value is consumed.
-    load_chunk<C>(A.gframe + w * A.N1 + seg0, n0, segN, gb);
+    if (A.mse != 2) {
+        load_chunk<C>(A.gframe + w * A.N1 + seg0, n0, segN, gb);
+    } else { // one-pass step: the frame is this kernel's own recomputed forward
+#pragma unroll
+        for (int j = 0; j < C; ++j) gb[j] = 0.f;
+    }
     if (A.mse && A.target) {
         load_chunk<C>(A.target + w * A.N1 + seg0, n0, segN, tg);
     } else {
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     STAMPB(1);
     {
         // upstream gradient (loaded above), attenuation folded in
-        if (A.mse) { // fused loss: `gframe` is the forward's frame; dL/dframe = 2 s (frame - target), L += s (frame - target)^2
+        if (A.mse == 1) { // fused loss: `gframe` is the forward's frame; dL/dframe = 2 s (frame - target), L += s (frame - target)^2
             float ssq = 0.f;
 #pragma unroll
             for (int j = 0; j < C; ++j) {
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     float gu[C]; // gbar_n / d'_n
     float rho[C];
     int esum = 0;
+    float ssq2 = 0.f; // one-pass step: this lane's share of sum((frame - target)^2)
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         Pin[j] = Pm;
@@ -187,6 +193,17 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         const float rd = __builtin_amdgcn_rcpf(Pm.d);
         const float e = Pm.b * rd;
         const bool num = (e == e);         // echoes zeroed by nan_to_num are constants: no gradient through them
+        if (A.mse == 2) {
+            // ONE-PASS STEP (diffus_render_step_mse): the echo just recomputed IS the forward's (same operations in the
+            // same order as render_fwd_kernel), so the frame, the loss term and dL/dframe are formed right here and
+            // the separate forward launch -- a second gather of every sample -- is not needed.
+            const float att = fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
+            const float fr = (n0 + j < segN) ? __fmul_rn(num ? e : 0.f, att) : 0.f;
+            const float dlt = fr - tg[j]; // tg is 0 past the end of the row
+            ssq2 = __builtin_fmaf(dlt, dlt, ssq2);
+            gb[j] = (2.f * A.loss_scale) * dlt * att;
+            tg[j] = fr; // the frame row, stored after the loop
+        }
         const float q = (num ? gb[j] : 0.f) * rd;
         rho[j] = num ? e : 0.f;
         // Nothing but a finite seed may enter the adjoint chain (a NaN in U would wipe out every earlier step as well).
@@ -196,6 +213,15 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         gu[j] = (finitef(q) && finitef(e)) ? q : 0.f;
     }
 
+    if (A.mse == 2) {
+        if (A.frame) store_chunk<C>(A.frame + w * A.N1 + seg0, n0, segN, tg);
+        ssq2 = wave_sum_to_lane63(ssq2);
+        if (lane == kWave - 1) {
+            float *lp = A.loss_part + w * 2 + part;
+            *lp = A.loss_scale * ssq2;
+            if (SPLIT == 1) lp[1] = 0.f;
+        }
+    }
     // exponent of this lane's last P' and the hop to the next lane's exclusive prefix
     const int elast = eps - esum;
     const int eps_next = lane_next0(eps);
@@ -483,15 +509,15 @@ int launch_bwd(const Args &A, int sampler, int layout, bool pose, hipStream_t st
 // diffus_render_bwd (mse = false: `gframe` is dL/dframe) and diffus_render_bwd_mse (mse = true: `gframe` is the frame)
 int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
                     const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
-                    const float *gframe, bool mse, const float *target, float loss_scale, float *loss,
+                    const float *gframe, int mse, const float *target, float loss_scale, float *loss, float *frame_out,
                     float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
                     void *workspace, size_t workspace_bytes, diffus_stream_t stream)
 {
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
-    if (!gframe) return DIFFUS_EINVAL;
+    if (!gframe && mse != 2) return DIFFUS_EINVAL;
     if (stages < 1 || stages > (DIFFUS_BWD_ALL | DIFFUS_BWD_KEEP_MEDIAN) || !(stages & DIFFUS_BWD_ALL)) return DIFFUS_EINVAL;
-    if (!gvol && !gsrc && !gdirs && !(mse && loss)) return DIFFUS_OK;
+    if (!gvol && !gsrc && !gdirs && !(mse && loss) && !(mse == 2 && frame_out)) return DIFFUS_OK;
     const bool do_scan = stages & DIFFUS_BWD_SCAN, do_scatter = stages & DIFFUS_BWD_SCATTER;
     Workspace ws = carve(workspace, P, R, S - start);
     if (!workspace || workspace_bytes < ws.bytes) return DIFFUS_EWORKSPACE;
@@ -501,10 +527,11 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
         if (gsrc && hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)P * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
         if (gdirs && hipMemsetAsync(gdirs, 0, sizeof(float) * (size_t)P * R * 3, st) != hipSuccess) return DIFFUS_ELAUNCH;
     }
-    if (sampler == DIFFUS_NEAREST && !gvol && !(mse && loss)) return DIFFUS_OK;
+    if (sampler == DIFFUS_NEAREST && !gvol && !(mse && loss) && !(mse == 2 && frame_out)) return DIFFUS_OK;
     Args A = make_args(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.gframe = gframe;
     A.mse = mse;
+    A.frame = (mse == 2) ? frame_out : nullptr;
     A.target = target;
     A.loss_scale = loss_scale;
     A.loss_part = ws.loss_part;
@@ -592,8 +619,8 @@ int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout, cons
                       void *workspace, size_t workspace_bytes, diffus_stream_t stream)
 {
     return render_bwd_impl(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler, gframe,
-                           false, nullptr, 0.f, nullptr, gvol, gvol_touched, gsrc, gdirs, stages, workspace, workspace_bytes,
-                           stream);
+                           0, nullptr, 0.f, nullptr, nullptr, gvol, gvol_touched, gsrc, gdirs, stages, workspace,
+                           workspace_bytes, stream);
 }
 
 int diffus_render_bwd_mse(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
@@ -603,8 +630,33 @@ int diffus_render_bwd_mse(const float *vol, int d0, int d1, int d2, int layout, 
                           diffus_stream_t stream)
 {
     return render_bwd_impl(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler, frame,
-                           true, target, loss_scale, loss, gvol, gvol_touched, gsrc, gdirs, stages, workspace, workspace_bytes,
-                           stream);
+                           1, target, loss_scale, loss, nullptr, gvol, gvol_touched, gsrc, gdirs, stages, workspace,
+                           workspace_bytes, stream);
+}
+
+int diffus_render_step_mse(const float *vol, int d0, int d1, int d2, int layout, const void *src, int src_dtype,
+                           const void *dirs, int dirs_dtype, int P, int R, int S, int start, float alpha, int sampler,
+                           const float *target, float loss_scale, float *frame, float *loss, float *gvol, int *gvol_touched,
+                           float *gsrc, float *gdirs, int stages, void *workspace, size_t workspace_bytes,
+                           diffus_stream_t stream)
+{
+    if (S - start > DIFFUS_MAX_SAMPLES) {
+        // rays of more than one launch: the forward and the fused-loss backward as two calls (the segmented backward
+        // runs its own carry-only forward passes anyway)
+        if (!frame) return DIFFUS_EINVAL;
+        if (stages & DIFFUS_BWD_SCAN) {
+            int rc = diffus_render_fwd(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler,
+                                       frame, nullptr, workspace, workspace_bytes, stream);
+            if (rc) return rc;
+            if (start > 0) stages |= DIFFUS_BWD_KEEP_MEDIAN;
+        }
+        return diffus_render_bwd_mse(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler,
+                                     frame, target, loss_scale, loss, gvol, gvol_touched, gsrc, gdirs, stages, workspace,
+                                     workspace_bytes, stream);
+    }
+    return render_bwd_impl(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler, nullptr,
+                           2, target, loss_scale, loss, frame, gvol, gvol_touched, gsrc, gdirs, stages, workspace,
+                           workspace_bytes, stream);
 }
 
 } // extern "C"

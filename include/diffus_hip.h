@@ -212,6 +212,25 @@ int diffus_render_bwd_mse(const float *vol, int d0, int d1, int d2, int layout,
                           diffus_stream_t stream);
 
 /*
+ * Forward, that loss and its backward in ONE pass: the backward recomputes the forward per ray anyway (nothing is
+ * saved between the two), so for the fused loss above the frame itself can come out of the adjoint-scan kernel -- the
+ * arithmetic of diffus_render_fwd, equal to it up to the rounding of the scan's association (chunk length, two waves
+ * per ray) -- and the separate forward launch, a second gather of every sample, disappears.  `frame` (nullable, (P,R,N1) float32) receives plot_beam_frame's
+ * processed_output (reference src/renderer.py:201-275, artifacts off), `loss` (nullable, (P)) the per-pose loss, the
+ * gradients and `stages` as in diffus_render_bwd (the frame and the loss belong to the SCAN stage).  Rays longer than
+ * one launch (N1 > 1024) run as diffus_render_fwd + diffus_render_bwd_mse inside the call (`frame` then required).
+ */
+int diffus_render_step_mse(const float *vol, int d0, int d1, int d2, int layout,
+                           const void *src, int src_dtype,
+                           const void *dirs, int dirs_dtype,
+                           int P, int R, int S, int start, float alpha, int sampler,
+                           const float *target, float loss_scale,
+                           float *frame, float *loss,
+                           float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
+                           void *workspace, size_t workspace_bytes,
+                           diffus_stream_t stream);
+
+/*
  * Stage 1 alone: replaces UltrasoundRenderer.trace_ray / simulate_rays
  * (reference src/renderer.py:90-180, :35-71) = custom_nearest_sampler
  * (:741-759) + compute_reflection_coeff (:27-33).  Any of the outputs may be

@@ -196,8 +196,21 @@ def test_fused_mse_backward_equals_loss_kernel_plus_backward(hot, S, start, samp
     g = torch.Generator().manual_seed(S)
     target = (torch.randn(P, R, S - start, generator=g) * 0.05).cuda()
     for tgt, scale in ((None, 1.0), (target, 0.37)):
-        fused = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale)
+        fused = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale,
+                            one_pass=False)
         fused.step()
+        # ... and the ONE-PASS step (diffus_render_step_mse: the frame too comes out of the adjoint-scan kernel)
+        one = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale)
+        one.frame.fill_(float("nan"))
+        one.step()
+        torch.cuda.synchronize()
+        # same arithmetic; the scan may associate differently (chunk length, two waves per ray), hence rounding only
+        # (each within 1e-5 of the float64 truth: tests/test_hip_parity.py)
+        assert float((one.frame - fused.frame).abs().max()) <= 2e-5 * float(fused.frame.abs().max())
+        assert torch.allclose(one.loss, fused.loss, rtol=1e-5)
+        assert float((one.gvol - fused.gvol).abs().max()) <= 1e-4 * float(fused.gvol.abs().max())
+        assert torch.allclose(one.gsrc, fused.gsrc, rtol=1e-4, atol=1e-4 * float(fused.gsrc.abs().max()))
+        assert torch.allclose(one.gdirs, fused.gdirs, rtol=1e-4, atol=1e-4 * float(fused.gdirs.abs().max()))
         ref = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, fused_loss=False)
         ref.fwd()
         diff = ref.frame if tgt is None else ref.frame - tgt

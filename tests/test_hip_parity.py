@@ -272,6 +272,46 @@ def test_backward_vs_float64_autograd(da, vols, sampler, S, start, layout):
 
 @pytest.mark.parametrize("layout", ["canonical", "paired"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
+@pytest.mark.parametrize("S,start", [(48, 0), (48, 7), (130, 1), (300, 12), (513, 0), (700, 30), (1024, 0), (1027, 3),
+                                     (1100, 0)])
+def test_one_pass_step_vs_float64_autograd(da, vols, sampler, S, start, layout):
+    """diffus_render_step_mse: frame, loss = scale * sum((frame - target)^2) and all three gradients out of one call (the
+    frame comes out of the adjoint-scan kernel; N1 > 1024 runs forward + fused backward inside the call) against
+    float64 autograd through the oracle's restatement of the reference."""
+    from oracle import autograd_ref as ar
+    n, P, R, alpha, scale = 64, 2, 6, 3e-3, 0.37
+    src, dirs = pose_ring(n, 4, R)
+    src, dirs = src[1:1 + P], dirs[1:1 + P].copy()
+    dirs[..., 2] = 0.21
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    if S > 300:
+        dirs *= np.float32(40.0 / S)
+    g = torch.Generator().manual_seed(S)
+    target = torch.randn(P, R, S - start, generator=g) * 0.05
+    vol64 = torch.from_numpy(vols[n]).double().requires_grad_(True)
+    s64 = torch.from_numpy(src).double().requires_grad_(True)
+    d64 = torch.from_numpy(dirs).double().requires_grad_(True)
+    f_ref = torch.stack([ar.render(vol64, s64[p], d64[p], S, alpha, start, sampler, points="f32") for p in range(P)])
+    l_ref = scale * ((f_ref - target.double()) ** 2).sum(dim=(1, 2))
+    l_ref.sum().backward()
+    one = da.CapturedStep(cuda(vols[n]), torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), S, alpha, sampler,
+                          start=start, layout=layout, persistent=False, target=target.cuda(), loss_scale=scale)
+    assert one.fused_loss and one.one_pass
+    one.frame.fill_(float("nan"))
+    one.step()
+    torch.cuda.synchronize()
+    assert maxnorm_rel(one.frame.cpu().numpy(), f_ref.detach().numpy()) < 2e-5
+    np.testing.assert_allclose(one.loss.cpu().numpy(), l_ref.detach().numpy(), rtol=1e-4)
+    assert maxnorm_rel(one.gvol.cpu().numpy(), vol64.grad.numpy()) < 1e-3
+    if sampler == "trilinear":
+        assert maxnorm_rel(one.gsrc.cpu().numpy(), s64.grad.numpy()) < 1e-3
+        assert maxnorm_rel(one.gdirs.cpu().numpy(), d64.grad.numpy()) < 1e-3
+    else:
+        assert torch.all(one.gsrc == 0) and torch.all(one.gdirs == 0)
+
+
+@pytest.mark.parametrize("layout", ["canonical", "paired"])
+@pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
 @pytest.mark.parametrize("S,start", [(1025, 0), (1500, 0), (2100, 5), (3300, 0)])
 def test_long_rays_segmented_forward_and_backward(da, oracle, vols, sampler, S, start, layout):
     """S - start > 1024: the ray is processed as 1024-sample segments chained through carries (forward: the
