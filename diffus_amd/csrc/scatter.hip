@@ -39,9 +39,19 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
 #ifndef DIFFUS_SCATTER_THREADS
 #define DIFFUS_SCATTER_THREADS 256
 #endif
-constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kPatchRays * kPatchSteps / kSB;
+#ifndef DIFFUS_SC_PATCH_STEPS
+#define DIFFUS_SC_PATCH_STEPS DIFFUS_PATCH_STEPS
+#endif
+#ifndef DIFFUS_SC_PATCH_RAYS
+#define DIFFUS_SC_PATCH_RAYS DIFFUS_PATCH_RAYS
+#endif
+#ifndef DIFFUS_SC_MIN_BLOCKS
+#define DIFFUS_SC_MIN_BLOCKS 6
+#endif
+constexpr int kScRays = DIFFUS_SC_PATCH_RAYS, kScSteps = DIFFUS_SC_PATCH_STEPS;
+constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kScRays * kScSteps / kSB;
 template <int SAMPLER, int LAYOUT, int PM>
-__global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
+__global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
 {
     // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
     // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
@@ -84,8 +94,8 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
     const int pose = Lb / ray_groups;
     const int tid = threadIdx.x;
     // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..)
-    const int ray = rg * kPatchRays + tid / (kPatchSteps / kSPT);
-    const int nbase = sg * kPatchSteps + (tid % (kPatchSteps / kSPT)) * kSPT;
+    const int ray = rg * kScRays + tid / (kScSteps / kSPT);
+    const int nbase = sg * kScSteps + (tid % (kScSteps / kSPT)) * kSPT;
     const bool ray_ok = ray < A.R;
     const long w = (long)pose * A.R + (ray_ok ? ray : 0);
 
@@ -247,17 +257,13 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
                 const float sc = ldexpf(zb[q], fx);
                 const int ex0 = part2(c.i0[0], 0), ex1 = part2(c.i1[0], 0), ey0 = part2(c.i0[1], 1), ey1 = part2(c.i1[1], 1);
                 const float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1;
-                auto add = [&](int e, float v) { // |v| < 2^62: round to a 64-bit integer as (hi, lo) words
-                    const float m = fabsf(v);
-                    if (m >= 0.5f) {
-                        // magnitude first: a float >= 2^32 is a multiple of 2^9, so both words below are exact
-                        const float mh = floorf(m * 0x1p-32f);                  // high word, < 2^30
-                        const float ml = __builtin_fmaf(mh, -0x1p32f, m);       // m - mh 2^32 in [0, 2^32), exact
-                        const unsigned lo = (unsigned)fminf(rintf(ml), 4294967040.f);
-                        long long qi = ((long long)(unsigned)mh << 32) + (long long)lo;
-                        if (v < 0.f) qi = -qi;
-                        atomicAdd(reinterpret_cast<unsigned long long *>(&tile64[e]), (unsigned long long)qi);
-                    }
+                auto add = [&](int e, float v) { // |v| < 2^62: round to a 64-bit integer
+                    // a float of 2^24 or more is an integer multiple of 2^(exponent - 24): its 24-bit mantissa, as an
+                    // int, shifted into place is exact; below that the conversion rounds to nearest (even), sh = 0
+                    const int sh = max(__builtin_amdgcn_frexp_expf(v) - 24, 0);
+                    const int mi = __float2int_rn(ldexpf(v, -sh));
+                    if (mi != 0)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&tile64[e]), (unsigned long long)((long long)mi << sh));
                 };
                 add(ex0 + ey0, sc * wa0 * wb0);
                 add(ex0 + ey1, sc * wa0 * wb1);
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(kSB, 6) void scatter_patch_kernel(Args A, int ray_g
 namespace diffus {
 int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
 {
-    const int rgs = (A.R + kPatchRays - 1) / kPatchRays, sgs = (A.N1 + kPatchSteps - 1) / kPatchSteps;
+    const int rgs = (A.R + kScRays - 1) / kScRays, sgs = (A.N1 + kScSteps - 1) / kScSteps;
     const unsigned np = (unsigned)((long)A.P * rgs * sgs);
     const unsigned nb = np + (A.finish_in_scatter ? (unsigned)A.P : 0u);
     const bool f32 = !A.src_f64 && !A.dir_f64;

@@ -20,4 +20,7 @@ f = time_events(hp.fwd, 30)["median"]
 b = time_events(lambda: hp.bwd(_lib.BWD_SCAN), 30)["median"]
 s = time_events(lambda: hp.bwd(_lib.BWD_SCATTER), 30, pre=hp.finish_grad)["median"]
 u = time_events(hp.finish_grad, 30, pre=lambda: hp.bwd(_lib.BWD_SCATTER))["median"]
-print("P=%d " % P + "%-34s fwd %.1f us  bwd-scan %.1f us  scatter %.1f us  flush %.1f us" % (os.path.basename(sys.argv[1]), f * 1e3, b * 1e3, s * 1e3, u * 1e3))
+o = time_events(lambda: hp.step_mse(_lib.BWD_SCAN), 30)["median"]
+g = hp.capture()
+t = time_events(g.replay, 50)["median"]
+print("P=%d " % P + "%-34s fwd %.1f us  bwd-scan %.1f us  scatter %.1f us  flush %.1f us  one-pass scan %.1f us  step (graph) %.1f us" % (os.path.basename(sys.argv[1]), f * 1e3, b * 1e3, s * 1e3, u * 1e3, o * 1e3, t * 1e3))
