@@ -536,7 +536,7 @@ def worker(args):
     hp.fwd(); hp.loss_and_grad()
     one_pass = hp.fused_loss and hp.one_pass
     if one_pass:    # the step has no forward launch: its scan kernel writes the frame too
-        k_ms = {"render_bwd_kernel": time_events(lambda: hp.step_mse(_lib.BWD_SCAN), it)}
+        k_ms = {"render_bwd_kernel": time_events(lambda: hp.step_mse(_lib.BWD_SCAN, epilogue=False), it)}
     else:
         k_ms = {"render_fwd_kernel": time_events(hp.fwd, it),
                 "render_bwd_kernel": time_events((lambda: hp.bwd_mse(_lib.BWD_SCAN)) if hp.fused_loss else

@@ -241,11 +241,14 @@ class CapturedStep:
         self.bwd(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self.start > 0 else 0))
         self.finish_grad()
 
-    def step_mse(self, stages: int = _lib.BWD_ALL):
-        """One pass: frame, loss = loss_scale * sum((frame - target)^2) per pose and gvol/gsrc/gdirs in one call."""
+    def step_mse(self, stages: int = _lib.BWD_ALL, epilogue: bool = True):
+        """One pass: frame, loss = loss_scale * sum((frame - target)^2) per pose and gvol/gsrc/gdirs in one call.
+        epilogue=False (timing one kernel): no per-pose loss / d/dsource sums, whose blocks would otherwise ride in the
+        scatter launch or, with stages = SCAN alone, be a launch of their own."""
         _lib.check(self.lib.diffus_render_step_mse(*self.common, _vp(self.target), self.loss_scale, _vp(self.frame),
-                                                   _vp(self.loss), _vp(self.gvol_k), _vp(self.touched), _vp(self.gsrc),
-                                                   _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(), self.stream()),
+                                                   _vp(self.loss if epilogue else None), _vp(self.gvol_k), _vp(self.touched),
+                                                   _vp(self.gsrc if epilogue else None), _vp(self.gdirs), stages,
+                                                   _vp(self.ws), self.ws.numel(), self.stream()),
                    "diffus_render_step_mse")
 
     def step(self):
