@@ -77,6 +77,33 @@ class _CapturedRender(torch.autograd.Function):
                 keep(step.gsrc).reshape(step._src_shape) if need_s else None, keep(step.gdirs) if need_d else None)
 
 
+class _CapturedMSE(torch.autograd.Function):
+    """loss = sum_p loss_scale * sum((frame_p - target_p)^2): the forward IS the whole one-pass step (frame, per-pose
+    losses and the three gradients out of diffus_render_step_mse); the backward only scales what is already there."""
+
+    @staticmethod
+    def forward(ctx, step, volume, sources, directions, slice_values, dim, index):
+        if slice_values is not None:
+            step.vol.select(dim, index).copy_(slice_values)
+        step._run("step")
+        ctx.step = step
+        ctx.where = None if slice_values is None else (dim, index)
+        ctx.stamp = step._stamp = step._stamp + 1
+        return step.loss.sum()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        step = ctx.step
+        if ctx.stamp != step._stamp:
+            raise RuntimeError("CapturedStep.mse_loss: backward of a loss whose buffers a later call has overwritten")
+        need_v, need_s, need_d, need_sl = ctx.needs_input_grad[1:5]
+        have_v = step.gvol is not None
+        return (None, step.gvol * g if (need_v and have_v) else None,
+                (step.gsrc * g).reshape(step._src_shape) if need_s else None, step.gdirs * g if need_d else None,
+                step.gvol.select(*ctx.where) * g if (need_sl and have_v and ctx.where is not None) else None, None, None)
+
+
 class _SliceIntoVolume(torch.autograd.Function):
     """step.vol[..., index, ...] = values (in place, the other voxels keep their values); d/dvalues = that slice of d/dvolume."""
 
@@ -310,6 +337,59 @@ class CapturedStep:
                                    "or learnable_volume=True")
         return _SliceIntoVolume.apply(self, values, int(dim), int(index))
 
+    def _adopt(self, volume, sources, directions, what: str):
+        """Copy arguments that are not the step's own tensors into them, in place; returns the three graph inputs."""
+        v = self.vol if volume is None else volume
+        s = self.src if sources is None else sources
+        d = self.dirs if directions is None else directions
+        with torch.no_grad():
+            if v.data_ptr() != self.vol.data_ptr():
+                if not self.learnable_volume and self.layout != _lib.CANONICAL:
+                    raise _lib.DiffusError(f"{what}(): a volume other than the step's own needs learnable_volume=True "
+                                           "(its converted copy must be rebuilt)")
+                self.vol.copy_(v)
+            if s.data_ptr() != self.src.data_ptr():
+                self.src.copy_(s.reshape(self.src.shape))
+            if d.data_ptr() != self.dirs.data_ptr():
+                self.dirs.copy_(d.reshape(self.dirs.shape))
+        return v, s, d
+
+    def set_target(self, target: Optional[torch.Tensor], loss_scale: Optional[float] = None):
+        """The frames the fused loss compares with ((P,R,N1) float32, None: the frame's energy) and its scale -- e.g.
+        1 / frame.numel() for torch's mse_loss.  Call before capture(): a captured graph holds the buffer's address
+        (later calls with a tensor of the same shape copy into that buffer) and the scale's value."""
+        if target is None:
+            self.target = None
+        else:
+            t = target.detach().to(device=self.dev, dtype=torch.float32).reshape(self.P, self.R, self.N1)
+            if self.target is not None and self.target.shape == t.shape:
+                self.target.copy_(t)
+            else:
+                self.target = t.contiguous().clone()
+        if loss_scale is not None:
+            self.loss_scale = float(loss_scale)
+
+    def mse_loss(self, volume: Optional[torch.Tensor] = None, sources: Optional[torch.Tensor] = None,
+                 directions: Optional[torch.Tensor] = None, *, slice_values: Optional[torch.Tensor] = None,
+                 slice_dim: int = 2, slice_index: int = 0) -> torch.Tensor:
+        """sum over poses of loss_scale * sum((frame - target)^2) as ONE node of torch's autograd graph: its forward
+        runs the one-pass step (diffus_render_step_mse: frame, losses and gradients from a single pass over the
+        samples -- no forward launch, no loss kernels, nothing left for the backward but a scaling), `loss.backward()`
+        hands d/dvolume, d/dsources, d/ddirections to the arguments that require grad.  The training loop of the
+        reference's `[DEMO] Train MRI to Impedance MLP - GPU` cell 16 in one call:
+
+            loss = step.mse_loss(slice_values=model(mri_slice, scale=1e6), slice_dim=2, slice_index=k)
+
+        writes the predicted impedance into slice k of the step's volume (in place) and returns to `slice_values` that
+        slice of d/dvolume (canonical layout, or learnable_volume=True).  `step.frame` holds the frame afterwards."""
+        if not (self.fused_loss and self.one_pass):
+            raise _lib.DiffusError("mse_loss() is the one-pass step: fused_loss and one_pass must be on")
+        if slice_values is not None and self.layout != _lib.CANONICAL and not self.learnable_volume:
+            raise _lib.DiffusError("mse_loss(slice_values=...): the converted copy must follow the volume: use "
+                                   "layout='canonical' or learnable_volume=True")
+        v, s, d = self._adopt(volume, sources, directions, "mse_loss")
+        return _CapturedMSE.apply(self, v, s, d, slice_values, int(slice_dim), int(slice_index))
+
     def render(self, volume: Optional[torch.Tensor] = None, sources: Optional[torch.Tensor] = None,
                directions: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Forward frame (P,R,N1) as a node of torch's autograd graph: `loss.backward()` runs the step's backward and
@@ -320,17 +400,5 @@ class CapturedStep:
         rebuilt inside the forward).  The returned frame aliases the step's frame buffer: it is valid until the next
         forward.  Uses the captured "forward" / "backward" graphs when `capture("forward")` / `capture("backward")`
         were called, eager launches otherwise (e.g. inside a caller's own torch.cuda.graph capture)."""
-        v = self.vol if volume is None else volume
-        s = self.src if sources is None else sources
-        d = self.dirs if directions is None else directions
-        with torch.no_grad():
-            if v.data_ptr() != self.vol.data_ptr():
-                if not self.learnable_volume and self.layout != _lib.CANONICAL:
-                    raise _lib.DiffusError("render(): a volume other than the step's own needs learnable_volume=True "
-                                           "(its converted copy must be rebuilt)")
-                self.vol.copy_(v)
-            if s.data_ptr() != self.src.data_ptr():
-                self.src.copy_(s.reshape(self.src.shape))
-            if d.data_ptr() != self.dirs.data_ptr():
-                self.dirs.copy_(d.reshape(self.dirs.shape))
+        v, s, d = self._adopt(volume, sources, directions, "render")
         return _CapturedRender.apply(self, v, s, d)

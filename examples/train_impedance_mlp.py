@@ -4,7 +4,9 @@ path: an MLP maps the MRI intensities of the imaging plane to acoustic impedance
 impedance (`plot_beam_frame`, 64 rays x 228 samples, start = 110), a loss compares it with the target frame, Adam updates
 the MLP.  The reference cannot run this loop with its current source; here the whole iteration -- fused MLP
 forward, slice update, median + forward frame, loss, adjoint scan + volume scatter, MLP backward, fused Adam -- is ONE
-captured hipGraph replayed per step.
+captured hipGraph replayed per step.  By default the MSE is fused into the renderer (`CapturedStep.mse_loss`: frame, loss and
+d/dimpedance out of ONE pass over the samples); `Loop(one_pass=False)` renders the frame as an autograd node and
+leaves the loss to torch.
 
     python examples/train_impedance_mlp.py [steps]
 """
@@ -20,7 +22,7 @@ from diffus_amd.phantom import phantom, pose_ring  # noqa: E402
 
 
 class Loop:
-    def __init__(self, n=256, rays=64, samples=228, start=110, alpha=1e-4, lr=1e-2, pose=0, seed=0):
+    def __init__(self, n=256, rays=64, samples=228, start=110, alpha=1e-4, lr=1e-2, pose=0, seed=0, one_pass=True):
         dev = torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(seed)
         z_true = torch.from_numpy(phantom(n)).to(dev)                    # "ground truth" impedance
@@ -37,13 +39,20 @@ class Loop:
                                     persistent=False, alias_grads=True)
         self.step.fwd()
         self.target = self.step.frame.clone()                            # the frame of the true impedance
+        # one_pass: MSE (mean over the frame, like torch's mse_loss) fused into the renderer -- frame, loss and gradient
+        # come out of one call (CapturedStep.mse_loss); else the frame is a node and the loss is torch's
+        self.one_pass = one_pass
+        self.step.set_target(self.target, 1.0 / self.target.numel())
         self.loss = torch.zeros((), device=dev)
         self.graph = None
 
     def iteration(self):
         z_slice = self.model(self.mri, scale=1e6)
-        frame = self.step.render(self.step.volume_with_slice(z_slice, 2, self.k))
-        loss = torch.nn.functional.mse_loss(frame, self.target)
+        if self.one_pass:
+            loss = self.step.mse_loss(slice_values=z_slice, slice_dim=2, slice_index=self.k)
+        else:
+            frame = self.step.render(self.step.volume_with_slice(z_slice, 2, self.k))
+            loss = torch.nn.functional.mse_loss(frame, self.target)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         self.opt.step()
