@@ -219,6 +219,14 @@ def test_zero_impedance_and_degenerate_volume(da, oracle):
         assert np.all(np.isfinite(f))
         np.testing.assert_allclose(f, fo, rtol=1e-5, atol=1e-6)
         assert np.all(f[0, 12:] == 0)
+        # the one-pass training step forms the same frame in its adjoint-scan kernel; no gradient is NaN
+        one = da.CapturedStep(cuda(vol), torch.from_numpy(src[None]).cuda(), torch.from_numpy(dirs[None]).cuda(), 30, 1e-3,
+                              sampler, layout=layout, persistent=False)
+        one.step()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(one.frame[0].cpu().numpy(), fo, rtol=1e-5, atol=1e-6)
+        assert torch.isfinite(one.loss).all() and torch.isfinite(one.gvol).all()
+        assert torch.isfinite(one.gsrc).all() and torch.isfinite(one.gdirs).all()
     flat = phantom(32)[:, :, :1].copy()   # d2 == 1: the paired dim-2 load must not be used
     _, _, _, fo = oracle.plot_beam_frame(flat, src, dirs, 30, 1e-3, 0, sampler="trilinear")
     for layout in ("canonical", "bricked", "paired"):
@@ -272,8 +280,8 @@ def test_backward_vs_float64_autograd(da, vols, sampler, S, start, layout):
 
 @pytest.mark.parametrize("layout", ["canonical", "paired"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
-@pytest.mark.parametrize("S,start", [(48, 0), (48, 7), (130, 1), (300, 12), (513, 0), (700, 30), (1024, 0), (1027, 3),
-                                     (1100, 0)])
+@pytest.mark.parametrize("S,start", [(2, 0), (3, 0), (48, 0), (48, 7), (65, 0), (130, 1), (300, 12), (513, 0), (700, 30),
+                                     (1024, 0), (1027, 3), (1100, 0)])
 def test_one_pass_step_vs_float64_autograd(da, vols, sampler, S, start, layout):
     """diffus_render_step_mse: frame, loss = scale * sum((frame - target)^2) and all three gradients out of one call (the
     frame comes out of the adjoint-scan kernel; N1 > 1024 runs forward + fused backward inside the call) against
@@ -300,7 +308,8 @@ def test_one_pass_step_vs_float64_autograd(da, vols, sampler, S, start, layout):
     one.frame.fill_(float("nan"))
     one.step()
     torch.cuda.synchronize()
-    assert maxnorm_rel(one.frame.cpu().numpy(), f_ref.detach().numpy()) < 2e-5
+    # (a frame of one or two echoes is nothing but differences of neighbouring float32 samples of ~1.6e6: 1e-4)
+    assert maxnorm_rel(one.frame.cpu().numpy(), f_ref.detach().numpy()) < (1e-4 if S <= 3 else 2e-5)
     np.testing.assert_allclose(one.loss.cpu().numpy(), l_ref.detach().numpy(), rtol=1e-4)
     assert maxnorm_rel(one.gvol.cpu().numpy(), vol64.grad.numpy()) < 1e-3
     if sampler == "trilinear":
