@@ -346,6 +346,17 @@ def callers_legs(args, vol, dev):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# Bucketed loss gather (N > 1): step k writes its P losses into slot k % K of ring (k // K) & 1; a full ring leaves in
+# one all_gather of K * P floats per rank.  Shared by the GPU worker and the CPU dry run (which tests exactly this).
+def ring_slot(k, K):
+    return k % K, (k // K) & 1
+
+
+def losses_of_step(gathered_ring, world, K, P, k):
+    """The (world * P,) losses of step k, in pose order, out of the gathered ring that holds it."""
+    return gathered_ring.view(world, K, P)[:, k % K, :].reshape(-1)
+
+
 def dry_run(args, world, rank):
     """Launcher / rendezvous / gather / timing logic without any GPU work (CPU-only boxes, tests)."""
     import torch
@@ -359,17 +370,34 @@ def dry_run(args, world, rank):
     P_total = args.poses * world
     local = torch.arange(rank * args.poses, (rank + 1) * args.poses, dtype=torch.float32) + 1.0
     allv = torch.empty(P_total)
+    K = max(1, args.gather_every)
+    ring = [torch.zeros((K, args.poses)) for _ in range(2)]
+    gathered = [torch.zeros(world * K * args.poses) for _ in range(2)]
+
+    def send(b):
+        if world > 1:
+            dist.all_gather_into_tensor(gathered[b], ring[b].view(-1))
+        else:
+            gathered[b].copy_(ring[b].view(-1))
+
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if world > 1:
-            dist.all_gather_into_tensor(allv, local)
-        else:
-            allv.copy_(local)
+    for k in range(args.steps):
+        j, b = ring_slot(k, K)
+        ring[b][j] = local + 1000.0 * k                       # stand-in for step k's losses
+        if j == K - 1:
+            send(b)
+    if args.steps % K:                                        # a part-filled ring goes out too
+        send(ring_slot(args.steps - 1, K)[1])
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if args.steps > 0:
+        last = args.steps - 1
+        allv.copy_(losses_of_step(gathered[ring_slot(last, K)[1]], world, K, args.poses, last) - 1000.0 * last)
+    else:
+        allv.copy_(torch.arange(P_total, dtype=torch.float32) + 1.0)
     per_rank = [dt]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
@@ -497,7 +525,7 @@ def worker(args):
 
     def step():
         k = kstep[0]
-        j, b = (k % K, (k // K) & 1) if overlap else (0, 0)
+        j, b = ring_slot(k, K) if overlap else (0, 0)
         if overlap and j == 0 and k >= 2 * K:
             torch.cuda.current_stream().wait_event(gather_ev[b])   # ring b is free again (its gather has finished)
         if graph is not None:
@@ -519,7 +547,7 @@ def worker(args):
     def barrier():
         if overlap:
             if kstep[0] % K:                                    # a part-filled ring goes out too
-                send(((kstep[0] - 1) // K) & 1)
+                send(ring_slot(kstep[0] - 1, K)[1])
             torch.cuda.current_stream().wait_stream(comm)       # every gather issued so far is part of the step count
         if dist is not None:
             dist.barrier()
@@ -546,7 +574,7 @@ def worker(args):
         world_seen = dist.get_world_size()
         if overlap:                                             # the last step's slot of every rank, in pose order
             last = kstep[0] - 1
-            losses_all.copy_(gathered[(last // K) & 1].view(world, K, args.poses)[:, last % K, :].reshape(-1))
+            losses_all.copy_(losses_of_step(gathered[ring_slot(last, K)[1]], world, K, args.poses, last))
         # every rank must hold all P losses, in pose order, and they must be finite
         assert torch.isfinite(losses_all).all() and float(losses_all.abs().min()) > 0, "loss gather failed"
     ray_steps = P_total * args.rays * args.samples

@@ -39,6 +39,27 @@ def test_gpus_2_spawns_two_ranks():
     assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]))      # MAX over ranks
 
 
+@pytest.mark.parametrize("steps,every", [(11, 4), (8, 8), (3, 8), (5, 1)])
+def test_bucketed_loss_gather_delivers_every_steps_losses_in_pose_order(steps, every):
+    """N > 1: the losses of `every` consecutive steps leave in one all_gather; a part-filled ring goes out at the end.
+    The dry run asserts that the last step's losses of every rank come back in pose order (rank-major)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", str(steps), "--poses", "3",
+                        "--gather-every", str(every)], env=_env(), capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert _json_line(r.stdout)["n_gpus"] == 2
+
+
+def test_ring_helpers():
+    sys.path.insert(0, ROOT)
+    import torch
+
+    import bench
+    assert [bench.ring_slot(k, 4) for k in (0, 3, 4, 7, 8)] == [(0, 0), (3, 0), (0, 1), (3, 1), (0, 0)]
+    world, K, P = 3, 4, 2
+    g = torch.arange(world * K * P, dtype=torch.float32)     # rank-major, then slot, then pose
+    assert bench.losses_of_step(g, world, K, P, 6).tolist() == [4.0, 5.0, 12.0, 13.0, 20.0, 21.0]   # slot 6 % 4 = 2
+
+
 def test_under_torchrun_it_is_a_rank_not_a_launcher():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
