@@ -24,6 +24,7 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
+GRAD_BRICKED = 0x10   # OR'ed into `layout` of the backward calls: the gradient is the bricked scratch whatever the volume's layout
 BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
 BWD_KEEP_MEDIAN = 4         # start > 0: the workspace still holds the forward's median (include/diffus_hip.h)
 MAX_SAMPLES = 1024          # cropped samples per launch; longer rays run as chained segments

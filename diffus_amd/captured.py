@@ -127,7 +127,8 @@ class CapturedStep:
                  attenuation_coeff: float, sampler: str = "trilinear", start: int = 0, want_gvol: bool = True,
                  layout: str = "paired", sparse: bool = True, persistent: bool = True,
                  learnable_volume: bool = False, alias_grads: bool = False, fused_loss: bool = True,
-                 target: Optional[torch.Tensor] = None, loss_scale: float = 1.0, one_pass: bool = True):
+                 target: Optional[torch.Tensor] = None, loss_scale: float = 1.0, one_pass: bool = True,
+                 bricked_grad: Optional[bool] = None):
         if not volume.is_cuda:
             raise _lib.DiffusError("CapturedStep needs a HIP-resident volume; there is no CPU fallback")
         if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous():
@@ -168,21 +169,30 @@ class CapturedStep:
         # canonical gradient, what the caller gets.  persistent: the tensor is kept across steps and
         # diffus_gradbuf_flush(PERSISTENT) clears what the previous step left where this step adds nothing, so it
         # always equals this step's dense gradient without a 64 MiB memset per step.
-        self.persistent = persistent and sparse and want_gvol and self.layout != _lib.CANONICAL
+        # The GRADIENT's layout is the bricked scratch + touched-brick flags for a bricked or paired volume, and by
+        # default (bricked_grad=None) for a canonical one too (DIFFUS_GRAD_BRICKED): the kernels then read the caller's
+        # tensor in place -- nothing to convert when the caller changes a slice of it every step -- and the gradient still
+        # comes back sparsely, without a 64 MiB memset per step.  bricked_grad=False: scatter straight into the
+        # canonical tensor (zeroed every step).
+        self.grad_bricked = (self.layout != _lib.CANONICAL) or (want_gvol and sparse and bricked_grad is not False)
+        self.persistent = persistent and sparse and want_gvol and self.grad_bricked
         self.gvol = torch.zeros_like(volume) if want_gvol else None
+        nb = self.lib.diffus_bricked_floats(d0, d1, d2)
         if self.layout != _lib.CANONICAL:
-            # HBM-resident converted copy of the volume; the bricked gradient scratch goes with it
-            nb = self.lib.diffus_bricked_floats(d0, d1, d2)
+            # HBM-resident converted copy of the volume
             nk = nb if self.layout == _lib.BRICKED else self.lib.diffus_paired_floats(d0, d1, d2)
             self.vol_k = torch.empty(nk, dtype=torch.float32, device=dev)
             self.refresh_volume()
+        else:
+            self.vol_k = volume
+        if self.grad_bricked:
             # sparse gradient hand-back: the bricked scratch and its touched-brick flags are all-zero
             # between steps (diffus_gradbuf_flush restores that), only touched bricks are converted
             self.gvol_k = torch.zeros(nb, dtype=torch.float32, device=dev) if want_gvol else None
             self.touched = (torch.zeros(self.lib.diffus_brick_count(d0, d1, d2), dtype=torch.int32, device=dev)
                             if (want_gvol and sparse) else None)
         else:
-            self.vol_k, self.gvol_k, self.touched = volume, self.gvol, None
+            self.gvol_k, self.touched = self.gvol, None
         self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
         self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
@@ -194,6 +204,8 @@ class CapturedStep:
         # every pointer below is fixed for the life of the object (inputs are updated in place)
         self.common = (_vp(self.vol_k), d0, d1, d2, self.layout, _vp(self.src), sdt, _vp(self.dirs), ddt, self.P, self.R,
                        self.S, self.start, self.alpha, self.sampler)
+        glay = self.layout | (_lib.GRAD_BRICKED if (self.grad_bricked and self.layout == _lib.CANONICAL) else 0)
+        self.common_bwd = self.common[:4] + (glay,) + self.common[5:]     # the backward entry points
         self._graphs: dict = {}
         self._side: Optional[torch.cuda.Stream] = None
 
@@ -221,13 +233,13 @@ class CapturedStep:
                                               self.stream()), "diffus_render_fwd")
 
     def bwd(self, stages=_lib.BWD_ALL):
-        _lib.check(self.lib.diffus_render_bwd(*self.common, _vp(self.gframe), _vp(self.gvol_k), _vp(self.touched),
+        _lib.check(self.lib.diffus_render_bwd(*self.common_bwd, _vp(self.gframe), _vp(self.gvol_k), _vp(self.touched),
                                               _vp(self.gsrc), _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(),
                                               self.stream()), "diffus_render_bwd")
 
     def bwd_mse(self, stages=_lib.BWD_ALL):
         """Backward of loss_p = loss_scale * sum((frame_p - target_p)^2), straight from `self.frame`; `self.loss` gets loss_p."""
-        _lib.check(self.lib.diffus_render_bwd_mse(*self.common, _vp(self.frame), _vp(self.target), self.loss_scale,
+        _lib.check(self.lib.diffus_render_bwd_mse(*self.common_bwd, _vp(self.frame), _vp(self.target), self.loss_scale,
                                                   _vp(self.loss), _vp(self.gvol_k), _vp(self.touched), _vp(self.gsrc),
                                                   _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(), self.stream()),
                    "diffus_render_bwd_mse")
@@ -242,15 +254,15 @@ class CapturedStep:
         """A fresh dense gradient every step: zero the caller's canonical (d0,d1,d2) tensor (sparse
         hand-back), or the bricked scratch (dense hand-back: the conversion overwrites every voxel)."""
         if self.gvol is not None and not self.persistent:
-            (self.gvol if (self.touched is not None or self.layout == _lib.CANONICAL) else self.gvol_k).zero_()
+            (self.gvol if (self.touched is not None or not self.grad_bricked) else self.gvol_k).zero_()
 
     def finish_grad(self):
         """touched bricks of the scratch -> the canonical gradient; scratch back to all-zero."""
-        if self.layout != _lib.CANONICAL and self.gvol is not None and self.touched is not None:
+        if self.grad_bricked and self.gvol is not None and self.touched is not None:
             # mode STORE: the tensor was zeroed this step and every touched voxel is written once
             _lib.check(self.lib.diffus_gradbuf_flush(_vp(self.gvol_k), _vp(self.touched), *self.dims, _vp(self.gvol),
                                                      2 if self.persistent else 0, self.stream()), "diffus_gradbuf_flush")
-        elif self.layout != _lib.CANONICAL and self.gvol is not None:
+        elif self.grad_bricked and self.gvol is not None:
             _lib.check(self.lib.diffus_unbrick_volume(_vp(self.gvol_k), *self.dims, _vp(self.gvol), 0, self.stream()),
                        "diffus_unbrick_volume")
 
@@ -272,7 +284,7 @@ class CapturedStep:
         """One pass: frame, loss = loss_scale * sum((frame - target)^2) per pose and gvol/gsrc/gdirs in one call.
         epilogue=False (timing one kernel): no per-pose loss / d/dsource sums, whose blocks would otherwise ride in the
         scatter launch or, with stages = SCAN alone, be a launch of their own."""
-        _lib.check(self.lib.diffus_render_step_mse(*self.common, _vp(self.target), self.loss_scale, _vp(self.frame),
+        _lib.check(self.lib.diffus_render_step_mse(*self.common_bwd, _vp(self.target), self.loss_scale, _vp(self.frame),
                                                    _vp(self.loss if epilogue else None), _vp(self.gvol_k), _vp(self.touched),
                                                    _vp(self.gsrc if epilogue else None), _vp(self.gdirs), stages,
                                                    _vp(self.ws), self.ws.numel(), self.stream()),

@@ -513,6 +513,9 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
                     float *gvol, int *gvol_touched, float *gsrc, float *gdirs, int stages,
                     void *workspace, size_t workspace_bytes, diffus_stream_t stream)
 {
+    const bool grad_bricked = (layout & DIFFUS_GRAD_BRICKED) != 0; // the gradient's layout, decoupled from the volume's
+    layout &= ~DIFFUS_GRAD_BRICKED;
+    const int glayout = (layout == DIFFUS_PAIRED || grad_bricked) ? DIFFUS_BRICKED : layout;
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
     if (!gframe && mse != 2) return DIFFUS_EINVAL;
@@ -537,7 +540,7 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
     A.loss_part = ws.loss_part;
     A.loss_out = (mse && do_scan) ? loss : nullptr;
     A.gvol = gvol;
-    A.gtouched = (gvol && layout != DIFFUS_CANONICAL) ? gvol_touched : nullptr;
+    A.gtouched = (gvol && glayout != DIFFUS_CANONICAL) ? gvol_touched : nullptr;
     A.zbar = gvol ? ws.zbar : nullptr;
     A.gsrc_part = (pose && gsrc) ? ws.gsrc_part : nullptr;
     A.gdirs = pose ? gdirs : nullptr;
@@ -587,11 +590,10 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
     A.gsrc_out = (pose && gsrc) ? gsrc : nullptr;
     A.finish_in_scatter = finish && gvol && do_scatter;
     if (gvol && do_scatter) {
-        rc = diffus::launch_scatter(A, sampler, layout, st);
+        rc = diffus::launch_scatter(A, sampler, glayout, st);
         if (rc) return rc;
     }
     if (finish && !A.finish_in_scatter) {
-        const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout;
         rc = dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
             constexpr int GL = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
             hipLaunchKernelGGL((pose_finish_kernel<decltype(S_)::value, GL>), dim3(P), dim3(kBlock), 0, st, A);
@@ -645,8 +647,8 @@ int diffus_render_step_mse(const float *vol, int d0, int d1, int d2, int layout,
         // runs its own carry-only forward passes anyway)
         if (!frame) return DIFFUS_EINVAL;
         if (stages & DIFFUS_BWD_SCAN) {
-            int rc = diffus_render_fwd(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, sampler,
-                                       frame, nullptr, workspace, workspace_bytes, stream);
+            int rc = diffus_render_fwd(vol, d0, d1, d2, layout & ~DIFFUS_GRAD_BRICKED, src, src_dtype, dirs, dirs_dtype, P, R, S,
+                                       start, alpha, sampler, frame, nullptr, workspace, workspace_bytes, stream);
             if (rc) return rc;
             if (start > 0) stages |= DIFFUS_BWD_KEEP_MEDIAN;
         }

@@ -34,9 +34,10 @@ class Loop:
         self.mri = (z_true[:, :, self.k] / 1e6).contiguous()             # stand-in MRI intensities of that plane
         self.model = da.ImpedanceEstimator().to(dev)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=True, fused=True)
-        # nearest sampling = the reference's sampler; canonical layout: only one slice of the volume changes per step
+        # nearest sampling = the reference's sampler; canonical layout: only one slice of the volume changes per step (the
+        # kernels read the tensor in place; the gradient still comes back through the sparse, never-memset hand-back)
         self.step = da.CapturedStep(z_true.clone(), s, d, samples, alpha, "nearest", start=start, layout="canonical",
-                                    persistent=False, alias_grads=True)
+                                    alias_grads=True)
         self.step.fwd()
         self.target = self.step.frame.clone()                            # the frame of the true impedance
         # one_pass: MSE (mean over the frame, like torch's mse_loss) fused into the renderer -- frame, loss and gradient

@@ -65,6 +65,10 @@ extern "C" {
                               the pair (v[z], v[min(z+1,d2-1)]), so that a trilinear sample is two 16-byte loads;
                               made by diffus_pair_volume; 2.5x the memory; the gradient that goes with it (gvol)
                               is DIFFUS_BRICKED */
+#define DIFFUS_GRAD_BRICKED 0x10 /* backward entry points only, OR'ed into `layout`: `gvol` / `gvol_touched` are the
+                              DIFFUS_BRICKED scratch and its flags whatever the layout of `vol` -- a DIFFUS_CANONICAL
+                              volume (one the caller updates in place, e.g. a slice per training step) then gets the
+                              sparse, never-memset hand-back (diffus_gradbuf_flush) too */
 
 /* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples, at most 16, so one launch
  * covers 1024 cropped samples.  Longer rays (N1 = S - start up to MAX_SAMPLES * MAX_SEGMENTS) are processed

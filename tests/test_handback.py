@@ -231,3 +231,33 @@ def test_fused_mse_backward_equals_loss_kernel_plus_backward(hot, S, start, samp
         only.step()
         torch.cuda.synchronize()
         assert torch.allclose(only.loss.double(), (only.frame.double() ** 2).sum((1, 2)), rtol=2e-6)
+
+
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
+def test_canonical_volume_with_the_bricked_sparse_gradient(hot, sampler):
+    """DIFFUS_GRAD_BRICKED: the kernels read the caller's canonical tensor in place, the gradient goes through the bricked
+    scratch and the touched-brick hand-back (no memset of the dense tensor) -- same values as the scatter straight into
+    the canonical tensor, step after step with fans that move and a volume slice that changes in place."""
+    n, P, R, S, start = 64, 4, 24, 100, 9
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, 12, R)
+    s = torch.from_numpy(src[:P]).cuda().contiguous()
+    d = torch.from_numpy(dirs[:P]).cuda().contiguous()
+    a = hot.HotPath(vol, s, d, S, 2e-3, sampler, start=start, layout="canonical")
+    b = hot.HotPath(vol, s, d, S, 2e-3, sampler, start=start, layout="canonical", bricked_grad=False)
+    assert a.grad_bricked and a.persistent and a.touched is not None
+    assert not b.grad_bricked and b.touched is None and b.gvol_k is b.gvol
+    for it in range(4):
+        lo = (it * 3) % 8
+        for hp in (a, b):
+            hp.set_poses(torch.from_numpy(src[lo:lo + P]).cuda(), torch.from_numpy(dirs[lo:lo + P]).cuda())
+        vol[:, :, 30 + it].mul_(1.01)                       # both steps read the same tensor, in place
+        a.step(); b.step()
+        torch.cuda.synchronize()
+        assert float(b.gvol.abs().max()) > 0
+        # (the planar 64-bit tiles of the bricked path keep contributions the 32-bit tiles of the canonical one round to 0)
+        assert not torch.any((b.gvol != 0) & (a.gvol == 0)), it
+        assert float((a.gvol - b.gvol).abs().max()) <= 2e-5 * float(b.gvol.abs().max()), it
+        assert torch.equal(a.frame, b.frame) and torch.equal(a.loss, b.loss)
+        assert torch.equal(a.gsrc, b.gsrc) and torch.equal(a.gdirs, b.gdirs)
+        assert torch.all(a.gvol_k == 0)
