@@ -194,9 +194,10 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         const float e = Pm.b * rd;
         const bool num = (e == e);         // echoes zeroed by nan_to_num are constants: no gradient through them
         if (A.mse == 2) {
-            // ONE-PASS STEP (diffus_render_step_mse): the echo just recomputed IS the forward's (same operations in the
-            // same order as render_fwd_kernel), so the frame, the loss term and dL/dframe are formed right here and
-            // the separate forward launch -- a second gather of every sample -- is not needed.
+            // ONE-PASS STEP (diffus_render_step_mse): the echo just recomputed IS the forward's (render_fwd_kernel's
+            // arithmetic; only the association of the scan may differ -- chunk length, two waves per ray -- i.e. the
+            // last bits), so the frame, the loss term and dL/dframe are formed right here and the separate forward
+            // launch -- a second gather of every sample -- is not needed.
             const float att = fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
             const float fr = (n0 + j < segN) ? __fmul_rn(num ? e : 0.f, att) : 0.f;
             const float dlt = fr - tg[j]; // tg is 0 past the end of the row
