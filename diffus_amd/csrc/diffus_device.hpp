@@ -738,6 +738,10 @@ __device__ __forceinline__ float2 ldb_f32x2(const float *base, unsigned byte_off
 {
     return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
 }
+__device__ __forceinline__ F2a4 ldb_f32x2u(const float *base, unsigned byte_off) // 8 bytes at a 4-byte-aligned offset
+{
+    return *reinterpret_cast<const F2a4 *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
+}
 struct __attribute__((aligned(8))) F4a8 { // a float4 that is only 8-byte aligned (a PAIRED row at an odd column)
     float x, y, z, w;
 };
@@ -801,6 +805,26 @@ __device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, in
 #endif
                     raw[jj][0] = q0.x; raw[jj][1] = q0.y; raw[jj][2] = q0.z; raw[jj][3] = q0.w;
                     raw[jj][4] = q1.x; raw[jj][5] = q1.y; raw[jj][6] = q1.z; raw[jj][7] = q1.w;
+                } else if constexpr (LAYOUT == DIFFUS_CANONICAL) {
+                    // dim 2 is contiguous: the two depth neighbours of a column come in ONE 8-byte load at the pair
+                    // (b, b + 1), b = min(z0, d2 - 2) -- four wave-loads per sample instead of eight (the gather runs
+                    // at the texture addresser's rate per wave-load).  At the far face (z0 = d2 - 1 = b + 1) both
+                    // values are the pair's second; d2 = 1 has no pair and keeps the dword loads.
+                    const unsigned c00 = x0 + y0, c01 = x0 + y1, c10 = x1 + y0, c11 = x1 + y1;
+                    if (A.G.d2 >= 2) { // kernel argument: uniform over the grid
+                        const int bz = min(c.i0, A.G.d2 - 2);
+                        const unsigned zb = (unsigned)bz << 2;
+                        const bool far = c.i0 != bz;
+                        const F2a4 p00 = ldb_f32x2u(vol, c00 + zb), p01 = ldb_f32x2u(vol, c01 + zb);
+                        const F2a4 p10 = ldb_f32x2u(vol, c10 + zb), p11 = ldb_f32x2u(vol, c11 + zb);
+                        raw[jj][0] = far ? p00.y : p00.x; raw[jj][1] = p00.y;
+                        raw[jj][2] = far ? p01.y : p01.x; raw[jj][3] = p01.y;
+                        raw[jj][4] = far ? p10.y : p10.x; raw[jj][5] = p10.y;
+                        raw[jj][6] = far ? p11.y : p11.x; raw[jj][7] = p11.y;
+                    } else {
+                        raw[jj][0] = raw[jj][1] = ldb_f32(vol, c00); raw[jj][2] = raw[jj][3] = ldb_f32(vol, c01);
+                        raw[jj][4] = raw[jj][5] = ldb_f32(vol, c10); raw[jj][6] = raw[jj][7] = ldb_f32(vol, c11);
+                    }
                 } else {
                     const unsigned z1 = part_z<LAYOUT>(c.i1);
                     const unsigned c00 = x0 + y0, c01 = x0 + y1, c10 = x1 + y0, c11 = x1 + y1;
