@@ -89,7 +89,8 @@ class _CapturedMSE(torch.autograd.Function):
         ctx.step = step
         ctx.where = None if slice_values is None else (dim, index)
         ctx.stamp = step._stamp = step._stamp + 1
-        return step.loss.sum()
+        # (one pose: the loss IS the buffer's only element -- a view, valid until the next step, instead of a reduction)
+        return step.loss.sum() if step.P > 1 else step.loss.detach().view(())
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -193,8 +194,11 @@ class CapturedStep:
                             if (want_gvol and sparse) else None)
         else:
             self.gvol_k, self.touched = self.gvol, None
-        self.gsrc = torch.empty((self.P, 3), dtype=torch.float32, device=dev)
-        self.gdirs = torch.empty((self.P, self.R, 3), dtype=torch.float32, device=dev)
+        # nearest sampling has no pose gradient (integer indices, reference :754-758): the two tensors are zero once and
+        # for all and are not handed to the library, which would otherwise memset them in every step
+        self._pose_grads = self.sampler == _lib.TRILINEAR
+        self.gsrc = (torch.empty if self._pose_grads else torch.zeros)((self.P, 3), dtype=torch.float32, device=dev)
+        self.gdirs = (torch.empty if self._pose_grads else torch.zeros)((self.P, self.R, 3), dtype=torch.float32, device=dev)
         self.loss = torch.empty((self.P,), dtype=torch.float32, device=dev)
         self.loss_ws = torch.zeros(max(512 * self.P, 512), dtype=torch.uint8, device=dev)   # arrival counters: zero once
         nws = max(self.lib.diffus_workspace_bytes(self.P, self.R, self.S, self.start), 256)
@@ -234,14 +238,17 @@ class CapturedStep:
 
     def bwd(self, stages=_lib.BWD_ALL):
         _lib.check(self.lib.diffus_render_bwd(*self.common_bwd, _vp(self.gframe), _vp(self.gvol_k), _vp(self.touched),
-                                              _vp(self.gsrc), _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(),
+                                              _vp(self.gsrc if self._pose_grads else None),
+                                              _vp(self.gdirs if self._pose_grads else None), stages, _vp(self.ws), self.ws.numel(),
                                               self.stream()), "diffus_render_bwd")
 
     def bwd_mse(self, stages=_lib.BWD_ALL):
         """Backward of loss_p = loss_scale * sum((frame_p - target_p)^2), straight from `self.frame`; `self.loss` gets loss_p."""
         _lib.check(self.lib.diffus_render_bwd_mse(*self.common_bwd, _vp(self.frame), _vp(self.target), self.loss_scale,
-                                                  _vp(self.loss), _vp(self.gvol_k), _vp(self.touched), _vp(self.gsrc),
-                                                  _vp(self.gdirs), stages, _vp(self.ws), self.ws.numel(), self.stream()),
+                                                  _vp(self.loss), _vp(self.gvol_k), _vp(self.touched),
+                                                  _vp(self.gsrc if self._pose_grads else None),
+                                                  _vp(self.gdirs if self._pose_grads else None), stages, _vp(self.ws),
+                                                  self.ws.numel(), self.stream()),
                    "diffus_render_bwd_mse")
 
     def loss_and_grad(self):
@@ -286,7 +293,8 @@ class CapturedStep:
         scatter launch or, with stages = SCAN alone, be a launch of their own."""
         _lib.check(self.lib.diffus_render_step_mse(*self.common_bwd, _vp(self.target), self.loss_scale, _vp(self.frame),
                                                    _vp(self.loss if epilogue else None), _vp(self.gvol_k), _vp(self.touched),
-                                                   _vp(self.gsrc if epilogue else None), _vp(self.gdirs), stages,
+                                                   _vp(self.gsrc if (epilogue and self._pose_grads) else None),
+                                                   _vp(self.gdirs if self._pose_grads else None), stages,
                                                    _vp(self.ws), self.ws.numel(), self.stream()),
                    "diffus_render_step_mse")
 
