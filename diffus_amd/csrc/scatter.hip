@@ -65,11 +65,11 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     __shared__ float s_sum[kSW];
     __shared__ int s_planar[kSW];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
-    // PLANAR patches (bricked gradient, trilinear): no ray of the patch moves along dim 2 -- every fan of the reference
+    // PLANAR patches (bricked gradient): no ray of the patch moves along dim 2 -- every fan of the reference
     // (src/cone.py:258) -- so all its samples share ONE dim-2 cell (iz0, iz1, tz).  The tile then holds the 2-D
     // footprint only, 16 entries per brick column: 4 LDS adds per sample instead of 8, half (z0 even) or a quarter
     // (z0 odd) of the tile entries, and the two depth weights are applied once per entry in the flush.
-    constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED) && (SAMPLER == DIFFUS_TRILINEAR);
+    constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED); // nearest sampling too: one add per sample, one depth
     constexpr int UNIT2 = 16; // tile entries per brick column in planar mode
     // Planar tiles are so much smaller (at config 3: 551 entries on average, 2304 at most, of 6144) that their entries
     // can be 64-BIT: the quantum is 2^-61 of the patch's sum of |zbar| instead of 2^-29, so a contribution 2^-37 below
@@ -265,10 +265,14 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
                     if (mi != 0)
                         atomicAdd(reinterpret_cast<unsigned long long *>(&tile64[e]), (unsigned long long)((long long)mi << sh));
                 };
-                add(ex0 + ey0, sc * wa0 * wb0);
-                add(ex0 + ey1, sc * wa0 * wb1);
-                add(ex1 + ey0, sc * wa1 * wb0);
-                add(ex1 + ey1, sc * wa1 * wb1);
+                if constexpr (SAMPLER == DIFFUS_NEAREST) {
+                    add(ex0 + ey0, sc); // i0 == i1: the sample's one voxel column
+                } else {
+                    add(ex0 + ey0, sc * wa0 * wb0);
+                    add(ex0 + ey1, sc * wa0 * wb1);
+                    add(ex1 + ey0, sc * wa1 * wb0);
+                    add(ex1 + ey1, sc * wa1 * wb1);
+                }
             }
         // the patch's dim-2 cell (the same in every thread: p2 = source[2] for every sample)
         const int iz0 = __builtin_amdgcn_readfirstlane(cells[0].i0[2]), iz1 = __builtin_amdgcn_readfirstlane(cells[0].i1[2]);

@@ -523,8 +523,9 @@ def test_full_size_one_pose_gradient_values_vs_float64_autograd(da, n, ring, R, 
     assert int((gv != 0).sum()) > 0.5 * int((gref != 0).sum())      # the support is there, not just the peak
 
 
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
 @pytest.mark.parametrize("alpha", [1e-4, 0.5])
-def test_fixed_point_scatter_error_bound_per_voxel(da, alpha):
+def test_fixed_point_scatter_error_bound_per_voxel(da, alpha, sampler):
     """The scatter accumulates a patch (32 rays x 32 steps) in integer fixed point with ONE power-of-two scale per
     patch.  With the reference's default attenuation_coeff = 0.5 the upstream gradient falls by e per step, 2^-46 over a
     patch: a 32-bit accumulator rounds the deep end of every patch to zero -- invisible in the max norm,
@@ -538,8 +539,9 @@ def test_fixed_point_scatter_error_bound_per_voxel(da, alpha):
     n, R, S = 64, 64, 96
     v = phantom(n)
     src, dirs = pose_ring(n, 8, R)
-    hp = CapturedStep(cuda(v), torch.from_numpy(src[2:3]).cuda(), torch.from_numpy(dirs[2:3]).cuda(), S, alpha, "trilinear",
+    hp = CapturedStep(cuda(v), torch.from_numpy(src[2:3]).cuda(), torch.from_numpy(dirs[2:3]).cuda(), S, alpha, sampler,
                       persistent=False)
+    gather = ar.sample_trilinear if sampler == "trilinear" else (lambda vol, p: ar.sample_nearest(vol, p)[0])
     hp.fwd(); hp.loss_and_grad(); hp.zero_grad()
     hp.bwd(_lib.BWD_SCAN)
     torch.cuda.synchronize()
@@ -550,9 +552,9 @@ def test_fixed_point_scatter_error_bound_per_voxel(da, alpha):
     g = hp.gvol.cpu().double()
     pts = ar.ray_points_f32(torch.from_numpy(src[2]).double(), torch.from_numpy(dirs[2]).double(), S)
     ve = torch.from_numpy(v).double().requires_grad_(True)
-    (zbar * ar.sample_trilinear(ve, pts)).sum().backward()
+    (zbar * gather(ve, pts)).sum().backward()
     vm = torch.from_numpy(v).double().requires_grad_(True)
-    (zbar.abs() * ar.sample_trilinear(vm, pts)).sum().backward()
+    (zbar.abs() * gather(vm, pts)).sum().backward()
     exact, mass = ve.grad, vm.grad
     tol = 4e-6 * mass + 2.0 ** -40 * float(mass.max())
     worst = float(((g - exact).abs() / tol).max())
@@ -560,7 +562,7 @@ def test_fixed_point_scatter_error_bound_per_voxel(da, alpha):
     # the deep end is really there: voxels whose mass is 2^-30 .. 2^-38 of the largest carry their gradient
     deep = (mass < 2.0 ** -30 * float(mass.max())) & (mass > 2.0 ** -38 * float(mass.max()))
     if alpha == 0.5:
-        assert int(deep.sum()) > 50
+        assert int(deep.sum()) > (50 if sampler == "trilinear" else 10)
         assert int((g[deep] != 0).sum()) > 0.9 * int(deep.sum())
 
 
