@@ -24,9 +24,15 @@ Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays 
   -> gather of the per-pose losses over ranks (RCCL, N > 1).
 Workload at N=1 = BASELINE config 3 (32 poses of the config-2 shape on one GPU;
 a single 256x512 frame is only 256 wavefronts, i.e. launch-latency-bound, and is
-reported separately as `single_pose`).  Multi-GPU: poses shard contiguously over
-ranks, 32 per GPU (weak scaling; N=8 is BASELINE config 4), the volume is
-replicated, the only collective is one all_gather of P losses.
+reported separately as `single_pose`).  Multi-GPU (N > 1) = BASELINE config 4 as SURVEY 8d defines it: STRONG
+scaling, --poses-total = 256 poses sharded contiguously over the N ranks (256 / N per GPU), the volume replicated,
+the only collective one all_gather of the P losses per step; the line then also carries `weak` (32 poses per GPU),
+and `strong.one_gpu` (all 256 poses on rank 0's GPU alone, timed in the same run) with `speedup_vs_one_gpu`.  The
+N = 1 line carries that one-GPU leg too (`strong_base` = config 4 at 1 of 8 GPUs).  `--scaling weak|strong` forces
+either mode at any N.
+
+After the timed region (never inside it) the step CHECKS ITSELF: frames and per-pose losses of the first and last
+pose against the scalar C oracle (`verified`); a mismatch makes the process exit non-zero.
 
 Inputs (volume -- canonical and its converted copy --, poses) are resident in HBM
 before the timed region.  The step (diffus_amd.CapturedStep) is issued either eagerly or, by default, as a
@@ -49,6 +55,7 @@ import ctypes as C
 import glob
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -72,9 +79,14 @@ HBM_PEAK_GBS = 8000.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--poses", type=int, default=32, help="poses per GPU")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--poses", type=int, default=32, help="poses per GPU (weak scaling: the per-GPU batch is fixed)")
+    ap.add_argument("--poses-total", type=int, default=256,
+                    help="strong scaling: poses of the WHOLE job, sharded contiguously over the ranks (BASELINE config 4: 256)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="weak: --poses per GPU whatever N; strong: --poses-total split over the N ranks (SURVEY 8d config 4: "
+                         "P=256 fixed, P/k per GPU); auto = config 3 (weak, 32 poses) at N=1 and strong at N>1")
     ap.add_argument("--rays", type=int, default=256)
     ap.add_argument("--samples", type=int, default=512)
     ap.add_argument("--start", type=int, default=0, help="start crop (reference src/renderer.py:237-244)")
@@ -103,20 +115,27 @@ def parse_args(argv=None):
     ap.add_argument("--sync-gather", action="store_true",
                     help="N > 1: issue the loss all_gather on the compute stream (default: on its own stream, overlapping "
                          "the next step's kernels)")
-    ap.add_argument("--gather-every", type=int, default=8,
-                    help="N > 1: bucket the per-pose losses of this many steps into one all_gather (1 = a gather per step)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: bucket the per-pose losses of this many steps into one all_gather.  1 (default) = one gather "
+                         "per step, what BASELINE config 4 describes; K > 1 is an opt-in optimisation (losses arrive up to K-1 "
+                         "steps late) and is reported beside the headline as `bucketed_gather`")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: initialise torch.distributed even for a single rank, to exercise the N > 1 code path")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work at all: ranks rendezvous (gloo), gather stand-in losses and time empty steps; "
                          "checks the launcher / rendezvous / gather / max-over-ranks logic on a CPU-only box")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the after-the-timed-loop comparison of the step's frames and losses with the CPU oracle")
+    ap.add_argument("--no-scaling-legs", action="store_true",
+                    help="skip the extra timed legs (one-GPU base of the strong curve, weak figure, bucketed gather)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank exits 3 before the rendezvous
     return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# launcher: `python bench.py --gpus N` starts its own N ranks.  Nothing here touches the GPU (torch.cuda.device_count()
-# does not initialise it on this image); the children are ordinary child processes, never an exec of this one.
+# launcher: `python bench.py --gpus N` starts its own N ranks.  Nothing here touches the GPU or imports torch: the device
+# count comes from the visibility variables or the KFD topology in sysfs (each child checks its own LOCAL_RANK against what
+# HIP shows it and exits non-zero otherwise); the children are ordinary child processes, never an exec of this one.
 def _free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -125,42 +144,80 @@ def _free_port() -> int:
     return p
 
 
+def visible_gpus(environ=None, kfd_nodes="/sys/class/kfd/kfd/topology/nodes"):
+    """How many GPUs a child would see, without initialising HIP: the shortest of the *_VISIBLE_DEVICES lists if any is
+    set, else the KFD topology nodes that have SIMDs (CPU nodes have simd_count 0).  None = cannot tell."""
+    env = os.environ if environ is None else environ
+    listed = [len([x for x in env[k].split(",") if x.strip() != ""])
+              for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if env.get(k) is not None]
+    n = None
+    try:
+        n = 0
+        for node in os.listdir(kfd_nodes):
+            try:
+                with open(os.path.join(kfd_nodes, node, "properties")) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        n = None
+    if listed:
+        return min(listed) if n is None else min(min(listed), n)
+    return n
+
+
 def launch_ranks(args) -> int:
     n = args.gpus
     if args.dist_backend == "nccl" and not args.dry_run:
-        import torch
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) visible (use --dist-backend gloo to rehearse {n} ranks "
                   f"on one GPU)", file=sys.stderr)
             return 2
     port = _free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        # rank 0 owns stdout (the one JSON line); the other ranks' stdout goes to stderr
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc, kill_at = 0, None
-    pending = dict(enumerate(procs))
-    while pending:
-        for r, p in list(pending.items()):
-            code = p.poll()
-            if code is None:
-                continue
-            del pending[r]
-            if code != 0 and rc == 0:          # a rank failed: the others would wait in a collective for ever
-                rc = code if 0 < code < 256 else 1
-                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
-                for q in pending.values():
-                    q.terminate()
-                kill_at = time.time() + 10
-        if kill_at is not None and pending and time.time() > kill_at:
-            for q in pending.values():
-                q.kill()
-            kill_at = None
-        time.sleep(0.05)
+
+    def on_term(signum, frame):                       # SIGTERM to the launcher ends like Ctrl-C: the finally below runs
+        raise KeyboardInterrupt
+
+    old_term = signal.signal(signal.SIGTERM, on_term)
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            # rank 0 owns stdout (the one JSON line); the other ranks' stdout goes to stderr
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0 and rc == 0:          # a rank failed: the others would wait in a collective for ever
+                    rc = code if 0 < code < 256 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    pending = {}
+                    break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = rc or 130
+    finally:                                          # whatever ended the wait: no rank is left behind
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_kill = time.time() + 10
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.0, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        signal.signal(signal.SIGTERM, old_term)
     return rc
 
 
@@ -236,9 +293,9 @@ def cpu_baseline(budget_rays=64, budget_steps=256):
     return out
 
 
-def workload_key(args):
-    """What a PMC summary must have been collected on to speak for this run."""
-    return {"n": args.n, "poses": args.poses, "rays": args.rays, "samples": args.samples, "start": args.start,
+def workload_key(args, poses=None):
+    """What a PMC summary must have been collected on to speak for this run (`poses` = per GPU)."""
+    return {"n": args.n, "poses": args.poses if poses is None else poses, "rays": args.rays, "samples": args.samples, "start": args.start,
             "sampler": args.sampler, "layout": args.layout,
             "passes": 2 if (args.two_pass or args.unfused_loss) else 1}
 
@@ -256,15 +313,35 @@ def find_pmc_summary(key):
     return best
 
 
-def config_label(args, ngpu):
+def plan_poses(args, world):
+    """-> (scaling, P_total, poses per rank).  weak: --poses per GPU whatever N.  strong: --poses-total over the whole
+    job, P_total / N per rank.  auto: BASELINE config 3 at N = 1, strong at N > 1."""
+    scaling = args.scaling
+    if scaling == "auto":
+        scaling = "weak" if world == 1 else "strong"
+    if scaling == "weak":
+        return scaling, args.poses * world, args.poses
+    if args.poses_total % world:
+        raise SystemExit(f"bench.py: --poses-total {args.poses_total} does not split evenly over {world} ranks")
+    return scaling, args.poses_total, args.poses_total // world
+
+
+def config_label(args, ngpu, P_total=None):
     """Which BASELINE.json config (if any) this run is."""
+    if P_total is None:
+        P_total = plan_poses(args, ngpu)[1]
     shape2 = (args.rays, args.samples, args.start) == (256, 512, 0)
-    if args.n == 256 and shape2 and args.poses == 32:
-        return "BASELINE config 3" if ngpu == 1 else ("BASELINE config 4" if ngpu == 8 else f"BASELINE config 4 shape at {ngpu} of 8 GPUs")
-    if args.n == 256 and shape2 and args.poses == 1 and ngpu == 1:
-        return "BASELINE config 2"
+    if args.n == 256 and shape2:
+        if P_total == 256:                         # config 4: 256 poses over k GPUs, k = 1, 2, 4, 8 is its scaling curve
+            return "BASELINE config 4" if ngpu == 8 else f"BASELINE config 4 at {ngpu} of 8 GPUs"
+        if P_total == 32 and ngpu == 1:
+            return "BASELINE config 3"
+        if P_total == 32 * ngpu:
+            return f"BASELINE config 3 per GPU x {ngpu} GPUs (weak scaling)"
+        if P_total == 1 and ngpu == 1:
+            return "BASELINE config 2"
     if args.n == 512 and (args.rays, args.samples, args.start) == (512, 1024, 0):
-        return f"BASELINE config 5 shape ({args.poses} poses per 512^3 volume, one volume per GPU)"
+        return f"BASELINE config 5 shape ({P_total // ngpu} poses per 512^3 volume, one volume per GPU)"
     return "custom workload (not a BASELINE.json config)"
 
 
@@ -358,7 +435,7 @@ def losses_of_step(gathered_ring, world, K, P, k):
 
 
 def dry_run(args, world, rank):
-    """Launcher / rendezvous / gather / timing logic without any GPU work (CPU-only boxes, tests)."""
+    """Launcher / rendezvous / sharding / gather / timing logic without any GPU work (CPU-only boxes, tests)."""
     import torch
     import torch.distributed as dist
     if rank == args.fail_rank:
@@ -367,12 +444,12 @@ def dry_run(args, world, rank):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group("gloo")
-    P_total = args.poses * world
-    local = torch.arange(rank * args.poses, (rank + 1) * args.poses, dtype=torch.float32) + 1.0
+    scaling, P_total, P = plan_poses(args, world)
+    local = torch.arange(rank * P, (rank + 1) * P, dtype=torch.float32) + 1.0     # stand-in loss of pose p: p + 1
     allv = torch.empty(P_total)
     K = max(1, args.gather_every)
-    ring = [torch.zeros((K, args.poses)) for _ in range(2)]
-    gathered = [torch.zeros(world * K * args.poses) for _ in range(2)]
+    ring = [torch.zeros((K, P)) for _ in range(2)]
+    gathered = [torch.zeros(world * K * P) for _ in range(2)]
 
     def send(b):
         if world > 1:
@@ -395,15 +472,17 @@ def dry_run(args, world, rank):
     dt = time.perf_counter() - t0
     if args.steps > 0:
         last = args.steps - 1
-        allv.copy_(losses_of_step(gathered[ring_slot(last, K)[1]], world, K, args.poses, last) - 1000.0 * last)
+        allv.copy_(losses_of_step(gathered[ring_slot(last, K)[1]], world, K, P, last) - 1000.0 * last)
     else:
         allv.copy_(torch.arange(P_total, dtype=torch.float32) + 1.0)
     per_rank = [dt]
+    counts = [P]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        every = torch.empty(world, dtype=torch.float64)
+        t = torch.tensor([dt, float(P)], dtype=torch.float64)
+        every = torch.empty(2 * world, dtype=torch.float64)
         dist.all_gather_into_tensor(every, t)
-        per_rank = [float(x) for x in every]
+        per_rank = [float(x) for x in every[0::2]]
+        counts = [int(x) for x in every[1::2]]
         dt = max(per_rank)
     assert torch.equal(allv, torch.arange(P_total, dtype=torch.float32) + 1.0), "loss gather out of order"
     if rank == 0:
@@ -411,10 +490,176 @@ def dry_run(args, world, rank):
                           "world_size_observed": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
                           "per_rank_ms_per_step": [x / max(args.steps, 1) * 1e3 for x in per_rank],
-                          "higher_is_better": True, "scaling": "weak", "dry_run": True, "data": "none (dry run: no GPU work)"}))
+                          "higher_is_better": True, "scaling": scaling, "poses_total": P_total, "poses_per_rank": counts,
+                          "config": {"workload": config_label(args, world, P_total)},
+                          "dry_run": True, "data": "none (dry run: no GPU work)"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class StepRunner:
+    """One CapturedStep, its ring of per-pose loss buffers (one captured hipGraph per slot) and, with N > 1, the loss
+    all_gather on a communication stream.  `timed(steps, warmup)` is the contract's timed region: warm-up, barrier +
+    synchronize, EXACTLY `steps` steps, barrier + synchronize, MAX over ranks."""
+
+    def __init__(self, hp, args, dev, dist=None, world=1, K=1, eager=False):
+        import torch
+        self.torch, self.hp, self.args, self.dev, self.dist, self.world = torch, hp, args, dev, dist, world
+        P = hp.P
+        self.P = P
+        self.nccl = dist is not None and args.dist_backend == "nccl"
+        self.K = K = 1 if (dist is None or not self.nccl or args.sync_gather) else max(1, K)
+        self.losses_all = torch.empty((P * world,), dtype=torch.float32, device=dev)
+        self.ring = [torch.ones((K, P), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.graphs = [[None] * K, [None] * K]
+        self.graph = None
+        self.kstep = 0
+        side = torch.cuda.Stream()
+        if not eager:
+            try:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        hp.step()
+                side.synchronize()
+                for b in range(2):
+                    for j in range(K):
+                        hp.loss = self.ring[b][j]
+                        self.graphs[b][j] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.graphs[b][j], stream=side):
+                            hp.step()
+                self.graph = self.graphs[0][0]
+            except Exception as e:  # capture unsupported -> eager, and say so
+                print(f"hipGraph capture failed ({e!r}); running eagerly", file=sys.stderr)
+                self.graph = None
+        hp.loss = self.ring[0][0]
+        # The one collective of the path: all_gather of the per-pose losses over xGMI, on its own stream (an event per
+        # ring orders reuse).  Every gather has completed before the closing barrier of the timed region.
+        self.overlap = self.nccl and not args.sync_gather
+        if self.overlap:
+            try:
+                self.comm = torch.cuda.Stream()
+                self.gathered = [torch.ones((world * K * P,), dtype=torch.float32, device=dev) for _ in range(2)]
+                self.full_ev = [torch.cuda.Event() for _ in range(2)]
+                self.gather_ev = [torch.cuda.Event() for _ in range(2)]
+            except Exception as e:
+                print(f"overlapped gather unavailable ({e!r}); gathering on the compute stream", file=sys.stderr)
+                self.overlap = False
+
+    def send(self, b):                                 # ring b -> every rank, on the communication stream
+        torch = self.torch
+        self.full_ev[b].record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.full_ev[b])
+            self.dist.all_gather_into_tensor(self.gathered[b], self.ring[b].view(-1))
+            self.gather_ev[b].record(self.comm)
+
+    def step(self):
+        torch, K = self.torch, self.K
+        k = self.kstep
+        j, b = ring_slot(k, K) if self.overlap else (0, 0)
+        if self.overlap and j == 0 and k >= 2 * K:
+            torch.cuda.current_stream().wait_event(self.gather_ev[b])   # ring b is free again (its gather has finished)
+        if self.graph is not None:
+            self.graphs[b][j].replay()
+        else:
+            self.hp.loss = self.ring[b][j]
+            self.hp.step()
+        self.kstep = k + 1
+        if self.overlap:
+            if j == K - 1:
+                self.send(b)
+        elif self.nccl:
+            self.dist.all_gather_into_tensor(self.losses_all, self.ring[0][0])
+        elif self.dist is not None:                             # gloo rehearsal: through host memory
+            out = torch.empty(self.P * self.world, dtype=torch.float32)
+            self.dist.all_gather_into_tensor(out, self.ring[0][0].cpu())
+            self.losses_all.copy_(out)
+
+    def barrier(self):
+        torch = self.torch
+        if self.overlap:
+            if self.kstep % self.K:                             # a part-filled ring goes out too
+                self.send(ring_slot(self.kstep - 1, self.K)[1])
+            torch.cuda.current_stream().wait_stream(self.comm)  # every gather issued so far is part of the step count
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def last_slot(self):
+        j, b = ring_slot(self.kstep - 1, self.K) if self.overlap else (0, 0)
+        return self.ring[b][j]
+
+    def timed(self, steps, warmup):
+        """-> dict(dt = seconds of the timed region, MAX over ranks; per_rank_ms; host_ms; world_seen)."""
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        host_ms = (time.perf_counter() - t0) * 1e3 / steps    # host time to ENQUEUE one step (no device wait)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        per_rank_ms = [dt / steps * 1e3]
+        world_seen = 1
+        if dist is not None:
+            on = self.dev if self.nccl else "cpu"
+            mine = torch.tensor([dt], dtype=torch.float64, device=on)
+            every = torch.empty(self.world, dtype=torch.float64, device=on)
+            dist.all_gather_into_tensor(every, mine)
+            per_rank_ms = [float(x) / steps * 1e3 for x in every.cpu()]
+            dt = float(every.max().item())                      # MAX over ranks
+            world_seen = dist.get_world_size()
+            if self.overlap:                                    # the last step's slot of every rank, in pose order
+                last = self.kstep - 1
+                self.losses_all.copy_(losses_of_step(self.gathered[ring_slot(last, self.K)[1]], self.world, self.K, self.P, last))
+        else:
+            self.losses_all.copy_(self.last_slot())
+        return {"dt": dt, "per_rank_ms": per_rank_ms, "host_ms": host_ms, "world_seen": world_seen}
+
+
+def verify_step(args, vol_np, src_all, dirs_all, local_lo, hp, losses_all, frame_poses, loss_poses):
+    """The timed step checks what it computed, OUTSIDE the timed region: frames of `frame_poses`
+    (indices into this rank's shard) and per-pose losses of `loss_poses` (global pose indices, read from the GATHERED
+    vector, so a gather that scrambles the pose order fails here) against the CPU oracle (oracle/diffus_oracle.c: the
+    restatement of reference src/renderer.py:201-275; echo series in float64).  Frame tolerance: 2e-5 max-norm-relative,
+    widened on fans that graze the skull to 16 input roundings' worth (oracle/conditioning.py -- the reference's own
+    float32 LU is 3e-5 .. 1.4e-4 from its float64 result on such rays, golden G17).  loss_p = sum(frame_p^2): 1e-4."""
+    import numpy as np
+    from oracle import oracle as orc
+    from oracle.conditioning import frame64_and_tolerance
+    orc.build()
+    cache = {}
+
+    def oracle_frame(p):
+        if p not in cache:
+            if args.start == 0:
+                f64, tol, _ = frame64_and_tolerance(vol_np, src_all[p], dirs_all[p], args.samples, args.alpha, sampler=args.sampler)
+            else:       # start crop + median: the float32 scalar oracle, fixed tolerance
+                f64 = orc.plot_beam_frame(vol_np, src_all[p], dirs_all[p], args.samples, args.alpha, args.start,
+                                          sampler=args.sampler)[3].astype(np.float64)
+                tol = 1e-4
+            cache[p] = (f64, tol)
+        return cache[p]
+
+    frames, losses, ok = [], [], True
+    for q in frame_poses:
+        f64, tol = oracle_frame(local_lo + q)
+        err = float(np.abs(hp.frame[q].cpu().numpy() - f64).max() / max(np.abs(f64).max(), 1e-300))
+        frames.append({"pose": int(local_lo + q), "rel_err": err, "tol": tol})
+        ok &= err <= tol
+    lv = losses_all.cpu().numpy()
+    for p in loss_poses:
+        want = float((oracle_frame(p)[0] ** 2).sum())
+        err = abs(float(lv[p]) - want) / max(abs(want), 1e-300)
+        losses.append({"pose": int(p), "rel_err": err, "tol": 1e-4})
+        ok &= err <= 1e-4
+    return {"oracle": "oracle/diffus_oracle.c + oracle/conditioning.py (CPU restatement of reference src/renderer.py:201-275, "
+                      "echo series in float64)",
+            "frames": frames, "losses": losses,
+            "max_rel_err": max([x["rel_err"] for x in frames + losses] or [0.0]), "ok": bool(ok)}
 
 
 def worker(args):
@@ -441,6 +686,9 @@ def worker(args):
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
+            if local >= torch.cuda.device_count():              # the launcher does not touch HIP: every rank checks itself
+                print(f"bench.py: rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+                sys.exit(2)
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -453,132 +701,97 @@ def worker(args):
     ngpu = world
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    P_total = args.poses * ngpu
+    scaling, P_total, P = plan_poses(args, world)
     # config 5 (--n 512): one distinct volume per GPU -- the phantom variant (tumour position) is the rank
-    vol = torch.from_numpy(phantom(args.n, variant=rank if args.n >= 512 else 0)).to(dev)
-    src_all, dirs_all = pose_ring(args.n, P_total, args.rays)
-    lo = rank * args.poses
-    src = torch.from_numpy(src_all[lo:lo + args.poses]).to(dev).contiguous()
-    dirs = torch.from_numpy(dirs_all[lo:lo + args.poses]).to(dev).contiguous()
+    vol_np = phantom(args.n, variant=rank if args.n >= 512 else 0)
+    vol = torch.from_numpy(vol_np).to(dev)
+
+    def shard(total, per_rank):
+        s_all, d_all = pose_ring(args.n, total, args.rays)
+        lo = rank * per_rank
+        return (s_all, d_all, lo, torch.from_numpy(s_all[lo:lo + per_rank]).to(dev).contiguous(),
+                torch.from_numpy(d_all[lo:lo + per_rank]).to(dev).contiguous())
+
+    src_all, dirs_all, lo, src, dirs = shard(P_total, P)
 
     def make_step(s, d, want_gvol=not args.no_gvol, learnable=args.learnable_volume):
         return CapturedStep(vol, s, d, args.samples, args.alpha, args.sampler, start=args.start, want_gvol=want_gvol,
                             layout=args.layout, sparse=not args.dense_grad, persistent=not args.memset_grad,
                             learnable_volume=learnable, fused_loss=not args.unfused_loss, one_pass=not args.two_pass)
 
+    # --- the headline: eager launches, or one captured hipGraph per loss slot (compute) + the collective ---
+    # N > 1: the per-pose losses leave in one all_gather per step on the communication stream (ring of K = 1 slot, twice:
+    # the gather of step k reads its buffer while step k+1 already writes the other one).  --gather-every K buckets K
+    # steps into one collective; that variant is timed as well and reported beside the headline.
     hp = make_step(src, dirs)
-    losses_all = torch.empty((P_total,), dtype=torch.float32, device=dev)
-
-    # --- the step: eager launches, or one captured hipGraph (compute) + the collective ---
-    # Two loss buffers, used alternately (and one captured graph per buffer): with N > 1 the gather of step k reads
-    # its buffer on the communication stream while step k+1 already writes the other one.
-    # Loss buffers: a ring of K slots, twice (one graph per slot, each writing its own slot).  N > 1: the per-pose
-    # losses of K consecutive steps leave in ONE all_gather (K x P x 4 bytes per rank) on the communication stream
-    # while the next K steps fill the other ring -- a bucketed collective: a small RCCL all_gather is ~12 us of kernel
-    # and launch gaps on the compute stream, or ~40 us of c10d host time on a stream of its own, against a 0.07 ms
-    # step (measured with a one-rank RCCL group: 0.085 / 0.086 ms per step with a gather every step).
-    nccl = dist is not None and args.dist_backend == "nccl"
-    K = 1 if (dist is None or not nccl or args.sync_gather) else max(1, args.gather_every)
-    ring = [torch.ones((K, args.poses), dtype=torch.float32, device=dev) for _ in range(2)]
-    graph = None
-    graphs = [[None] * K, [None] * K]
-    side = torch.cuda.Stream()
-    if not args.eager:
-        try:
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    hp.step()
-            side.synchronize()
-            for b in range(2):
-                for j in range(K):
-                    hp.loss = ring[b][j]
-                    graphs[b][j] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graphs[b][j], stream=side):
-                        hp.step()
-            graph = graphs[0][0]
-        except Exception as e:  # capture unsupported -> eager, and say so
-            print(f"hipGraph capture failed ({e!r}); running eagerly", file=sys.stderr)
-            graph = None
-    hp.loss = ring[0][0]
-
-    # The one collective of the path: all_gather of the per-pose losses over xGMI, on its own stream (an event per ring
-    # orders reuse).  Every gather has completed before the closing barrier of the timed region.
-    overlap = nccl and not args.sync_gather
-    if overlap:
-        try:
-            comm = torch.cuda.Stream()
-            gathered = [torch.ones((world * K * args.poses,), dtype=torch.float32, device=dev) for _ in range(2)]
-            full_ev = [torch.cuda.Event() for _ in range(2)]
-            gather_ev = [torch.cuda.Event() for _ in range(2)]
-        except Exception as e:
-            print(f"overlapped gather unavailable ({e!r}); gathering on the compute stream", file=sys.stderr)
-            overlap = False
-    kstep = [0]
-
-    def send(b):                                   # ring b -> every rank, on the communication stream
-        main = torch.cuda.current_stream()
-        full_ev[b].record(main)
-        with torch.cuda.stream(comm):
-            comm.wait_event(full_ev[b])
-            dist.all_gather_into_tensor(gathered[b], ring[b].view(-1))
-            gather_ev[b].record(comm)
-
-    def step():
-        k = kstep[0]
-        j, b = ring_slot(k, K) if overlap else (0, 0)
-        if overlap and j == 0 and k >= 2 * K:
-            torch.cuda.current_stream().wait_event(gather_ev[b])   # ring b is free again (its gather has finished)
-        if graph is not None:
-            graphs[b][j].replay()
-        else:
-            hp.loss = ring[b][j]
-            hp.step()
-        kstep[0] = k + 1
-        if overlap:
-            if j == K - 1:
-                send(b)
-        elif nccl:
-            dist.all_gather_into_tensor(losses_all, ring[0][0])
-        elif dist is not None:                                  # gloo rehearsal: through host memory
-            out = torch.empty(P_total, dtype=torch.float32)
-            dist.all_gather_into_tensor(out, ring[0][0].cpu())
-            losses_all.copy_(out)
-
-    def barrier():
-        if overlap:
-            if kstep[0] % K:                                    # a part-filled ring goes out too
-                send(ring_slot(kstep[0] - 1, K)[1])
-            torch.cuda.current_stream().wait_stream(comm)       # every gather issued so far is part of the step count
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    host_ms = (time.perf_counter() - t0) * 1e3 / args.steps   # host time to ENQUEUE one step (no device wait)
-    barrier()
-    dt = time.perf_counter() - t0
-    per_rank_ms = [dt / args.steps * 1e3]
-    world_seen = 1
-    if dist is not None:
-        on = dev if args.dist_backend == "nccl" else "cpu"
-        mine = torch.tensor([dt], dtype=torch.float64, device=on)
-        every = torch.empty(world, dtype=torch.float64, device=on)
-        dist.all_gather_into_tensor(every, mine)
-        per_rank_ms = [float(x) / args.steps * 1e3 for x in every.cpu()]
-        dt = float(every.max().item())                          # MAX over ranks
-        world_seen = dist.get_world_size()
-        if overlap:                                             # the last step's slot of every rank, in pose order
-            last = kstep[0] - 1
-            losses_all.copy_(losses_of_step(gathered[ring_slot(last, K)[1]], world, K, args.poses, last))
-        # every rank must hold all P losses, in pose order, and they must be finite
-        assert torch.isfinite(losses_all).all() and float(losses_all.abs().min()) > 0, "loss gather failed"
+    run = StepRunner(hp, args, dev, dist, world, K=args.gather_every, eager=args.eager)
+    res = run.timed(args.steps, args.warmup)
+    dt = res["dt"]
     ray_steps = P_total * args.rays * args.samples
     value = ray_steps * args.steps / dt
+    if dist is not None:      # every rank must hold all P losses, in pose order, and they must be finite
+        assert torch.isfinite(run.losses_all).all() and float(run.losses_all.abs().min()) > 0, "loss gather failed"
+
+    # --- the step checks itself (outside the timed region): rank 0's first and last pose as frames, and the gathered
+    # losses of those two plus the LAST pose of the whole job (the last rank's, so the gather's pose order is covered) ---
+    verified = None
+    if rank == 0 and not args.no_verify:
+        try:
+            loss_poses = sorted({0, P - 1, P_total - 1})
+            # (P * 9) // 16: pose 18 of config 3, a fan that grazes the skull -- the hard case is checked too
+            verified = verify_step(args, vol_np, src_all, dirs_all, lo, hp, run.losses_all,
+                                   sorted({0, (P * 9) // 16, P - 1}), loss_poses)
+        except Exception as e:      # the oracle could not be built or run: say so, never claim a check that did not happen
+            verified = {"ok": False, "failed": repr(e)}
+
+    # --- a thicker window: the same step replayed >= 200 times (the driver's own K may be as small as 20) ---
+    extra = {}
+    if dist is None and args.steps < 200:
+        r200 = run.timed(200, 0)
+        extra["replays_200"] = {"ms_per_step": r200["dt"] / 200 * 1e3, "value": ray_steps * 200 / r200["dt"]}
+
+    # --- the other leg of the scaling story, measured in the same run ---
+    #   strong (N > 1): the weak figure (--poses per GPU) and the one-GPU leg of the strong curve (all P_total poses on
+    #                   rank 0's GPU alone, no collective) -> speedup_vs_one_gpu
+    #   N = 1, auto:    BASELINE config 4 at 1 of 8 GPUs (P_total poses on this GPU) = the base of the strong curve
+    scale_info = {}
+    if not args.no_scaling_legs:
+        def one_gpu_leg(total):
+            s_all, d_all = pose_ring(args.n, total, args.rays)
+            h = make_step(torch.from_numpy(s_all).to(dev).contiguous(), torch.from_numpy(d_all).to(dev).contiguous())
+            r = StepRunner(h, args, dev, None, 1, eager=args.eager).timed(args.steps, args.warmup)
+            return {"poses_total": total, "n_gpus": 1, "ms_per_step": r["dt"] / args.steps * 1e3,
+                    "value": total * args.rays * args.samples * args.steps / r["dt"],
+                    "workload": config_label(args, 1, total)}
+        if scaling == "strong" and world > 1:
+            if P != args.poses:
+                _, _, _, s_w, d_w = shard(args.poses * world, args.poses)
+                rw = StepRunner(make_step(s_w, d_w), args, dev, dist, world, K=args.gather_every, eager=args.eager)
+                w = rw.timed(args.steps, args.warmup)
+                scale_info["weak"] = {"poses_per_gpu": args.poses, "poses_total": args.poses * world,
+                                      "ms_per_step": w["dt"] / args.steps * 1e3,
+                                      "value": args.poses * world * args.rays * args.samples * args.steps / w["dt"]}
+                del rw
+            else:
+                scale_info["weak"] = {"poses_per_gpu": P, "poses_total": P_total, "ms_per_step": dt / args.steps * 1e3,
+                                      "value": value, "note": "identical to the headline at this N"}
+            if rank == 0:
+                base = one_gpu_leg(P_total)
+                scale_info["strong"] = {"poses_total": P_total, "poses_per_gpu": P, "one_gpu": base,
+                                        "speedup_vs_one_gpu": value / base["value"]}
+            dist.barrier()
+        elif world == 1 and args.scaling == "auto" and config_label(args, 1, P_total) == "BASELINE config 3":
+            scale_info["strong_base"] = one_gpu_leg(args.poses_total)
+            scale_info["note"] = ("`value` is BASELINE config 3 (32 poses on one GPU).  With --gpus N > 1 this script shards "
+                                  f"config 4's {args.poses_total} poses over the N ranks (strong scaling); the one-GPU leg of THAT "
+                                  "curve is strong_base.value, not `value`")
+        if args.gather_every == 1 and dist is not None and run.nccl and not args.sync_gather:
+            rb = StepRunner(make_step(src, dirs), args, dev, dist, world, K=8, eager=args.eager)
+            bk = rb.timed(args.steps, args.warmup)
+            scale_info["bucketed_gather"] = {"gather_every": 8, "ms_per_step": bk["dt"] / args.steps * 1e3,
+                                             "value": ray_steps * args.steps / bk["dt"],
+                                             "note": "opt-in (--gather-every 8): the losses of 8 steps leave in one all_gather"}
+            del rb
 
     # --- per-kernel device time (HIP events on the launch stream), rank-local ---
     it = max(10, min(args.steps, 50))
@@ -596,7 +809,7 @@ def worker(args):
         hp.finish_grad()
     if args.start > 0:
         k_ms["note"] = "start > 0: the forward and scan figures include the per-pose median launch"
-    local_rs = args.poses * args.rays * args.samples
+    local_rs = P * args.rays * args.samples
     b = BYTES[args.sampler]
     kern = {k: v for k, v in k_ms.items() if isinstance(v, dict)}
     dom = max(kern, key=lambda k: kern[k]["mean"])
@@ -605,7 +818,7 @@ def worker(args):
     # HBM-side bytes per launch from the committed PMC passes, only if they were collected on exactly this workload
     traffic = measured = limiter = pmc_file = None
     evidence = None
-    found = find_pmc_summary(workload_key(args))
+    found = find_pmc_summary(workload_key(args, P))
     if found is not None:
         pmc_file, pm = found
         e = pm.get("kernels", {}).get(dom, {})
@@ -614,6 +827,8 @@ def worker(args):
         evidence = {k: e[k] for k in ("l2_hit_rate", "valu_busy_frac", "wait_any_frac_of_wave", "active_valu_frac_of_wave",
                                       "lds_busy_frac", "insts_valu_per_wave", "insts_lds_per_wave", "atomic_GBs", "vgpr",
                                       "avg_us") if k in e}
+        if "step_valu_wave_insts" in pm:
+            evidence["step_valu_wave_insts"] = pm["step_valu_wave_insts"]
         if traffic is not None:
             measured = traffic / (dom_ms * 1e-3) / 1e9
     if measured is not None and measured / HBM_PEAK_GBS >= 0.4:
@@ -642,25 +857,27 @@ def worker(args):
         hp1p.step()
     sp_pose = time_events(hp1p.step, 20)
 
+    ok = True
     if rank == 0:
         grads = "d/dsource, d/ddirections" if args.no_gvol else "d/dvolume, d/dsource, d/ddirections"
+        K, overlap = run.K, run.overlap
         out = {
             "metric": "ray-steps/sec fwd+bwd",
             "value": value,
             "unit": "ray-steps/s",
             "n_gpus": ngpu,
-            "world_size_observed": world_seen,
+            "world_size_observed": res["world_seen"],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_ms_per_step": res["per_rank_ms"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"{config_label(args, ngpu)}: {args.poses} poses/GPU x "
+                "workload": (f"{config_label(args, ngpu, P_total)}: {P_total} poses ({P} per GPU) x "
                              f"{args.rays} rays x {args.samples} steps through a {args.n}^3 analytic head phantom; "
                              f"{args.sampler} sampling; forward + sum-of-squares loss + backward ({grads}) "
                              f"+ canonical gradient + per-pose loss gather"),
@@ -668,19 +885,20 @@ def worker(args):
                          "fused: dL/dframe formed inside the backward, per-pose loss summed by its closing blocks"),
                 "passes": ("one (diffus_render_step_mse: the adjoint-scan kernel also writes the frame; no forward launch)"
                            if one_pass else "two (diffus_render_fwd, then the backward)"),
-                "poses_per_gpu": args.poses, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
+                "poses_per_gpu": P, "poses_total": P_total, "rays": args.rays, "samples": args.samples,
                 "volume": [args.n] * 3, "sampler": args.sampler, "start": args.start, "alpha": args.alpha,
                 "layout": args.layout,
                 "volume_conversion": ("inside every step (learnable volume)" if args.learnable_volume else
                                       "once, outside the timed region (constant volume; see callers.learnable_volume)") if args.layout != "canonical" else "none",
-                "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": "hipGraph replay" if graph is not None else "eager",
+                "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": "hipGraph replay" if run.graph is not None else "eager",
                 "parallelism": f"poses sharded x{ngpu}, volume replicated" if args.n < 512 else f"one volume per GPU x{ngpu} (replicas only)",
-                "host_enqueue_ms_per_step": host_ms,
+                "host_enqueue_ms_per_step": res["host_ms"],
                 "loss_gather": ("none (1 GPU)" if dist is None else
-                                (f"one all_gather per {K} steps ({K} x P losses per rank) on its own stream, overlapping the next steps"
+                                (f"one all_gather per {K} step(s) ({K} x P losses per rank) on its own stream, overlapping the next step(s)"
                                  if overlap else "all_gather every step on the compute stream")),
                 "dist_backend": None if dist is None else args.dist_backend,
             },
+            "verified": verified,
             "roofline": {
                 "bound": bound,
                 "kernel": dom,
@@ -707,6 +925,8 @@ def worker(args):
                             "pose_gradient_only_ms": sp_pose["median"],
                             "value": args.rays * args.samples / (min(sp["median"], (sp_graph or sp)["median"]) * 1e-3)},
         }
+        out.update(extra)
+        out.update(scale_info)
         if ngpu == 1 and not args.no_callers:
             try:
                 out["callers"] = callers_legs(args, vol, dev)
@@ -719,10 +939,15 @@ def worker(args):
                 out["cpu_baseline"] = {"value": None, "unit": "ray-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if verified is not None and not verified.get("ok", False):
+            print(f"bench.py: the timed step does NOT match the oracle: {verified}", file=sys.stderr)
+            ok = False
     os.close(json_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(4)
 
 
 def main():

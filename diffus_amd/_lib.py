@@ -21,6 +21,7 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
            "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats", "diffus_rows_conv1d",
            "diffus_prop_single_ray", "diffus_propagate_rays", "diffus_sample_points")
 
+ABI_VERSION = 3          # include/diffus_hip.h DIFFUS_ABI_VERSION
 DIFFUS_F32, DIFFUS_F64 = 0, 1
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
@@ -117,7 +118,7 @@ def load():
     lib.diffus_propagate_rays.argtypes = [vp, i, i, vp, vp]
     lib.diffus_sample_points.restype = i
     lib.diffus_sample_points.argtypes = [vp, i, i, i, i, vp, C.c_long, i, vp, vp, vp]
-    if lib.diffus_abi_version() != 1:
+    if lib.diffus_abi_version() != ABI_VERSION:
         raise DiffusError("libdiffus_hip.so ABI version mismatch")
     _lib = lib
     return lib

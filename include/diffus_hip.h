@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DIFFUS_ABI_VERSION 1
+#define DIFFUS_ABI_VERSION 3 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points */
 
 /* error codes */
 #define DIFFUS_OK            0

@@ -431,6 +431,26 @@ def main():
                    sim_x=qx.numpy(), sim_y=qy.numpy(), sim_z=qz.numpy(), sim_r=qr.numpy(), sim_mri=z1.numpy())
         save("g16_api_functions", **out)
 
+    # ---- G17: ILL-CONDITIONED rays of the benchmark workload (config 3), through the reference's dense solves ----------
+    # Rays that graze the skull cross air <-> bone several times: |r| -> 0.9997, the transfer matrices are nearly
+    # singular and ANY float32 evaluation (the reference's LU included) carries cond x eps of noise.  Recorded here so
+    # that the tolerance of the full-size parity tests is the reference's own float32 noise on exactly these rays, not a
+    # guess: impedance along the ray (trilinear samples of the 256^3 phantom, from the oracle -- the reference has no
+    # trilinear sampler) -> the reference's compute_reflection_coeff + compute_echo_traces in fp32 and fp64.
+    if want("g17"):
+        from oracle import oracle as orc
+        v = phantom(256)
+        s, d = pose_ring(256, 32, 256)
+        picks = [(18, 4), (30, 22), (0, 128)]            # two grazing rays, one ordinary ray
+        Z = np.stack([orc.sample_trilinear(v, s[p], d[p][r:r + 1], 512)[0] for p, r in picks])
+        Z32 = torch.from_numpy(Z)
+        r32 = ref.UltrasoundRenderer.compute_reflection_coeff(Z32[:, :-1], Z32[:, 1:])
+        with quiet():
+            e32, _ = ref.compute_echo_traces(r32)
+            e64, _ = ref.compute_echo_traces(r32.double())
+        save("g17_grazing_rays", picks=np.array(picks, dtype=np.int64), Z=Z, r=r32.numpy(), echo32=e32.numpy(),
+             echo64=e64.numpy())
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

@@ -49,6 +49,68 @@ def test_bucketed_loss_gather_delivers_every_steps_losses_in_pose_order(steps, e
     assert _json_line(r.stdout)["n_gpus"] == 2
 
 
+def test_default_scaling_is_strong_config_4_over_the_ranks():
+    """P = 256 fixed, P / k poses per GPU.  `--gpus 2` must shard 128 poses per rank, in pose order
+    (the dry run asserts that the gathered stand-in losses come back as pose 0..255), and say "strong"."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "3"], env=_env(),
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert out["scaling"] == "strong" and out["poses_total"] == 256 and out["poses_per_rank"] == [128, 128]
+    assert out["config"]["workload"] == "BASELINE config 4 at 2 of 8 GPUs"
+    # weak on request: --poses per GPU whatever N
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "3", "--scaling", "weak", "--poses", "5"],
+                       env=_env(), capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert out["scaling"] == "weak" and out["poses_total"] == 10 and out["poses_per_rank"] == [5, 5]
+
+
+def test_plan_poses_and_one_gpu_default():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert bench.plan_poses(a, 1) == ("weak", 32, 32)                 # N = 1: BASELINE config 3
+    assert [bench.plan_poses(a, k)[1:] for k in (2, 4, 8)] == [(256, 128), (256, 64), (256, 32)]
+    assert bench.plan_poses(bench.parse_args(["--scaling", "strong"]), 1) == ("strong", 256, 256)
+    with pytest.raises(SystemExit):
+        bench.plan_poses(bench.parse_args(["--poses-total", "250"]), 4)
+    assert a.gather_every == 1 and a.steps >= 200                     # ADVICE r2 / VERDICT r2 item 9
+
+
+def test_launcher_counts_gpus_without_touching_hip(tmp_path):
+    """the launcher must not call torch.cuda.  The count comes from the visibility variables / KFD sysfs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):                # two CPU nodes, three GPUs
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\n")
+    assert bench.visible_gpus({}, str(nodes)) == 3
+    assert bench.visible_gpus({"HIP_VISIBLE_DEVICES": "0,1"}, str(nodes)) == 2
+    assert bench.visible_gpus({"ROCR_VISIBLE_DEVICES": "0,1,2,3,4,5"}, str(nodes)) == 3
+    assert bench.visible_gpus({}, str(tmp_path / "missing")) is None
+    assert bench.visible_gpus({"HIP_VISIBLE_DEVICES": "3"}, str(tmp_path / "missing")) == 1
+    import inspect
+    assert "torch" not in inspect.getsource(bench.launch_ranks)
+
+
+def test_sigterm_to_the_launcher_takes_the_ranks_down():
+    """a SIGTERM (or Ctrl-C) to the launcher must not orphan the ranks."""
+    import signal
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2000000", "--poses-total", "2"], env=_env(),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(6)
+    kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+    assert len(kids) == 2, kids
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=60)
+    assert p.returncode != 0
+    time.sleep(0.5)
+    for k in kids:
+        assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
+
+
 def test_ring_helpers():
     sys.path.insert(0, ROOT)
     import torch
@@ -92,7 +154,11 @@ def test_labels_and_pmc_lookup_follow_the_workload(tmp_path, monkeypatch):
     a = bench.parse_args([])
     assert bench.config_label(a, 1) == "BASELINE config 3"
     assert bench.config_label(a, 8) == "BASELINE config 4"
-    assert "config 4" in bench.config_label(a, 2)
+    assert bench.config_label(a, 2) == "BASELINE config 4 at 2 of 8 GPUs"
+    # 256 poses on ONE GPU is the k = 1 leg of config 4's scaling curve, not a "custom workload" 
+    assert bench.config_label(bench.parse_args(["--scaling", "strong"]), 1) == "BASELINE config 4 at 1 of 8 GPUs"
+    assert bench.config_label(bench.parse_args(["--poses", "256"]), 1) == "BASELINE config 4 at 1 of 8 GPUs"
+    assert "weak" in bench.config_label(bench.parse_args(["--scaling", "weak"]), 4)
     a5 = bench.parse_args(["--n", "512", "--rays", "512", "--samples", "1024", "--poses", "8"])
     assert "config 5" in bench.config_label(a5, 1) and "config 3" not in bench.config_label(a5, 1)
     odd = bench.parse_args(["--n", "512"])

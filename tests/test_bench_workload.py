@@ -1,0 +1,145 @@
+"""The entry point bench.py times, value-checked AT THE SIZE IT IS TIMED AT.
+
+`CapturedStep` at exactly the headline workload -- 256^3 phantom, 32 poses x 256 rays x 512 steps, trilinear, paired
+volume, persistent sparse hand-back, the one-pass `diffus_render_step_mse`, captured as a hipGraph and replayed twice --
+against
+  * the oracle (oracle/diffus_oracle.c, restating reference src/renderer.py:201-275), echo series in float64: frames
+    <= 2e-5 max-norm-relative -- on the poses whose fan grazes the skull (echo = b/d with d nearly cancelled, |echo| > 100)
+    <= 16 input roundings' worth (oracle/conditioning.py; the reference's own float32 LU is 3.3e-5 / 1.4e-4 from its
+    float64 result on two such rays, golden G17) --, per-pose losses <= 1e-4;
+  * the two-call `render_poses` autograd path (diffus_render_fwd + diffus_render_bwd): gsrc / gdirs / gvol <= 1e-4;
+  * float64 torch autograd over oracle/autograd_ref.py for one pose: <= 1e-3.
+The same at 256 poses (BASELINE config 4 at 1 of 8 GPUs): forward + loss."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxnorm_rel
+from diffus_amd.phantom import phantom, pose_ring
+
+pytestmark = pytest.mark.gpu
+
+N, R, S, ALPHA = 256, 256, 512, 1e-4
+
+
+@pytest.fixture(scope="module")
+def vol256():
+    return phantom(N)
+
+
+def _captured(vol, src, dirs):
+    import diffus_amd as da
+    step = da.CapturedStep(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), S, ALPHA, "trilinear",
+                           layout="paired")
+    assert step.persistent and step.fused_loss and step.one_pass            # what bench.py's default line runs
+    step.capture()
+    step.replay()
+    step.replay()                      # twice: the persistent gradient tensor must equal ONE step's gradient, not two
+    torch.cuda.synchronize()
+    return step
+
+
+def test_config3_one_pass_step_values(oracle, vol256):
+    import diffus_amd as da
+    P = 32
+    src, dirs = pose_ring(N, P, R)
+    vol = torch.from_numpy(vol256).cuda()
+    step = _captured(vol, src, dirs)
+    frames = step.frame.cpu().numpy()
+    losses = step.loss.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(frames)) and np.all(frames[:, :, 0] == 0)
+    from oracle.conditioning import frame64_and_tolerance
+    tols = {}
+    for p in (0, 6, 9, 18, 27, 30, 31):                 # 6, 18, 30: fans that graze the skull (ill-conditioned rays)
+        f64, tol, _ = frame64_and_tolerance(vol256, src[p], dirs[p], S, ALPHA)
+        tols[p] = tol
+        assert maxnorm_rel(frames[p], f64) < tol, (p, tol)
+        want = float((f64 ** 2).sum())
+        assert abs(losses[p] - want) <= 1e-4 * want, (p, losses[p], want)
+    assert tols[0] == tols[9] == tols[27] == tols[31] == 2e-5 and tols[18] > 1e-4      # the tolerance is earned, not blanket
+    for p in (0, 9, 27, 31):                            # ... and the float32 oracle itself on the well-conditioned ones
+        fo = oracle.plot_beam_frame(vol256, src[p], dirs[p], S, ALPHA, 0, sampler="trilinear")[3]
+        assert maxnorm_rel(frames[p], fo) < 2e-5, p
+    # every pose's loss against its own frame (the fused sum), all 32
+    own = (frames.astype(np.float64) ** 2).sum((1, 2))
+    assert np.all(np.abs(losses - own) <= 1e-5 * own)
+
+    # the three gradients against the two-call path (forward launch + diffus_render_bwd) on the same inputs
+    v2 = vol.clone().requires_grad_(True)
+    s2 = torch.from_numpy(src).cuda().requires_grad_(True)
+    d2 = torch.from_numpy(dirs).cuda().requires_grad_(True)
+    f2 = da.render_poses(v2, s2, d2, S, ALPHA, sampler="trilinear", layout="paired")
+    (f2 ** 2).sum().backward()
+    assert float((step.frame - f2.detach()).abs().max()) <= 2e-5 * float(f2.detach().abs().max())
+    assert float((step.gsrc - s2.grad).abs().max()) <= 1e-4 * float(s2.grad.abs().max())
+    assert float((step.gdirs - d2.grad).abs().max()) <= 1e-4 * float(d2.grad.abs().max())
+    assert float((step.gvol - v2.grad).abs().max()) <= 1e-4 * float(v2.grad.abs().max())
+    assert torch.equal(step.gvol != 0, v2.grad != 0) or \
+        int(((step.gvol != 0) != (v2.grad != 0)).sum()) <= 1e-4 * int((v2.grad != 0).sum())   # same support (up to underflow)
+    assert torch.all(step.gvol_k == 0)                                       # the bricked scratch is all-zero again
+    del v2, f2
+
+
+def test_config3_one_pose_of_the_batch_vs_float64_autograd(vol256):
+    """One pose of the 32-pose captured batch against float64 autograd: frame, d/dsource, d/ddirections, and d/dvolume
+    of that pose alone (a one-pose CapturedStep of the same launch shape per ray, same kernels)."""
+    from oracle import autograd_ref as ar
+    P, pose = 32, 21
+    src, dirs = pose_ring(N, P, R)
+    vol = torch.from_numpy(vol256).cuda()
+    step = _captured(vol, src, dirs)
+    got_f = step.frame[pose].cpu().numpy()
+    got_s = step.gsrc[pose].cpu().numpy()
+    got_d = step.gdirs[pose].cpu().numpy()
+    one = _captured(vol, src[pose:pose + 1], dirs[pose:pose + 1])
+    # the pose's d/dsource does not depend on what else is in the batch
+    assert maxnorm_rel(one.gsrc[0].cpu().numpy(), got_s) < 1e-6
+    gv = one.gvol.cpu()
+    del step, one
+    torch.cuda.empty_cache()
+    v64 = torch.from_numpy(vol256).double().requires_grad_(True)
+    s64 = torch.from_numpy(src[pose]).double().requires_grad_(True)
+    d64 = torch.from_numpy(dirs[pose]).double().requires_grad_(True)
+    fr = ar.render(v64, s64, d64, S, ALPHA, 0, "trilinear", points="f32")
+    (fr ** 2).sum().backward()
+    assert maxnorm_rel(got_f, fr.detach().numpy()) < 2e-5         # pose 21 is well conditioned (sens 5e-7)
+    assert maxnorm_rel(got_s, s64.grad.numpy()) < 1e-3
+    assert maxnorm_rel(got_d, d64.grad.numpy()) < 1e-3
+    den = float(v64.grad.abs().max())
+    err = max(float((gv[i:i + 64].double() - v64.grad[i:i + 64]).abs().max()) for i in range(0, N, 64))
+    assert den > 0 and err / den < 1e-3, err / den
+
+
+def test_config4_one_gpu_leg_256_poses(oracle, vol256):
+    """BASELINE config 4 at 1 of 8 GPUs: all 256 poses in one captured one-pass step (131 072 wavefronts, 16 512 patch
+    blocks ...): frames and losses against the oracle, the gradients against the 32-pose batches they are made of."""
+    P = 256
+    src, dirs = pose_ring(N, P, R)
+    vol = torch.from_numpy(vol256).cuda()
+    step = _captured(vol, src, dirs)
+    losses = step.loss.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(losses)) and np.all(losses > 0)
+    from oracle.conditioning import frame64_and_tolerance
+    for p in (0, 47, 100, 146, 201, 255):
+        f64, tol, _ = frame64_and_tolerance(vol256, src[p], dirs[p], S, ALPHA)
+        assert maxnorm_rel(step.frame[p].cpu().numpy(), f64) < tol, (p, tol)
+        want = float((f64 ** 2).sum())
+        assert abs(losses[p] - want) <= 1e-4 * want, (p, losses[p], want)
+    own = (step.frame.double() ** 2).sum((1, 2)).cpu().numpy()
+    assert np.all(np.abs(losses - own) <= 1e-5 * own)
+    # sharding invariance (what the strong-scaling curve relies on): the pose gradients of poses [64, 96) are the same
+    # whether they are rendered inside the 256-pose launch or as a 32-pose shard of their own; the volume gradient of
+    # the whole job is the sum of the shards'
+    gs, gd = step.gsrc[64:96].clone(), step.gdirs[64:96].clone()
+    gv_all = step.gvol.clone()
+    del step
+    torch.cuda.empty_cache()
+    acc = torch.zeros_like(gv_all)
+    for lo in range(0, P, 64):
+        sh = _captured(vol, src[lo:lo + 64], dirs[lo:lo + 64])
+        if lo == 64:
+            assert float((sh.gsrc[:32] - gs).abs().max()) <= 1e-6 * float(gs.abs().max())
+            assert float((sh.gdirs[:32] - gd).abs().max()) <= 1e-6 * float(gd.abs().max())
+        acc += sh.gvol
+        del sh
+    assert float((acc - gv_all).abs().max()) <= 1e-4 * float(gv_all.abs().max())
