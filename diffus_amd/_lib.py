@@ -19,13 +19,16 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
            "diffus_artifacts_workspace_bytes", "diffus_artifacts",
            "diffus_mlp_fwd", "diffus_mlp_workspace_bytes", "diffus_mlp_bwd", "diffus_brain_mask_workspace_bytes",
            "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats", "diffus_rows_conv1d",
-           "diffus_prop_single_ray", "diffus_propagate_rays", "diffus_sample_points")
+           "diffus_prop_single_ray", "diffus_propagate_rays", "diffus_sample_points",
+           "diffus_echo_bwd_workspace_bytes", "diffus_echo_traces_bwd", "diffus_splat_axes", "diffus_rotate_around_apex",
+           "diffus_ssim_workspace_bytes", "diffus_ssim_loss_fwd", "diffus_ssim_loss_bwd")
 
 ABI_VERSION = 3          # include/diffus_hip.h DIFFUS_ABI_VERSION
-DIFFUS_F32, DIFFUS_F64 = 0, 1
+DIFFUS_F32, DIFFUS_F64, DIFFUS_I64 = 0, 1, 2
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
 GRAD_BRICKED = 0x10   # OR'ed into `layout` of the backward calls: the gradient is the bricked scratch whatever the volume's layout
+FLUSH_STORE, FLUSH_ACCUMULATE, FLUSH_PERSISTENT, FLUSH_DENSE = 0, 1, 2, 3   # diffus_gradbuf_flush modes
 BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
 BWD_KEEP_MEDIAN = 4         # start > 0: the workspace still holds the forward's median (include/diffus_hip.h)
 MAX_SAMPLES = 1024          # cropped samples per launch; longer rays run as chained segments
@@ -85,8 +88,22 @@ def load():
     lib.diffus_unbrick_volume.argtypes = [vp, i, i, i, vp, i, vp]
     lib.diffus_echo_traces.restype = i
     lib.diffus_echo_traces.argtypes = [vp, i, i, vp, vp]
+    lib.diffus_echo_bwd_workspace_bytes.restype = sz
+    lib.diffus_echo_bwd_workspace_bytes.argtypes = [i, i]
+    lib.diffus_echo_traces_bwd.restype = i
+    lib.diffus_echo_traces_bwd.argtypes = [vp, i, i, vp, vp, vp, sz, vp]
     lib.diffus_splat_workspace_bytes.restype = sz
     lib.diffus_splat_workspace_bytes.argtypes = [i, i, i]
+    lib.diffus_ssim_workspace_bytes.restype = sz
+    lib.diffus_ssim_workspace_bytes.argtypes = [i, i, i]
+    lib.diffus_ssim_loss_fwd.restype = i
+    lib.diffus_ssim_loss_fwd.argtypes = [vp, vp, i, i, i, i, f, f, f, vp, vp, sz, vp]
+    lib.diffus_ssim_loss_bwd.restype = i
+    lib.diffus_ssim_loss_bwd.argtypes = [vp, vp, i, i, i, i, f, f, f, vp, vp, i, vp, sz, vp]
+    lib.diffus_rotate_around_apex.restype = i
+    lib.diffus_rotate_around_apex.argtypes = [vp, vp, C.c_long, vp, vp, f, vp, vp, vp]
+    lib.diffus_splat_axes.restype = i
+    lib.diffus_splat_axes.argtypes = [vp, i, vp, i, vp, i, C.c_long, vp, vp, vp, vp]
     lib.diffus_splat_fwd.restype = i
     lib.diffus_splat_fwd.argtypes = [vp, vp, vp, i, C.c_long, i, i, i, f, vp, vp, sz, vp]
     lib.diffus_splat_bwd.restype = i

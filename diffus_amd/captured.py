@@ -26,19 +26,19 @@ previous step touched, so after every step `gvol` is exactly this step's dense g
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import torch
 
 from . import _lib
+from .renderer import _stream_id
 
 _LAYOUT_ID = {"canonical": _lib.CANONICAL, "bricked": _lib.BRICKED, "paired": _lib.PAIRED}
 _SAMPLER_ID = {"nearest": _lib.NEAREST, "prop": _lib.NEAREST, "trilinear": _lib.TRILINEAR}
 
 
 def _vp(t: Optional[torch.Tensor]):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None        # ctypes turns the int into the void* of the signature
 
 
 def _pose_tensor(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
@@ -154,6 +154,11 @@ class CapturedStep:
         self.alias_grads = bool(alias_grads)
         self._src_shape = tuple(sources.shape)
         self._stamp = 0
+        # start > 0: the forward leaves the per-pose median (and the median ray's samples) in the workspace and the
+        # backward may reuse it (DIFFUS_BWD_KEEP_MEDIAN) -- but only while it belongs to the CURRENT inputs.  `_median_of`
+        # remembers the inputs' in-place version counters at the time the median was computed.
+        self._median_of = None
+        self._conv_stamp = 0
         # step(): loss_p = loss_scale * sum((frame_p - target_p)^2) (target None: the frame's energy).  fused_loss: the
         # backward forms dL/dframe from the frame on the fly and its closing per-pose blocks sum the loss
         # (diffus_render_bwd_mse) -- no loss kernel, no gradient-of-frame buffer traffic
@@ -215,17 +220,28 @@ class CapturedStep:
 
     # -- plumbing ---------------------------------------------------------------------------------------------
     def stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        return _stream_id(self.dev)
 
 
     # -- inputs, updated in place (a captured graph keeps reading the same buffers) -----------------------------
+    def _inputs_now(self):
+        return (self.vol._version, self.src._version, self.dirs._version, self._conv_stamp)
+
+    def _median_valid(self) -> bool:
+        """The workspace median was computed from the inputs as they are now (no set_poses / in-place volume edit /
+        refresh_volume since)."""
+        return self.start > 0 and self._median_of is not None and self._median_of == self._inputs_now()
+
     def set_poses(self, sources: torch.Tensor, directions: Optional[torch.Tensor] = None):
         self.src.copy_(sources.reshape(self.src.shape))
         if directions is not None:
             self.dirs.copy_(directions.reshape(self.dirs.shape))
+        self._stamp += 1            # a frame rendered before this call can no longer be back-propagated
 
     def refresh_volume(self):
         """Rebuild the converted copy from `self.vol` (after the caller changed the volume in place)."""
+        self._conv_stamp += 1
+        self._stamp += 1
         if self.layout == _lib.BRICKED:
             _lib.check(self.lib.diffus_brick_volume(_vp(self.vol), *self.dims, _vp(self.vol_k), self.stream()), "diffus_brick_volume")
         elif self.layout == _lib.PAIRED:
@@ -235,6 +251,8 @@ class CapturedStep:
     def fwd(self):
         _lib.check(self.lib.diffus_render_fwd(*self.common, _vp(self.frame), None, _vp(self.ws), self.ws.numel(),
                                               self.stream()), "diffus_render_fwd")
+        self._stamp += 1
+        self._median_of = self._inputs_now()
 
     def bwd(self, stages=_lib.BWD_ALL):
         _lib.check(self.lib.diffus_render_bwd(*self.common_bwd, _vp(self.gframe), _vp(self.gvol_k), _vp(self.touched),
@@ -284,7 +302,7 @@ class CapturedStep:
         Must follow `forward()` on the same inputs: with start > 0 it reuses the per-pose median the forward left in
         this object's own workspace (DIFFUS_BWD_KEEP_MEDIAN) instead of launching the median kernel again."""
         self.zero_grad()
-        self.bwd(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self.start > 0 else 0))
+        self.bwd(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self._median_valid() else 0))
         self.finish_grad()
 
     def step_mse(self, stages: int = _lib.BWD_ALL, epilogue: bool = True):
@@ -301,17 +319,19 @@ class CapturedStep:
     def step(self):
         # (a forked stream for zero_grad beside the forward was measured: the fork/join events cost
         # more than the 10 us they hide -- 0.217 vs 0.202 ms/step -- so the step stays on one stream)
+        self._stamp += 1
         if self.fused_loss and self.one_pass:
             if self.learnable_volume:
                 self.refresh_volume()
             self.zero_grad()
-            self.step_mse(_lib.BWD_ALL)
+            self.step_mse(_lib.BWD_ALL)      # computes its own median (start > 0): valid for these inputs afterwards
             self.finish_grad()
+            self._median_of = self._inputs_now()
             return
         self.forward()
         if self.fused_loss:
             self.zero_grad()
-            self.bwd_mse(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self.start > 0 else 0))
+            self.bwd_mse(_lib.BWD_ALL | (_lib.BWD_KEEP_MEDIAN if self._median_valid() else 0))
             self.finish_grad()
         else:
             if self.target is not None or self.loss_scale != 1.0:
@@ -331,9 +351,12 @@ class CapturedStep:
                 fn()
         self._side.synchronize()
         g = torch.cuda.CUDAGraph()
+        keeps = what == "backward" and self._median_valid()      # the stages word is baked into the captured launch
         with torch.cuda.graph(g, stream=self._side):
             fn()
         self._graphs[what] = g
+        self._graph_keeps_median = getattr(self, "_graph_keeps_median", {})
+        self._graph_keeps_median[what] = keeps
         return g
 
     def replay(self, what: str = "step"):
@@ -341,8 +364,14 @@ class CapturedStep:
 
     def _run(self, what: str):
         g = self._graphs.get(what)
+        if g is not None and what == "backward" and getattr(self, "_graph_keeps_median", {}).get(what) \
+                and not self._median_valid():
+            g = None            # the captured launch would reuse a median of other inputs: recompute it eagerly instead
         if g is not None:
             g.replay()
+            if what in ("forward", "step"):     # the replayed launches leave the median of the current inputs
+                self._median_of = self._inputs_now()
+                self._stamp += 1
         else:
             getattr(self, what)()
 
@@ -368,10 +397,13 @@ class CapturedStep:
                     raise _lib.DiffusError(f"{what}(): a volume other than the step's own needs learnable_volume=True "
                                            "(its converted copy must be rebuilt)")
                 self.vol.copy_(v)
+                self._stamp += 1
             if s.data_ptr() != self.src.data_ptr():
                 self.src.copy_(s.reshape(self.src.shape))
+                self._stamp += 1
             if d.data_ptr() != self.dirs.data_ptr():
                 self.dirs.copy_(d.reshape(self.dirs.shape))
+                self._stamp += 1
         return v, s, d
 
     def set_target(self, target: Optional[torch.Tensor], loss_scale: Optional[float] = None):

@@ -15,9 +15,9 @@ from .phantom import cone_directions_np
 
 
 def generate_cone_directions(direction_mri_world, opening_angle, n_rays):
-    """Generate a fan of directions centered on direction_mri_world, spanning
-    opening_angle (radians), in the (x, y) plane (z=0).  Returns (n_rays, 3) float32.
-    Same signature and values as reference src/cone.py:242."""
+    """n_rays unit vectors (n_rays, 3) float32 that fan out symmetrically about the first two components of
+    `direction_mri_world`, `opening_angle` radians from the first ray to the last, all with a zero third component --
+    signature and values of reference src/cone.py:242-258 (bit-exact, golden G8)."""
     if isinstance(direction_mri_world, torch.Tensor):
         direction_mri_world = direction_mri_world.detach().cpu().numpy()
     return torch.from_numpy(cone_directions_np(direction_mri_world, float(opening_angle), int(n_rays)))

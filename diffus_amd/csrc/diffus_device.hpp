@@ -231,6 +231,25 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// ... of a double (the two halves move separately); total valid in lane 63 only
+__device__ __forceinline__ double wave_sum_to_lane63(double v)
+{
+#define DIFFUS_SUM_STEP(ctrl, rmask)                                                                     \
+    {                                                                                                    \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, true);        \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, true);        \
+        v += __hiloint2double(hi, lo);                                                                   \
+    }
+    DIFFUS_SUM_STEP(kDppRowShr + 1, 0xf)
+    DIFFUS_SUM_STEP(kDppRowShr + 2, 0xf)
+    DIFFUS_SUM_STEP(kDppRowShr + 4, 0xf)
+    DIFFUS_SUM_STEP(kDppRowShr + 8, 0xf)
+    DIFFUS_SUM_STEP(kDppBcast15, 0xa)
+    DIFFUS_SUM_STEP(kDppBcast31, 0xc)
+#undef DIFFUS_SUM_STEP
+    return v;
+}
+
 // ----------------------------------------------------------------------------
 struct Pose {
     // source and direction of this wave's ray, kept in both precisions; pmode

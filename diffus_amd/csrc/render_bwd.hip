@@ -71,6 +71,12 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     float *wb = lds[wib];
     float *gst = stash[KEEP_GRAD ? wib : 0];
 
+#ifdef DIFFUS_STAGGER_CYCLES // experiment (DESIGN "tried"): de-phase the blocks that share a CU so that one's gather overlaps another's scans
+    {
+        const unsigned slot = (blockIdx.x >> DIFFUS_STAGGER_SHIFT) & 3u;
+        for (unsigned i = 0; i < slot * (DIFFUS_STAGGER_CYCLES / 640); ++i) __builtin_amdgcn_s_sleep(10); // 10 x 64 cycles
+    }
+#endif
     STAMPRT(10); // 100 MHz wall clock, the same on every XCD: when the wave started ...
     STAMPB(0);
     Pose ps;

@@ -267,6 +267,75 @@ __global__ __launch_bounds__(kBlock) void prop_single_ray_kernel(const T *__rest
         if (o[k] != o[k]) o[k] = T(0);
 }
 
+// Backward of compute_echo_traces (what torch autograd does through the reference's N+1 linalg.solve nodes,
+// src/renderer.py:407,430,454): r (B,N), dL/d echo (B,N+1) -> dL/d r (B,N).  SURVEY App. A.4 with the rescaling made
+// explicit: forward P'_n = 2^-e_n P'_{n-1} M(r_{n-1}), echo_n = b'_n / d'_n; reverse sweep
+//     Pbar_n += gbar_n [[0, 1/d'],[0, -b'/d'^2]],  Mbar = 2^-e_n P'_{n-1}^T Pbar_n,  Pbar_{n-1} = 2^-e_n Pbar_n M^T,
+//     rbar_{n-1} = -4 r Mbar_00 + Mbar_01 - Mbar_10.
+// One thread per ray, float64 inside (this is the module-level API, not the hot path: the fused render_bwd_kernel does
+// the same adjoint as a wave scan in float32).  The forward products wait in the workspace, (N+1) x B x 4 doubles +
+// exponents, laid out step-major so that neighbouring threads touch neighbouring addresses.  An echo that nan_to_num
+// (:408) turned into the constant 0 passes no gradient; nothing flows through a non-finite coefficient.
+__global__ __launch_bounds__(kBlock) void echo_traces_bwd_kernel(const float *__restrict__ rin, const float *__restrict__ gecho,
+                                                                 float *__restrict__ gr, double *__restrict__ wsP,
+                                                                 int *__restrict__ wsE, int B, int N)
+{
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const float *r = rin + (long)b * N;
+    double p00 = 1.0, p01 = 0.0, p10 = 0.0, p11 = 1.0;
+    auto slot = [&](int n) { return ((size_t)n * B + b) * 4; };
+    {
+        double *q = wsP + slot(0);
+        q[0] = p00; q[1] = p01; q[2] = p10; q[3] = p11;
+        wsE[(size_t)0 * B + b] = 0;
+    }
+    for (int n = 1; n <= N; ++n) {
+        const double rk = (double)r[n - 1], a = 1.0 - 2.0 * rk * rk;
+        const double q00 = p00 * a - p01 * rk, q01 = p00 * rk + p01, q10 = p10 * a - p11 * rk, q11 = p10 * rk + p11;
+        const double mx = fmax(fmax(fabs(q00), fabs(q01)), fmax(fabs(q10), fabs(q11)));
+        int e = 0;
+        if (mx > 0.0 && mx < __builtin_inf()) frexp(mx, &e);
+        p00 = ldexp(q00, -e); p01 = ldexp(q01, -e); p10 = ldexp(q10, -e); p11 = ldexp(q11, -e);
+        double *q = wsP + slot(n);
+        q[0] = p00; q[1] = p01; q[2] = p10; q[3] = p11;
+        wsE[(size_t)n * B + b] = e;
+    }
+    double u00 = 0.0, u01 = 0.0, u10 = 0.0, u11 = 0.0; // Pbar_n
+    for (int n = N; n >= 1; --n) {
+        const double *q = wsP + slot(n);
+        const double bb = q[1], dd = q[3];
+        const double echo = bb / dd;
+        const double g = (double)gecho[(long)b * (N + 1) + n];
+        if (echo == echo && g != 0.0) { // a NaN echo became the constant 0: no gradient through it
+            const double s = g / dd, t = -g * echo / dd;
+            if (s - s == 0.0 && t - t == 0.0) { // finite seeds only
+                u01 += s;
+                u11 += t;
+            }
+        }
+        const double rk = (double)r[n - 1];
+        if (!(rk - rk == 0.0)) { // non-finite coefficient: everything after it is the constant 0, nothing flows
+            gr[(long)b * N + n - 1] = 0.f;
+            u00 = u01 = u10 = u11 = 0.0;
+            continue;
+        }
+        const double *pm = wsP + slot(n - 1);
+        const int e = wsE[(size_t)n * B + b];
+        // Mbar = 2^-e P'_{n-1}^T Pbar_n
+        const double m00 = pm[0] * u00 + pm[2] * u10, m01 = pm[0] * u01 + pm[2] * u11;
+        const double m10 = pm[1] * u00 + pm[3] * u10;
+        double rb = ldexp(-4.0 * rk * m00 + m01 - m10, -e);
+        if (!(rb - rb == 0.0)) rb = 0.0;
+        gr[(long)b * N + n - 1] = (float)rb;
+        // Pbar_{n-1} = 2^-e Pbar_n M^T,  M = [[a, r],[-r, 1]]
+        const double a = 1.0 - 2.0 * rk * rk;
+        const double v00 = u00 * a + u01 * rk, v01 = -u00 * rk + u01, v10 = u10 * a + u11 * rk, v11 = -u10 * rk + u11;
+        u00 = ldexp(v00, -e); u01 = ldexp(v01, -e); u10 = ldexp(v10, -e); u11 = ldexp(v11, -e);
+        if (!(u00 - u00 == 0.0 && u01 - u01 == 0.0 && u10 - u10 == 0.0 && u11 - u11 == 0.0)) u00 = u01 = u10 = u11 = 0.0;
+    }
+}
+
 // running sum along each row, in place: the cumsum of propagate_full_rays_batched (reference :435)
 __global__ __launch_bounds__(kBlock) void rows_cumsum_kernel(float *__restrict__ a, int B, int M)
 {
@@ -440,6 +509,26 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo, diffus_stre
     case 8: hipLaunchKernelGGL(echo_traces_kernel<8>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
     default: hipLaunchKernelGGL(echo_traces_kernel<16>, dim3(nblk), dim3(kBlock), 0, st, refl, echo, B, N); break;
     }
+    return last_launch();
+}
+
+size_t diffus_echo_bwd_workspace_bytes(int B, int N)
+{
+    if (B <= 0 || N < 0) return 0;
+    return align256((size_t)B * (N + 1) * 4 * sizeof(double)) + align256((size_t)B * (N + 1) * sizeof(int));
+}
+
+int diffus_echo_traces_bwd(const float *refl, int B, int N, const float *gecho, float *grefl, void *workspace,
+                           size_t workspace_bytes, diffus_stream_t stream)
+{
+    if (B <= 0 || N < 0 || !gecho) return DIFFUS_EINVAL;
+    if (N == 0) return DIFFUS_OK; // no coefficient, no gradient
+    if (!refl || !grefl) return DIFFUS_EINVAL;
+    if (!workspace || workspace_bytes < diffus_echo_bwd_workspace_bytes(B, N)) return DIFFUS_EWORKSPACE;
+    double *wsP = (double *)workspace;
+    int *wsE = (int *)((char *)workspace + align256((size_t)B * (N + 1) * 4 * sizeof(double)));
+    hipLaunchKernelGGL(echo_traces_bwd_kernel, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       refl, gecho, grefl, wsP, wsE, B, N);
     return last_launch();
 }
 

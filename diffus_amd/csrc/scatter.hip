@@ -50,34 +50,314 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
 #endif
 constexpr int kScRays = DIFFUS_SC_PATCH_RAYS, kScSteps = DIFFUS_SC_PATCH_STEPS;
 constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kScRays * kScSteps / kSB;
+constexpr int kCapD = kTileCap / 2; // 64-bit entries in the tile
+
+// ---- PLANAR patches (bricked gradient) -----------------------------------------------------------------------------
+// No ray of the patch moves along dim 2 -- every fan of the reference (src/cone.py:258) -- so all its samples share ONE
+// dim-2 cell (iz0, iz1, tz).  The tile then holds the 2-D footprint only: a plain row-major array of DOUBLES over the
+// brick-aligned (dim 0, dim 1) box of the patch, 4 adds per sample instead of 8, and the two depth weights are applied
+// once per entry in the flush.
+//
+// Why doubles: ds_add_f32 costs ~194 cycles per wave-instruction on gfx950 whatever the addresses, ds_add_u32 5-15,
+// ds_add_u64 12-56 -- and ds_add_f64 21-89 (tools/lds_atomic_bench.hip, round 3): the LDS float64 atomic is a native
+// full-rate path where the float32 one is not.  Rounds 1-2 therefore accumulated in 64-bit FIXED POINT, which cost a
+// patch-wide sum of |zbar| (a DPP reduction, an LDS record per wave, scalar bookkeeping) for the common scale and ~10
+// VALU instructions per corner for the float -> (mantissa << shift) conversion: 40 of a sample's ~215 instructions in a
+// kernel that runs at its VALU issue rate (PMC: 870 VALU instructions per wave, pipes 68 % busy).  A double takes the
+// contribution as it is (one v_cvt_f64_f32); accumulation error 2^-53 relative per add instead of a 2^-61 quantum of
+// the patch's sum -- both far below the float32 atomics of the flush.
+//
+// Returns false -- nothing added, tile clear -- when some ray of the block is not planar (the caller then runs the
+// general 3-D path); true when the patch is done.
+template <int SAMPLER, int PM>
+__device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile, int (*s_box)[4], int *s_planar, const Pose &ps,
+                                                     long w, bool ray_ok, int nbase, int tid)
+{
+    const int wib = tid >> 6;
+    // ---- loads first: a thread's kSPT consecutive zbar values (one 16-byte load when the row allows it) ...
+    float zb[kSPT];
+    {
+        const float *row = A.zbar + w * A.N1;
+#ifdef DIFFUS_ABLATE_SC_LOAD // timing probes (tools/): the zbar values are made up, nothing is loaded
+        if (true) {
+#pragma unroll
+            for (int q = 0; q < kSPT; ++q) zb[q] = (ray_ok && nbase + q < A.N1) ? 1e-3f * (float)((tid + q) & 15) : 0.f;
+        } else
+#endif
+        if (ray_ok && nbase + kSPT <= A.N1) {
+            if constexpr (kSPT == 4) {
+                const F4a4 t = *reinterpret_cast<const F4a4 *>(row + nbase);
+                zb[0] = t.x; zb[1] = t.y; zb[2] = t.z; zb[3] = t.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < kSPT; ++q) zb[q] = row[nbase + q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kSPT; ++q) zb[q] = (ray_ok && nbase + q < A.N1) ? row[nbase + q] : 0.f;
+        }
+    }
+    // ... and the WHOLE tile is cleared while they are in flight (6 ds_write_b128 per thread)
+    {
+        int4 *t4 = reinterpret_cast<int4 *>(tile);
+#pragma unroll
+        for (int e = 0; e < kTileCap / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
+        static_assert(kTileCap % (4 * kSB) == 0, "tile clear assumes whole int4 passes");
+    }
+    const bool ray_planar = (PM == 0 || ps.pmode != 2) ? (ps.df[2] == 0.f) : (ps.dd[2] == 0.0);
+    const bool wave_planar = __ballot(ray_planar) == ~0ull;
+    // ---- cells along dim 0 and dim 1 (the pose only: worked out while the loads are in flight)
+    int x0[kSPT], x1[kSPT], y0[kSPT], y1[kSPT];
+    float tx[kSPT], ty[kSPT];
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) {
+        const float kf = (float)(A.start + nbase + q);
+        const float p0 = ray_point_f<PM>(ps, 0, kf), p1 = ray_point_f<PM>(ps, 1, kf);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            x0[q] = x1[q] = nearest_index(p0, A.G.d0);
+            y0[q] = y1[q] = nearest_index(p1, A.G.d1);
+            tx[q] = ty[q] = 0.f;
+        } else {
+            const Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1);
+            x0[q] = a.i0; x1[q] = a.i1; tx[q] = a.t;
+            y0[q] = b.i0; y1[q] = b.i1; ty[q] = b.t;
+        }
+    }
+    // ---- bounding box of the thread's samples.  A ray is a straight line and every step of the chain p -> clamp -> floor
+    // is monotone in the step index, so the extremes sit at the first and the last of its consecutive samples.
+    unsigned nz = 0;
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) {
+        if (!finitef(zb[q])) zb[q] = 0.f;
+        nz |= __float_as_uint(zb[q]) & 0x7fffffffu;
+    }
+    const bool live = nz != 0u;
+    int bx[4];
+    bx[0] = live ? min(x0[0], x0[kSPT - 1]) : 0x7fffffff;
+    bx[1] = live ? max(x1[0], x1[kSPT - 1]) : -1;
+    bx[2] = live ? min(y0[0], y0[kSPT - 1]) : 0x7fffffff;
+    bx[3] = live ? max(y1[0], y1[kSPT - 1]) : -1;
+    STAMP(1);
+    bx[0] = wave_reduce_minmax<true>(bx[0]);
+    bx[1] = wave_reduce_minmax<false>(bx[1]);
+    bx[2] = wave_reduce_minmax<true>(bx[2]);
+    bx[3] = wave_reduce_minmax<false>(bx[3]);
+    if ((tid & 63) == 63) {
+        s_planar[wib] = wave_planar;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_box[wib][a] = bx[a];
+    }
+    __syncthreads(); // also: the tile is clear
+    STAMP(2);
+    // ---- block-uniform bookkeeping, on the scalar unit (readfirstlane): the boxes in BRICK units
+    int wb[kSW][4];
+    int all_planar = 1;
+#pragma unroll
+    for (int wv = 0; wv < kSW; ++wv) {
+        all_planar &= s_planar[wv];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wb[wv][a] = __builtin_amdgcn_readfirstlane(s_box[wv][a]) >> 2; // 0x7fffffff stays huge, -1 stays -1
+    }
+    if (!__builtin_amdgcn_readfirstlane(all_planar)) return false;
+    // box of the waves [w0, w0 + cnt) -> origin (bricks), extent (bricks); entries needed: 0 = nothing to add,
+    // kCapD + 1 = does not fit
+    auto box_of = [&](int w0, int cnt, int &l0, int &l1, int &b0, int &b1) -> int {
+        int mn0 = 0x7fffffff, mx0 = -1, mn1 = 0x7fffffff, mx1 = -1;
+#pragma unroll
+        for (int wv = 0; wv < kSW; ++wv) {
+            const bool in = wv >= w0 && wv < w0 + cnt;
+            mn0 = in ? min(mn0, wb[wv][0]) : mn0; mx0 = in ? max(mx0, wb[wv][1]) : mx0;
+            mn1 = in ? min(mn1, wb[wv][2]) : mn1; mx1 = in ? max(mx1, wb[wv][3]) : mx1;
+        }
+        l0 = mn0; l1 = mn1; b0 = mx0 - mn0 + 1; b1 = mx1 - mn1 + 1;
+        if (mx0 < 0 || mx1 < 0) return 0;
+        const unsigned e0 = (unsigned)min(b0, 0x3fff), e1 = (unsigned)min(b1, 0x3fff); // saturate: only "> kCapD" matters
+        return (int)min(16u * e0 * e1, (unsigned)kCapD + 1u);
+    };
+    static_assert(kSW == 4 || kSW == 8, "wave grouping below: 1, 2 or 4 groups of waves");
+    int nsub = 1, l0, l1, b0, b1;
+    int need = box_of(0, kSW, l0, l1, b0, b1);
+    if (need > kCapD) {
+        int t0, t1, t2, t3;
+        nsub = 2;
+        if (box_of(0, kSW / 2, t0, t1, t2, t3) > kCapD || box_of(kSW / 2, kSW / 2, t0, t1, t2, t3) > kCapD) nsub = 4;
+    }
+    // the patch's dim-2 cell: the same in every thread (p2 = source[2] for every sample)
+    int iz0, iz1;
+    float tz;
+    {
+        const float p2 = ray_point_f<PM>(ps, 2, 0.f);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            iz0 = iz1 = nearest_index(p2, A.G.d2);
+            tz = 0.f;
+        } else {
+            const Axis c = tri_axis(p2, A.G.d2);
+            iz0 = c.i0; iz1 = c.i1; tz = c.t;
+        }
+        iz0 = __builtin_amdgcn_readfirstlane(iz0); iz1 = __builtin_amdgcn_readfirstlane(iz1);
+        tz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tz)));
+    }
+    const int wpg = kSW / nsub;
+#pragma unroll 1
+    for (int sp = 0; sp < nsub; ++sp) { // block-uniform trip count and branches
+        if (nsub > 1) need = box_of(sp * wpg, wpg, l0, l1, b0, b1);
+        if (need == 0) continue; // nothing to add in this group
+        const bool mine = (wib / wpg) == sp;
+        // keep the per-sample values INSIDE the trip (hoisted out of this almost always single-trip loop they cost registers)
+#pragma unroll
+        for (int q = 0; q < kSPT; ++q)
+            asm volatile("" : "+v"(zb[q]), "+v"(tx[q]), "+v"(ty[q]), "+v"(x0[q]), "+v"(y0[q]), "+v"(x1[q]), "+v"(y1[q]));
+        if (need > kCapD) { // a single wave's strip does not fit (never seen with unit steps): direct atomics
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < kSPT; ++q)
+                    if (zb[q] != 0.f) {
+                        Cell c;
+                        c.i0[0] = x0[q]; c.i1[0] = x1[q]; c.t[0] = tx[q];
+                        c.i0[1] = y0[q]; c.i1[1] = y1[q]; c.t[1] = ty[q];
+                        c.i0[2] = iz0; c.i1[2] = iz1; c.t[2] = tz;
+                        for_each_corner<SAMPLER>(c, zb[q], [&](int i, int j, int k, float v) {
+                            if (v != 0.f) {
+                                unsigned g = vox_off<DIFFUS_BRICKED>(A.G, i, j, k);
+                                atomicAdd(A.gvol + g, v);
+                                if (A.gtouched) A.gtouched[g >> 5] = 1;
+                            }
+                        });
+                    }
+            }
+            continue;
+        }
+        STAMP(3);
+        // tile entry of voxel (x, y) = (x - 4 l0) * BY + (y - 4 l1), BY = 4 b1 voxels per row
+        const int BY = 4 * b1;
+        const int org = -(4 * l0) * BY - 4 * l1;
+        // Same-address lanes of one LDS atomic are served one after the other (ds_add_f64: 21 cycles per wave-instruction
+        // with distinct addresses, +23 per duplicate).  The worst case is also a common one: a ray that has left the
+        // volume through an edge of the slice is clamped onto ONE voxel for the rest of its steps, all the rays around
+        // it onto the same one -- 64 lanes, one address (6.5 % of the adds of config 3 and, at ~1400 cycles each, half
+        // of the LDS pipe's time).  So each sample first asks whether the wave's lanes all sit in the same cell (two
+        // readfirstlanes and compares); if so the four contributions are summed over the wave (DPP, in double) and ONE
+        // lane adds them.
+#pragma unroll
+        for (int q = 0; q < kSPT; ++q) {
+            const bool on = mine && zb[q] != 0.f;
+            const int r0 = x0[q] * BY + org, r1 = x1[q] * BY + org;
+            const int e00 = r0 + y0[q], e11 = r1 + y1[q];
+            float c00, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+            if constexpr (SAMPLER == DIFFUS_NEAREST) {
+                c00 = on ? zb[q] : 0.f;
+            } else {
+                const float wa1 = tx[q], wa0 = 1.f - wa1, wb1 = ty[q], wb0 = 1.f - wb1;
+                const float s0 = on ? zb[q] * wa0 : 0.f, s1 = on ? zb[q] * wa1 : 0.f;
+                c00 = s0 * wb0; c01 = s0 * wb1; c10 = s1 * wb0; c11 = s1 * wb1;
+            }
+#ifdef DIFFUS_ABLATE_SC_ADD
+            asm volatile("" :: "v"(c00), "v"(c01), "v"(c10), "v"(c11), "v"(e00), "v"(e11));
+            continue;
+#endif
+            const unsigned long long act = __ballot(on);
+            if (act == 0ull) continue; // wave-uniform
+            const int lead = __builtin_ctzll(act);
+            const int f00 = __builtin_amdgcn_readlane(e00, lead), f11 = __builtin_amdgcn_readlane(e11, lead);
+            const bool same = __ballot(on && e00 == f00 && e11 == f11) == act;
+            if (same && __builtin_popcountll(act) > 4) { // wave-uniform: one cell for every live lane
+                const int f01 = __builtin_amdgcn_readlane(r0 + y1[q], lead), f10 = __builtin_amdgcn_readlane(r1 + y0[q], lead);
+                const double t00 = wave_sum_to_lane63((double)c00);
+                double t01 = 0.0, t10 = 0.0, t11 = 0.0;
+                if constexpr (SAMPLER != DIFFUS_NEAREST) {
+                    t01 = wave_sum_to_lane63((double)c01);
+                    t10 = wave_sum_to_lane63((double)c10);
+                    t11 = wave_sum_to_lane63((double)c11);
+                }
+                if ((tid & 63) == 63) {
+                    if (t00 != 0.0) atomicAdd(&tile[f00], t00);
+                    if (t01 != 0.0) atomicAdd(&tile[f01], t01);
+                    if (t10 != 0.0) atomicAdd(&tile[f10], t10);
+                    if (t11 != 0.0) atomicAdd(&tile[f11], t11);
+                }
+            } else {
+                // clamped samples (outside the volume: more than half of a typical fan) have zero weights on half or
+                // more of their corners: no LDS atomic is spent on a zero
+                if (c00 != 0.f) atomicAdd(&tile[e00], (double)c00);
+                if constexpr (SAMPLER != DIFFUS_NEAREST) {
+                    if (c01 != 0.f) atomicAdd(&tile[r0 + y1[q]], (double)c01);
+                    if (c10 != 0.f) atomicAdd(&tile[r1 + y0[q]], (double)c10);
+                    if (c11 != 0.f) atomicAdd(&tile[e11], (double)c11);
+                }
+            }
+            // one sample at a time: left alone the scheduler converts all 16 contributions to doubles first (32 VGPRs)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        STAMP(4);
+        // flush: a half-wave = one brick column = the 32 floats (x & 3, y & 3, z) of its brick(s); two lanes share a
+        // tile entry and apply the two depth weights.  z0 even: one brick, a contiguous 128-B atomic run.
+        const int ncols = b0 * b1;
+        const float rb1 = __frcp_rn((float)b1);
+        const int o = tid & 31, msub = tid >> 5, mstep = kSB / 32;
+        const int zz = (o & 1) ? iz1 : iz0;
+        const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
+        const unsigned zpart = (unsigned)(zz >> 1) * kBrickFloats + (unsigned)((o >> 1) << 1) + (unsigned)(zz & 1);
+        const int lane_off = (o >> 3) * BY + ((o >> 1) & 3); // this lane's voxel inside its brick column
+        constexpr int FU2 = 4; // tile reads in flight per thread
+        for (int q0 = msub; q0 < ncols; q0 += mstep * FU2) {
+            double v[FU2];
+            int ei[FU2], ci[FU2], cj[FU2];
+#pragma unroll
+            for (int u = 0; u < FU2; ++u) {
+                const int q = q0 + u * mstep;
+                ci[u] = __float2int_rz(((float)q + 0.5f) * rb1); // exact: q < 2^14, i * b1 <= q
+                cj[u] = q - ci[u] * b1;
+                ei[u] = (4 * ci[u]) * BY + 4 * cj[u] + lane_off;
+                v[u] = (q < ncols) ? tile[ei[u]] : 0.0;
+            }
+            if (nsub > 1) { // leave the tile clean for the next group (after both lanes of a pair have read their entry)
+#pragma unroll
+                for (int u = 0; u < FU2; ++u)
+                    if (v[u] != 0.0 && !(o & 1)) tile[ei[u]] = 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < FU2; ++u) {
+                const bool any = (unsigned)(__ballot(v[u] != 0.0) >> (tid & 32)) != 0u;
+                if (any) {
+                    const unsigned g = ((unsigned)(l0 + ci[u]) * (unsigned)A.G.nb1 + (unsigned)(l1 + cj[u])) * (unsigned)A.G.nb2 * kBrickFloats + zpart;
+#ifdef DIFFUS_ABLATE_SC_FLUSH
+                    asm volatile("" :: "v"(g), "v"((float)v[u] * wz));
+#else
+                    if (A.gtouched && o < 2) A.gtouched[g >> 5] = 1; // lanes 0 and 1: the brick of z0 and the brick of z1
+                    if (v[u] != 0.0 && wz != 0.f) atomicAdd(A.gvol + g, (float)v[u] * wz);
+#endif
+                }
+            }
+        }
+        STAMP(5);
+#ifdef DIFFUS_STAMP
+        if (threadIdx.x == 0 && g_stamps) {
+            g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)need;
+            g_stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)nsub;
+        }
+#endif
+        if (sp + 1 < nsub) __syncthreads();
+    }
+    return true;
+}
+
 template <int SAMPLER, int LAYOUT, int PM>
 __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
 {
-    // Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 costs ~194 cycles per
-    // wave-instruction whatever the addresses (lanes are serialised), ds_add_u32 5-15.
-    // The tile therefore accumulates in 32-bit FIXED POINT with a per-patch power-of-two
-    // scale 2^fx chosen so that even all 1024 samples landing on one voxel cannot
-    // overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel can
-    // receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution,
-    // typically 2^-23..2^-26; integer adds commute, so a tile sum is bitwise reproducible.
+    // General (3-D) tile: 32-bit FIXED POINT with a per-patch power-of-two scale 2^fx chosen so that even all 1024 samples
+    // landing on one voxel cannot overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel
+    // can receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution, typically 2^-23..2^-26;
+    // integer adds commute, so a tile sum is bitwise reproducible.  (ds_add_f32 is ~194 cycles per wave-instruction on
+    // gfx950, ds_add_u32 5-15: tools/lds_atomic_bench.hip.)  Planar patches -- every fan of the reference -- take the
+    // 2-D double-precision tile of scatter_patch_planar instead.
     __shared__ __attribute__((aligned(16))) int tile[kTileCap];
     __shared__ int s_wlo[kSW][3], s_whi[kSW][3]; // per-WAVE boxes (a wave = 64 / kPatchSteps * kSPT rays x kPatchSteps steps)
     __shared__ float s_sum[kSW];
     __shared__ int s_planar[kSW];
+    __shared__ int s_box[kSW][4];
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
-    // PLANAR patches (bricked gradient): no ray of the patch moves along dim 2 -- every fan of the reference
-    // (src/cone.py:258) -- so all its samples share ONE dim-2 cell (iz0, iz1, tz).  The tile then holds the 2-D
-    // footprint only, 16 entries per brick column: 4 LDS adds per sample instead of 8, half (z0 even) or a quarter
-    // (z0 odd) of the tile entries, and the two depth weights are applied once per entry in the flush.
     constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED); // nearest sampling too: one add per sample, one depth
-    constexpr int UNIT2 = 16; // tile entries per brick column in planar mode
-    // Planar tiles are so much smaller (at config 3: 551 entries on average, 2304 at most, of 6144) that their entries
-    // can be 64-BIT: the quantum is 2^-61 of the patch's sum of |zbar| instead of 2^-29, so a contribution 2^-37 below
-    // the patch's largest still has full float precision.  It matters for strongly attenuated frames: with the
-    // reference's default attenuation_coeff = 0.5 the upstream gradient falls by 2^-46 across the 32 steps of a patch
-    // and a 32-bit accumulator rounds the deep end of every patch to exactly zero.
-    constexpr int kCap2 = kTileCap / 2; // 64-bit entries in the tile
-    long long *tile64 = reinterpret_cast<long long *>(tile);
 
     if (blockIdx.x >= npatch) { // tail blocks of the launch, one per pose: median routing (start > 0) and d/dsource
         pose_finish_block<SAMPLER, LAYOUT>(A, (int)(blockIdx.x - npatch), reinterpret_cast<float *>(tile));
@@ -87,21 +367,40 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     // depth range of all poses and ray groups -- patches of similar cost (the box grows with the distance from the
     // apex) spread over the whole volume -- instead of all depths of a few neighbouring fans (58 -> 52 us).  Within a
     // step group the XCD remap keeps a pose on one XCD.
-    const int per_sg = (int)(npatch / (unsigned)step_groups);
-    const int sg = (int)(blockIdx.x / (unsigned)per_sg);
-    const unsigned Lb = xcd_remap(blockIdx.x % (unsigned)per_sg, (unsigned)per_sg);
-    const int rg = Lb % ray_groups;
-    const int pose = Lb / ray_groups;
     const int tid = threadIdx.x;
-    // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..)
-    const int ray = rg * kScRays + tid / (kScSteps / kSPT);
-    const int nbase = sg * kScSteps + (tid % (kScSteps / kSPT)) * kSPT;
-    const bool ray_ok = ray < A.R;
-    const long w = (long)pose * A.R + (ray_ok ? ray : 0);
+    int pose, nbase;
+    bool ray_ok;
+    long w;
+    auto decode = [&](unsigned bid) {
+        const int per_sg = (int)(npatch / (unsigned)step_groups);
+        const int sg = (int)(bid / (unsigned)per_sg);
+        const unsigned Lb = xcd_remap(bid % (unsigned)per_sg, (unsigned)per_sg);
+        const int rg = Lb % ray_groups;
+        pose = Lb / ray_groups;
+        // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..)
+        const int ray = rg * kScRays + tid / (kScSteps / kSPT);
+        nbase = sg * kScSteps + (tid % (kScSteps / kSPT)) * kSPT;
+        ray_ok = ray < A.R;
+        w = (long)pose * A.R + (ray_ok ? ray : 0);
+    };
+    unsigned bid = blockIdx.x;
+    decode(bid);
 
     STAMP(0);
     Pose ps;
     load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    if constexpr (kCanPlanar) {
+        if (scatter_patch_planar<SAMPLER, PM>(A, reinterpret_cast<double *>(tile), s_box, s_planar, ps, w, ray_ok, nbase, tid)) return;
+#ifdef DIFFUS_SC_PLANAR_ONLY // timing probe: the general path compiled out (register budget of the planar path alone)
+        return;
+#endif
+        __syncthreads(); // an oblique patch: every wave has read the records above before the general path rewrites them
+        // The general path starts from scratch: laundering the block index keeps the compiler from carrying the patch
+        // coordinates and the pose across the planar code above in registers it does not have (60 bytes of spills).
+        asm volatile("" : "+s"(bid));
+        decode(bid);
+        load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    }
     Cell cells[kSPT];
     float zb[kSPT];
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
@@ -143,11 +442,8 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         hi[a] = wave_reduce_minmax<false>(hi[a]);
     }
     zsum = wave_sum_to_lane63(zsum);
-    const bool ray_planar = (PM == 0 || ps.pmode != 2) ? (ps.df[2] == 0.f) : (ps.dd[2] == 0.0);
-    const bool wave_planar = kCanPlanar && __ballot(ray_planar) == ~0ull;
     const int wib = tid >> 6;
     if ((tid & 63) == 63) {
-        s_planar[wib] = wave_planar;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             s_wlo[wib][a] = lo[a];
@@ -172,13 +468,9 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
             wlo[wv][a] = __builtin_amdgcn_readfirstlane(s_wlo[wv][a]);
             whi[wv][a] = __builtin_amdgcn_readfirstlane(s_whi[wv][a]);
         }
-    int all_planar = 1; // no short-circuit: the four flags come back with the box records, in one LDS round trip
-#pragma unroll
-    for (int wv = 0; wv < kSW; ++wv) all_planar &= s_planar[wv];
-    const bool planar = kCanPlanar && __builtin_amdgcn_readfirstlane(all_planar) != 0;
     // box of the waves [w0, w0 + cnt); tile entries it needs: 0 for an empty group, kTileCap + 1 when it does not fit
     auto box_of = [&](int w0, int cnt, int (&l)[3], int (&b)[3]) -> int {
-        unsigned v = planar ? UNIT2 : UNIT;
+        unsigned v = UNIT;
         bool empty = false;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -193,10 +485,9 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
             b[a] = mx - mn + 1;
             empty |= mx < 0;
             // only "> kTileCap" matters: saturate so that the 32-bit product cannot overflow
-            const unsigned e = (a == 2 && planar) ? 1u : (unsigned)min(max(b[a], 0), 0x7fff);
+            const unsigned e = (unsigned)min(max(b[a], 0), 0x7fff);
             v = min(v, (unsigned)kTileCap + 1u) * e;
         }
-        if (planar && v > (unsigned)kCap2) v = (unsigned)kTileCap + 1u; // 64-bit entries: half as many fit
         return empty ? 0 : (int)min(v, (unsigned)kTileCap + 1u);
     };
     static_assert(kSW == 4 || kSW == 8, "wave grouping below: 1, 2 or 4 groups of waves");
@@ -212,7 +503,7 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     float ztot = 0.f; // >= every single |zbar| of the patch (a float sum of non-negative terms is monotone)
 #pragma unroll
     for (int wv = 0; wv < kSW; ++wv) ztot += __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_sum[wv])));
-    const int fx = (planar ? 61 : 29) - __builtin_amdgcn_frexp_expf(ztot); // planar: (sum) * 2^fx in [2^60, 2^61)
+    const int fx = 29 - __builtin_amdgcn_frexp_expf(ztot);
     const int wpg = kSW / nsub; // waves per group
 #pragma unroll 1
     for (int sp = 0; sp < nsub; ++sp) { // block-uniform trip count and branches
@@ -245,87 +536,6 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     const int l0 = lb[0], l1 = lb[1], l2 = lb[2], b0 = bb[0], b1 = bb[1], b2 = bb[2];
     const int nt = vol_tile;
     STAMP(3);
-    if (kCanPlanar && planar) {
-        // ---- planar patch: 2-D tile, entry = (brick column, x & 3, y & 3) ----
-        auto part2 = [&](int v, int axis) -> int {
-            return axis == 0 ? ((((v >> 2) - l0) * b1) * UNIT2 + ((v & 3) << 2)) : ((((v >> 2) - l1) * UNIT2) + (v & 3));
-        };
-#pragma unroll
-        for (int q = 0; q < kSPT; ++q)
-            if (mine && zb[q] != 0.f) {
-                const Cell &c = cells[q];
-                const float sc = ldexpf(zb[q], fx);
-                const int ex0 = part2(c.i0[0], 0), ex1 = part2(c.i1[0], 0), ey0 = part2(c.i0[1], 1), ey1 = part2(c.i1[1], 1);
-                const float wa1 = c.t[0], wa0 = 1.f - wa1, wb1 = c.t[1], wb0 = 1.f - wb1;
-                auto add = [&](int e, float v) { // |v| < 2^62: round to a 64-bit integer
-                    // a float of 2^24 or more is an integer multiple of 2^(exponent - 24): its 24-bit mantissa, as an
-                    // int, shifted into place is exact; below that the conversion rounds to nearest (even), sh = 0
-                    const int sh = max(__builtin_amdgcn_frexp_expf(v) - 24, 0);
-                    const int mi = __float2int_rn(ldexpf(v, -sh));
-                    if (mi != 0)
-                        atomicAdd(reinterpret_cast<unsigned long long *>(&tile64[e]), (unsigned long long)((long long)mi << sh));
-                };
-                if constexpr (SAMPLER == DIFFUS_NEAREST) {
-                    add(ex0 + ey0, sc); // i0 == i1: the sample's one voxel column
-                } else {
-                    add(ex0 + ey0, sc * wa0 * wb0);
-                    add(ex0 + ey1, sc * wa0 * wb1);
-                    add(ex1 + ey0, sc * wa1 * wb0);
-                    add(ex1 + ey1, sc * wa1 * wb1);
-                }
-            }
-        // the patch's dim-2 cell (the same in every thread: p2 = source[2] for every sample)
-        const int iz0 = __builtin_amdgcn_readfirstlane(cells[0].i0[2]), iz1 = __builtin_amdgcn_readfirstlane(cells[0].i1[2]);
-        const float tz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cells[0].t[2])));
-        __syncthreads();
-        STAMP(4);
-        // flush: a half-wave = one brick column = the 32 floats (x & 3, y & 3, z) of its brick(s); two lanes share a
-        // tile entry and apply the two depth weights.  z0 even: one brick, a contiguous 128-B atomic run.
-        const int ncols = b0 * b1;
-        const float rb1 = __frcp_rn((float)b1);
-        const int o = tid & 31, msub = tid >> 5, mstep = kSB / 32;
-        const int zz = (o & 1) ? iz1 : iz0;
-        const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
-        const unsigned zpart = (unsigned)(zz >> 1) * kBrickFloats + (unsigned)((o >> 1) << 1) + (unsigned)(zz & 1);
-        constexpr int FU2 = 4;
-        for (int q0 = msub; q0 < ncols; q0 += mstep * FU2) {
-            long long v[FU2];
-#pragma unroll
-            for (int u = 0; u < FU2; ++u) {
-                const int q = q0 + u * mstep;
-                v[u] = (q < ncols) ? tile64[q * UNIT2 + (o >> 1)] : 0ll;
-            }
-            if (nsub > 1) { // leave the tile clean for the next group (after both lanes of a pair have read their entry)
-#pragma unroll
-                for (int u = 0; u < FU2; ++u) {
-                    const int q = q0 + u * mstep;
-                    if (v[u] != 0 && !(o & 1)) tile64[q * UNIT2 + (o >> 1)] = 0ll;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < FU2; ++u) {
-                const int q = q0 + u * mstep;
-                const bool any = (unsigned)(__ballot(v[u] != 0) >> (tid & 32)) != 0u;
-                if (any) {
-                    const int i = __float2int_rz(((float)q + 0.5f) * rb1); // exact: q < 2^14, i * b1 <= q
-                    const int j = q - i * b1;
-                    const unsigned g = ((unsigned)(l0 + i) * (unsigned)A.G.nb1 + (unsigned)(l1 + j)) * (unsigned)A.G.nb2 * kBrickFloats + zpart;
-                    if (A.gtouched && o < 2) A.gtouched[g >> 5] = 1; // lanes 0 and 1: the brick of z0 and the brick of z1
-                    // back to the natural scale first (2^-fx alone may underflow a float), then the depth weight
-                    if (v[u] != 0 && wz != 0.f) atomicAdd(A.gvol + g, ldexpf(__ll2float_rn(v[u]), -fx) * wz);
-                }
-            }
-        }
-        STAMP(5);
-#ifdef DIFFUS_STAMP
-        if (threadIdx.x == 0 && g_stamps) {
-            g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)nt;
-            g_stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)nsub;
-        }
-#endif
-        if (sp + 1 < nsub) __syncthreads();
-        continue;
-    }
     // tile index = ex(i) + ey(j) + ez(k): three separable parts, each evaluated for the two
     // coordinates of its axis only (6 small computations per sample instead of 8 full ones)
     auto part = [&](int v, int axis) -> int {
@@ -506,6 +716,36 @@ __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict
     if (b0 >= nbricks) return;
     const long mine = b0 + lane;
     int f = (mine < nbricks) ? touched[mine] : 0;
+    if (mode == DIFFUS_FLUSH_DENSE) {
+        // EVERY voxel of `out` is written: a lane takes one brick, the wave 64 consecutive ones -- consecutive along dim 2,
+        // so that each of a brick's 16 (x, y) rows is a 512-byte run of the canonical tensor across the wave.
+        if (mine >= nbricks) return;
+        if (f) touched[mine] = 0;
+        const bool live = f == 1; // 2 = left by a PERSISTENT flush: the scratch is already zero there
+        const long bz = mine % G.nb2, t = mine / G.nb2;
+        const long by = t % G.nb1, bx = t / G.nb1;
+        float *bsrc = bricked + mine * kBrickFloats;
+        const int z = (int)bz * 2;
+#pragma unroll 4
+        for (int row = 0; row < 16; ++row) {
+            const int x = (int)bx * 4 + (row >> 2), y = (int)by * 4 + (row & 3);
+            float2 v = make_float2(0.f, 0.f);
+            if (live) {
+                v = *reinterpret_cast<const float2 *>(bsrc + row * 2);
+                *reinterpret_cast<float2 *>(bsrc + row * 2) = make_float2(0.f, 0.f);
+            }
+            if (x < G.d0 && y < G.d1) {
+                float *o = out + ((long)x * G.d1 + y) * G.d2 + z;
+                if (z + 1 < G.d2 && !(G.d2 & 1)) {
+                    *reinterpret_cast<float2 *>(o) = v;
+                } else {
+                    o[0] = v.x;
+                    if (z + 1 < G.d2) o[1] = v.y;
+                }
+            }
+        }
+        return;
+    }
     unsigned long long m = __ballot(f != 0);
     if (m == 0) return; // wave-uniform: nothing touched in these 64 bricks
     if (f) {
@@ -594,7 +834,7 @@ int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, f
                          diffus_stream_t stream)
 {
     if (!bricked || !touched || !vol || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
-    if (accumulate < DIFFUS_FLUSH_STORE || accumulate > DIFFUS_FLUSH_PERSISTENT) return DIFFUS_EINVAL;
+    if (accumulate < DIFFUS_FLUSH_STORE || accumulate > DIFFUS_FLUSH_DENSE) return DIFFUS_EINVAL;
     Geom G = make_geom(d0, d1, d2);
     const long nbricks = (long)(bricked_floats(d0, d1, d2) / kBrickFloats);
     const long waves = (nbricks + kWave - 1) / kWave;

@@ -303,6 +303,102 @@ __global__ __launch_bounds__(kBlock) void splat_gather_kernel(const float *__res
 }
 
 // ----------------------------------------------------------------------------
+// Which two coordinate axes span the image: the two of largest variance, largest first, ties in axis order (reference
+// src/renderer.py:702-707: `variances = [c.float().var().item() ...]`, `sorted(range(3), key=lambda i: -variances[i])[:2]`).
+// The reference decides on the HOST (three .item() syncs); here the decision stays on the device -- one block sums the
+// three planes (values cast to float32 like `.float()`, sums in float64), writes the two axis numbers, and a second
+// launch casts the two chosen planes to float32 for the splat kernels -- so render -> splat -> loss -> backward can be
+// captured as one hipGraph.
+__device__ __forceinline__ float coord_f32(const void *p, int dtype, long i)
+{
+    if (dtype == DIFFUS_F32) return ((const float *)p)[i];
+    if (dtype == DIFFUS_F64) return (float)((const double *)p)[i];
+    return (float)((const long long *)p)[i]; // DIFFUS_I64
+}
+
+constexpr int kAxesThreads = 1024;
+__global__ __launch_bounds__(kAxesThreads) void splat_axes_kernel(const void *x, const void *y, const void *z, int dx, int dy,
+                                                                  int dz, long n, int *__restrict__ axes)
+{
+    __shared__ double sm[6][kAxesThreads / kWave];
+    __shared__ double var[3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ONE pass over the three planes (six running sums): the block's time is the latency of its load chain.
+    // Shifted sums (first element as the pivot): no cancellation for coordinates far from 0.
+    const double p0 = (double)coord_f32(x, dx, 0), p1 = (double)coord_f32(y, dy, 0), p2 = (double)coord_f32(z, dz, 0);
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (long i = threadIdx.x; i < n; i += kAxesThreads) {
+        const double a = (double)coord_f32(x, dx, i) - p0, b = (double)coord_f32(y, dy, i) - p1, c = (double)coord_f32(z, dz, i) - p2;
+        acc[0] += a; acc[1] += a * a;
+        acc[2] += b; acc[3] += b * b;
+        acc[4] += c; acc[5] += c * c;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        acc[k] = wave_sum_to_lane63(acc[k]);
+        if (lane == kWave - 1) sm[k][wv] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double S = 0.0, Q = 0.0;
+        for (int w = 0; w < kAxesThreads / kWave; ++w) { // fixed order: deterministic
+            S += sm[2 * threadIdx.x][w];
+            Q += sm[2 * threadIdx.x + 1][w];
+        }
+        var[threadIdx.x] = (n > 1) ? (Q - S * S / (double)n) / (double)(n - 1) : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // stable descending order of three keys; a NaN variance (NaN coordinates) sorts last
+        int o[3] = {0, 1, 2};
+        auto before = [&](int a, int b) { // a strictly before b
+            const double va = var[a], vb = var[b];
+            if (va != va) return false;
+            if (vb != vb) return true;
+            return va > vb;
+        };
+        for (int i = 1; i < 3; ++i)
+            for (int j = i; j > 0 && before(o[j], o[j - 1]); --j) {
+                const int t = o[j]; o[j] = o[j - 1]; o[j - 1] = t;
+            }
+        axes[0] = o[0];
+        axes[1] = o[1];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void splat_select_kernel(const void *x, const void *y, const void *z, int dx, int dy, int dz,
+                                                              long n, const int *__restrict__ axes, float *__restrict__ c0,
+                                                              float *__restrict__ c1)
+{
+    const int a0 = axes[0], a1 = axes[1]; // uniform: scalar loads
+    const void *p0 = a0 == 0 ? x : (a0 == 1 ? y : z), *p1 = a1 == 0 ? x : (a1 == 1 ? y : z);
+    const int d0 = a0 == 0 ? dx : (a0 == 1 ? dy : dz), d1 = a1 == 0 ? dx : (a1 == 1 ? dy : dz);
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        c0[i] = coord_f32(p0, d0, i);
+        c1[i] = coord_f32(p1, d1, i);
+    }
+}
+
+// rotate_around_apex (reference src/renderer.py:655-692) in one launch: every point (x - shift, z) turned by the angle
+// between (0, 1) and `median`, then moved to `apex`.  apex / median are read from device memory (no host values: the
+// call sits inside captured graphs); the angle goes through atan2 / cos / sin like the reference's.
+__global__ __launch_bounds__(kBlock) void rotate_apex_kernel(const float *__restrict__ x, const float *__restrict__ z, long n,
+                                                             const float *__restrict__ apex, const float *__restrict__ median,
+                                                             float shift, float *__restrict__ xr, float *__restrict__ zr)
+{
+    const float m0 = median[0], m1 = median[1];
+    const float nrm = sqrtf(m0 * m0 + m1 * m1);
+    const float turn = atan2f(__fdiv_rn(m0, nrm), __fdiv_rn(m1, nrm));
+    const float c = cosf(turn), sn = sinf(turn);
+    const float a0 = apex[0], a1 = apex[1];
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        const float u = x[i] - shift, v = z[i];
+        xr[i] = __fadd_rn(__fadd_rn(__fmul_rn(c, u), __fmul_rn(-sn, v)), a0);
+        zr[i] = __fadd_rn(__fadd_rn(__fmul_rn(sn, u), __fmul_rn(c, v)), a1);
+    }
+}
+
+// ----------------------------------------------------------------------------
 // Energy loss used by the benchmarks and examples: loss[p] = sum(frame[p]^2), gframe = 2 * frame,
 // in one streaming pass.  kLossSplit blocks per pose write partial sums, the last of them to arrive adds
 // them in a fixed order (deterministic; one block per pose alone used only P of the 256 CUs).
@@ -374,6 +470,31 @@ size_t diffus_splat_workspace_bytes(int P, int H, int W)
 {
     if (P <= 0 || H <= 0 || W <= 0) return 0;
     return align256(sizeof(int) * (size_t)P * H * W) + 2 * align256(sizeof(float) * (size_t)P * 2 * H * W);
+}
+
+int diffus_rotate_around_apex(const float *x, const float *z, long n, const float *apex, const float *median, float shift,
+                              float *x_rot, float *z_rot, diffus_stream_t stream)
+{
+    if (!x || !z || !apex || !median || !x_rot || !z_rot || n <= 0) return DIFFUS_EINVAL;
+    unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(rotate_apex_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, x, z, n, apex, median, shift, x_rot, z_rot);
+    return last_launch();
+}
+
+int diffus_splat_axes(const void *x, int x_dtype, const void *y, int y_dtype, const void *z, int z_dtype, long n, int *axes,
+                      float *c0, float *c1, diffus_stream_t stream)
+{
+    if (!x || !y || !z || !axes || n <= 0) return DIFFUS_EINVAL;
+    for (int d : {x_dtype, y_dtype, z_dtype})
+        if (d != DIFFUS_F32 && d != DIFFUS_F64 && d != DIFFUS_I64) return DIFFUS_EINVAL;
+    if ((c0 == nullptr) != (c1 == nullptr)) return DIFFUS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(splat_axes_kernel, dim3(1), dim3(kAxesThreads), 0, st, x, y, z, x_dtype, y_dtype, z_dtype, n, axes);
+    if (c0) {
+        unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splat_select_kernel, dim3(nb), dim3(kBlock), 0, st, x, y, z, x_dtype, y_dtype, z_dtype, n, axes, c0, c1);
+    }
+    return last_launch();
 }
 
 int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, long n, int cols, int H, int W,

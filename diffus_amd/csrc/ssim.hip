@@ -1,0 +1,314 @@
+// ssim.hip -- the loss the reference's training notebook attaches after the scan conversion:
+//     synth = (img - img.min()) / (img.max() - img.min() + 1e-8);   loss = 1 - piq.ssim(synth, real, data_range=1.0)
+// (reference notebooks/[DEMO] Train MRI to Impedance MLP - GPU.ipynb cell 16, `UltrasoundSynthesisModel.loss`), forward and
+// backward, fused into five small launches so that the whole training iteration fits one short hipGraph (as torch ops it is
+// ~110 kernels, eight of them MIOpen convolutions of ~20 us).  SSIM = Wang, Bovik, Sheikh & Simoncelli, IEEE TIP 2004,
+// with piq's defaults: 11 x 11 Gaussian window of sigma 1.5 ('valid' correlation), K1 = 0.01, K2 = 0.03, mean over the
+// map.  piq is a third-party package (not in the reference's requirements.txt, not installed here): the formula is
+// restated from the paper; examples/losses.py holds the same thing in plain torch and is what the tests compare with.
+#include "diffus_host.hpp"
+
+namespace {
+
+constexpr int kSsimMaxWin = 15;
+constexpr int kSsimTile = 16;
+constexpr int kSsimPatch = kSsimTile + kSsimMaxWin - 1;
+
+struct SsimArgs {
+    const float *img, *ref;
+    int H, W, Hm, Wm, win;
+    float c1, c2;
+    int normalise;
+    int reuse_stats; // backward: stats[0..3] still hold the forward's min / max / tie counts of this very image
+    float *stats; // [0] lo [1] hi [2] ties of lo [3] ties of hi [4] sum of the SSIM map [5] dL/dlo [6] dL/dhi [7] block counter (as int)
+    float *loss;
+    const float *gloss; // nullable: upstream gradient of the loss (device scalar)
+    float *gmap;        // (3, Hm, Wm): dL/d mu_x, dL/d E[x^2], dL/d E[xy] per map position
+    float *gimg;
+    float w1d[kSsimMaxWin]; // normalised 1-D Gaussian: the 2-D window is its outer product
+};
+
+// lo / hi of the image and how many pixels attain them (torch's min() / max() backward shares the gradient equally
+// among ties -- and a splat image has thousands of exact zeros); also clears the accumulators of the other kernels
+__global__ __launch_bounds__(1024) void ssim_minmax_kernel(SsimArgs A)
+{
+    __shared__ float s_lo[16], s_hi[16];
+    __shared__ int s_cl[16], s_ch[16];
+    __shared__ float b_lo, b_hi;
+    const long n = (long)A.H * A.W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    bool nan = false;
+    // four independent loads per trip: one block walks the whole image, so its time is the latency of its load chain
+    const long n4 = n & ~3L;
+    for (long i = 4L * threadIdx.x; i < n4; i += 4096) {
+        const float v0 = A.img[i], v1 = A.img[i + 1], v2 = A.img[i + 2], v3 = A.img[i + 3];
+        nan |= (v0 != v0) | (v1 != v1) | (v2 != v2) | (v3 != v3);
+        lo = fminf(fminf(lo, v0), fminf(fminf(v1, v2), v3));
+        hi = fmaxf(fmaxf(hi, v0), fmaxf(fmaxf(v1, v2), v3));
+    }
+    for (long i = n4 + threadIdx.x; i < n; i += 1024) {
+        const float v = A.img[i];
+        nan |= v != v;
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    if (nan) lo = hi = __builtin_nanf(""); // torch.min / max propagate NaN
+    for (int o = 32; o > 0; o >>= 1) {
+        const float l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = (lo != lo || l2 != l2) ? __builtin_nanf("") : fminf(lo, l2);
+        hi = (hi != hi || h2 != h2) ? __builtin_nanf("") : fmaxf(hi, h2);
+    }
+    if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l = s_lo[0], h = s_hi[0];
+        for (int w = 1; w < 16; ++w) {
+            l = (l != l || s_lo[w] != s_lo[w]) ? __builtin_nanf("") : fminf(l, s_lo[w]);
+            h = (h != h || s_hi[w] != s_hi[w]) ? __builtin_nanf("") : fmaxf(h, s_hi[w]);
+        }
+        b_lo = l; b_hi = h;
+    }
+    __syncthreads();
+    lo = b_lo; hi = b_hi;
+    int cl = 0, ch = 0;
+    for (long i = 4L * threadIdx.x; i < n4; i += 4096) {
+        const float v0 = A.img[i], v1 = A.img[i + 1], v2 = A.img[i + 2], v3 = A.img[i + 3];
+        cl += (v0 == lo) + (v1 == lo) + (v2 == lo) + (v3 == lo);
+        ch += (v0 == hi) + (v1 == hi) + (v2 == hi) + (v3 == hi);
+    }
+    for (long i = n4 + threadIdx.x; i < n; i += 1024) {
+        const float v = A.img[i];
+        cl += v == lo;
+        ch += v == hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) { cl += __shfl_xor(cl, o); ch += __shfl_xor(ch, o); }
+    if (lane == 0) { s_cl[wv] = cl; s_ch[wv] = ch; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tl = 0, th = 0;
+        for (int w = 0; w < 16; ++w) { tl += s_cl[w]; th += s_ch[w]; }
+        A.stats[0] = lo; A.stats[1] = hi; A.stats[2] = (float)tl; A.stats[3] = (float)th;
+        A.stats[4] = 0.f; A.stats[5] = 0.f; A.stats[6] = 0.f;
+        reinterpret_cast<int *>(A.stats)[7] = 0;
+    }
+}
+
+__device__ __forceinline__ float ssim_x(const SsimArgs &A, float v, float lo, float den)
+{
+    return A.normalise ? __fdiv_rn(v - lo, den) : v;
+}
+
+// One map position per thread, 16 x 16 positions per block, the (16 + win - 1)^2 patches of x and y in LDS.
+// GRAD = false: sum of the SSIM map (-> loss by the last block).  GRAD = true: the three partial derivatives per position.
+template <bool GRAD>
+__global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_map_kernel(SsimArgs A)
+{
+    __shared__ float px[kSsimPatch][kSsimPatch + 1], py[kSsimPatch][kSsimPatch + 1];
+    __shared__ float s_part[4];
+    const int tx = threadIdx.x % kSsimTile, ty = threadIdx.x / kSsimTile;
+    const int r0 = blockIdx.y * kSsimTile, c0 = blockIdx.x * kSsimTile;
+    const int pw = kSsimTile + A.win - 1;
+    const float lo = A.normalise ? A.stats[0] : 0.f;
+    const float den = A.normalise ? __fadd_rn(A.stats[1] - lo, 1e-8f) : 1.f;
+    for (int e = threadIdx.x; e < pw * pw; e += kSsimTile * kSsimTile) {
+        const int r = e / pw, c = e - r * pw, gr = r0 + r, gc = c0 + c;
+        const bool in = gr < A.H && gc < A.W;
+        px[r][c] = in ? ssim_x(A, A.img[(long)gr * A.W + gc], lo, den) : 0.f;
+        py[r][c] = in ? A.ref[(long)gr * A.W + gc] : 0.f;
+    }
+    __syncthreads();
+    const int r = r0 + ty, c = c0 + tx;
+    const bool live = r < A.Hm && c < A.Wm;
+    float mx = 0.f, my = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+    for (int i = 0; i < A.win; ++i) {
+        float rx = 0.f, ry = 0.f, rxx = 0.f, ryy = 0.f, rxy = 0.f;
+        for (int j = 0; j < A.win; ++j) {
+            const float w = A.w1d[j], x = px[ty + i][tx + j], y = py[ty + i][tx + j];
+            rx = __builtin_fmaf(w, x, rx); ry = __builtin_fmaf(w, y, ry);
+            rxx = __builtin_fmaf(w, x * x, rxx); ryy = __builtin_fmaf(w, y * y, ryy); rxy = __builtin_fmaf(w, x * y, rxy);
+        }
+        const float w = A.w1d[i];
+        mx = __builtin_fmaf(w, rx, mx); my = __builtin_fmaf(w, ry, my);
+        exx = __builtin_fmaf(w, rxx, exx); eyy = __builtin_fmaf(w, ryy, eyy); exy = __builtin_fmaf(w, rxy, exy);
+    }
+    const float sxx = exx - mx * mx, syy = eyy - my * my, sxy = exy - mx * my;
+    const float a1 = 2.f * mx * my + A.c1, a2 = 2.f * sxy + A.c2, b1 = mx * mx + my * my + A.c1, b2 = sxx + syy + A.c2;
+    const float ib = __fdiv_rn(1.f, b1 * b2);
+    const float S = a1 * a2 * ib;
+    if constexpr (!GRAD) {
+        float v = live ? S : 0.f;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&A.stats[4], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+            __threadfence();
+            const int done = atomicAdd(reinterpret_cast<int *>(A.stats) + 7, 1);
+            if (done == (int)(gridDim.x * gridDim.y) - 1) { // the last block: every partial sum is in
+                const float tot = atomicAdd(&A.stats[4], 0.f);
+                A.loss[0] = 1.f - tot / (float)((long)A.Hm * A.Wm);
+            }
+        }
+    } else {
+        if (A.reuse_stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) A.stats[5] = A.stats[6] = 0.f; // ssim_back_kernel adds into them
+        if (live) {
+            // loss = 1 - mean(S): every position weighs -gloss / N
+            const float k = -(A.gloss ? A.gloss[0] : 1.f) / (float)((long)A.Hm * A.Wm);
+            const float dmx = (2.f * my * (a2 - a1)) * ib - 2.f * mx * S / b1 + 2.f * mx * S / b2;
+            const float dexx = -S / b2;
+            const float dexy = 2.f * a1 * ib;
+            const long q = (long)r * A.Wm + c, hw = (long)A.Hm * A.Wm;
+            A.gmap[q] = k * dmx;
+            A.gmap[hw + q] = k * dexx;
+            A.gmap[2 * hw + q] = k * dexy;
+        }
+    }
+}
+
+// dL/dx(p) = sum over the map positions q whose window covers p of w(p - q) (G_mu(q) + 2 x(p) G_xx(q) + y(p) G_xy(q)),
+// then through the normalisation: dL/dimg = dL/dx / den, and the sums that go to the min / max pixels
+__global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_back_kernel(SsimArgs A)
+{
+    __shared__ float g[3][kSsimPatch][kSsimPatch + 1];
+    __shared__ float s_a[4], s_b[4];
+    const int tx = threadIdx.x % kSsimTile, ty = threadIdx.x / kSsimTile;
+    const int r0 = blockIdx.y * kSsimTile, c0 = blockIdx.x * kSsimTile;
+    const int pw = kSsimTile + A.win - 1, off = A.win - 1;
+    const long hw = (long)A.Hm * A.Wm;
+    for (int e = threadIdx.x; e < pw * pw; e += kSsimTile * kSsimTile) {
+        const int r = e / pw, c = e - r * pw, qr = r0 + r - off, qc = c0 + c - off;
+        const bool in = qr >= 0 && qc >= 0 && qr < A.Hm && qc < A.Wm;
+        const long q = (long)qr * A.Wm + qc;
+        g[0][r][c] = in ? A.gmap[q] : 0.f;
+        g[1][r][c] = in ? A.gmap[hw + q] : 0.f;
+        g[2][r][c] = in ? A.gmap[2 * hw + q] : 0.f;
+    }
+    __syncthreads();
+    const int r = r0 + ty, c = c0 + tx;
+    const bool live = r < A.H && c < A.W;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int i = 0; i < A.win; ++i) {
+        float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+        for (int j = 0; j < A.win; ++j) { // q = p - (i, j): patch index (ty + off - i, tx + off - j)
+            const float w = A.w1d[j];
+            u0 = __builtin_fmaf(w, g[0][ty + off - i][tx + off - j], u0);
+            u1 = __builtin_fmaf(w, g[1][ty + off - i][tx + off - j], u1);
+            u2 = __builtin_fmaf(w, g[2][ty + off - i][tx + off - j], u2);
+        }
+        const float w = A.w1d[i];
+        t0 = __builtin_fmaf(w, u0, t0); t1 = __builtin_fmaf(w, u1, t1); t2 = __builtin_fmaf(w, u2, t2);
+    }
+    float da = 0.f, db = 0.f;
+    if (live) {
+        const long p = (long)r * A.W + c;
+        const float lo = A.normalise ? A.stats[0] : 0.f;
+        const float den = A.normalise ? __fadd_rn(A.stats[1] - lo, 1e-8f) : 1.f;
+        const float x = ssim_x(A, A.img[p], lo, den), y = A.ref[p];
+        const float gx = t0 + 2.f * x * t1 + y * t2;
+        if (A.normalise) {
+            const float s = __fdiv_rn(1.f, den);
+            A.gimg[p] = gx * s;
+            da = -gx * s * (1.f - x); // d x / d lo = -(1 - x) / den
+            db = -gx * s * x;         // d x / d hi = -x / den
+        } else {
+            A.gimg[p] = gx;
+        }
+    }
+    if (A.normalise) {
+        for (int o = 32; o > 0; o >>= 1) { da += __shfl_xor(da, o); db += __shfl_xor(db, o); }
+        if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = da; s_b[threadIdx.x >> 6] = db; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&A.stats[5], s_a[0] + s_a[1] + s_a[2] + s_a[3]);
+            atomicAdd(&A.stats[6], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+        }
+    }
+}
+
+// the gradient of img.min() / img.max(): shared equally by the pixels that attain them (torch: evenly_distribute_backward)
+__global__ __launch_bounds__(kBlock) void ssim_ties_kernel(SsimArgs A)
+{
+    const long n = (long)A.H * A.W;
+    const float lo = A.stats[0], hi = A.stats[1];
+    const float glo = A.stats[5] / A.stats[2], ghi = A.stats[6] / A.stats[3];
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        const float v = A.img[i];
+        float add = 0.f;
+        if (v == lo) add += glo;
+        if (v == hi) add += ghi;
+        if (add != 0.f) A.gimg[i] += add;
+    }
+}
+
+int ssim_setup(SsimArgs &A, const float *img, const float *ref, int H, int W, int normalise, int win, float sigma, float k1,
+               float k2, void *workspace, size_t workspace_bytes)
+{
+    if (!img || !ref || H <= 0 || W <= 0 || win < 1 || win > kSsimMaxWin || !(win & 1) || !(sigma > 0.f)) return DIFFUS_EINVAL;
+    if (H < win || W < win) return DIFFUS_EINVAL;
+    A.img = img; A.ref = ref; A.H = H; A.W = W; A.Hm = H - win + 1; A.Wm = W - win + 1; A.win = win;
+    A.c1 = k1 * k1; A.c2 = k2 * k2; A.normalise = normalise != 0;
+    if (!workspace || workspace_bytes < align256(8 * sizeof(float)) + sizeof(float) * 3 * (size_t)A.Hm * A.Wm) return DIFFUS_EWORKSPACE;
+    A.stats = (float *)workspace;
+    A.gmap = (float *)((char *)workspace + align256(8 * sizeof(float)));
+    // normalised 2-D Gaussian exp(-(i^2 + j^2) / (2 sigma^2)) / sum = outer product of the normalised 1-D one
+    double w[kSsimMaxWin], tot = 0.0;
+    for (int i = 0; i < win; ++i) {
+        const double c = i - (win - 1) / 2.0;
+        w[i] = exp(-(c * c) / (2.0 * (double)sigma * sigma));
+        tot += w[i];
+    }
+    for (int i = 0; i < kSsimMaxWin; ++i) A.w1d[i] = i < win ? (float)(w[i] / tot) : 0.f;
+    return DIFFUS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t diffus_ssim_workspace_bytes(int H, int W, int win)
+{
+    if (H <= 0 || W <= 0 || win < 1 || H < win || W < win) return 0;
+    return align256(8 * sizeof(float)) + align256(sizeof(float) * 3 * (size_t)(H - win + 1) * (W - win + 1));
+}
+
+int diffus_ssim_loss_fwd(const float *img, const float *ref, int H, int W, int normalise, int win, float sigma, float k1, float k2,
+                         float *loss, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+{
+    SsimArgs A{};
+    int rc = ssim_setup(A, img, ref, H, W, normalise, win, sigma, k1, k2, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!loss) return DIFFUS_EINVAL;
+    A.loss = loss;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(1024), 0, st, A); // (also clears the accumulators: needed without normalisation too)
+    dim3 grid((A.Wm + kSsimTile - 1) / kSsimTile, (A.Hm + kSsimTile - 1) / kSsimTile);
+    hipLaunchKernelGGL(ssim_map_kernel<false>, grid, dim3(kSsimTile * kSsimTile), 0, st, A);
+    return last_launch();
+}
+
+int diffus_ssim_loss_bwd(const float *img, const float *ref, int H, int W, int normalise, int win, float sigma, float k1, float k2,
+                         const float *gloss, float *gimg, int reuse_stats, void *workspace, size_t workspace_bytes,
+                         diffus_stream_t stream)
+{
+    SsimArgs A{};
+    int rc = ssim_setup(A, img, ref, H, W, normalise, win, sigma, k1, k2, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!gimg) return DIFFUS_EINVAL;
+    A.gloss = gloss; A.gimg = gimg;
+    A.reuse_stats = (reuse_stats != 0) && A.normalise;
+    hipStream_t st = (hipStream_t)stream;
+    // min / max and the tie counts: recomputed, unless the caller vouches that `workspace` still holds the forward's
+    if (A.normalise && !A.reuse_stats) hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(1024), 0, st, A);
+    dim3 gm((A.Wm + kSsimTile - 1) / kSsimTile, (A.Hm + kSsimTile - 1) / kSsimTile);
+    hipLaunchKernelGGL(ssim_map_kernel<true>, gm, dim3(kSsimTile * kSsimTile), 0, st, A);
+    dim3 gi((W + kSsimTile - 1) / kSsimTile, (H + kSsimTile - 1) / kSsimTile);
+    hipLaunchKernelGGL(ssim_back_kernel, gi, dim3(kSsimTile * kSsimTile), 0, st, A);
+    if (A.normalise) {
+        unsigned nb = (unsigned)(((long)H * W + kBlock - 1) / kBlock); if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(ssim_ties_kernel, dim3(nb), dim3(kBlock), 0, st, A);
+    }
+    return last_launch();
+}
+
+} // extern "C"

@@ -97,16 +97,16 @@ class ImpedanceEstimator(nn.Module):
     @classmethod
     def train_model(cls, X: torch.Tensor, y: torch.Tensor, input_dim: int = 1, lr: float = 1e-3,
                     epochs: int = 5000) -> "ImpedanceEstimator":
-        """Fit on paired data with Adam + MSE (reference :19-36); forward/backward in the fused kernels."""
-        model = cls(input_dim)
-        optimizer = torch.optim.Adam(model.parameters(), lr=lr)
-        loss_fn = nn.MSELoss()
-        for _ in range(epochs):
-            optimizer.zero_grad()
-            loss = loss_fn(model(X), y)
-            loss.backward()
-            optimizer.step()
-        return model
+        """A fresh estimator fitted to the (X, y) pairs: `epochs` full-batch Adam steps on the mean squared error -- the
+        recipe of reference src/impedance.py:19-36 --, every forward and backward through the fused MLP kernels."""
+        net = cls(input_dim)
+        adam = torch.optim.Adam(net.parameters(), lr=lr)
+        for _epoch in range(int(epochs)):
+            err = torch.nn.functional.mse_loss(net(X), y)
+            adam.zero_grad(set_to_none=True)
+            err.backward()
+            adam.step()
+        return net
 
     @staticmethod
     def compute_impedance_volume(volume: torch.Tensor, model: "ImpedanceEstimator", threshold: float = 50) -> torch.Tensor:

@@ -81,11 +81,47 @@ def _device_for(t: torch.Tensor) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+# The drop-in path is HOST-bound (a 32-pose step is ~0.1 ms of kernels): what follows avoids torch/ctypes work that buys
+# nothing per call -- the raw stream handle instead of a Stream object, plain ints for pointers (ctypes converts them to
+# void* itself), no device context switch when the device is already current, no detach()/to()/contiguous() dispatches
+# for tensors that are already what the kernels need.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream_id(dev) -> int:
+    """The current HIP stream of `dev` as an integer handle."""
+    idx = dev.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if _raw_stream is not None:
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _Scope:
+    """`with _Scope(dev):` = torch.cuda.device(dev), skipped altogether when `dev` is already the current device."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        idx = dev.index
+        cur = _cur_device() if _cur_device is not None else torch.cuda.current_device()
+        self.ctx = None if (idx is None or idx == cur) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*a)
+
+
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     """Scratch of the current stream of `dev` (one buffer per stream: two streams or autograd worker threads on one
     device never share contents).  A buffer that has to grow is replaced; the caching allocator hands the old block out
     again only to allocations of the same stream, i.e. behind the kernels still using it."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev, _stream_id(dev))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
@@ -93,10 +129,24 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+_ws_bytes: dict = {}
+
+
+def _render_ws_bytes(P: int, R: int, S: int, start: int) -> int:
+    """diffus_workspace_bytes, remembered per shape (a ctypes round trip per call otherwise)."""
+    key = (P, R, S, start)
+    n = _ws_bytes.get(key)
+    if n is None:
+        if len(_ws_bytes) > 256:
+            _ws_bytes.clear()
+        n = _ws_bytes[key] = _lib.load().diffus_workspace_bytes(P, R, S, start)
+    return n
+
+
 def _gradbuf(dev: torch.device, shape):
     """Persistent sparse-gradient scratch of a device/shape/stream: bricked floats + one flag per brick.
     Invariant: both all-zero whenever no backward is in flight on that stream (diffus_gradbuf_flush restores it)."""
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _stream_id(dev)
     key = (dev, tuple(shape), stream)   # one scratch per stream: no cross-stream races
     gb = _gradbufs.pop(key, None)
     if gb is None:
@@ -118,8 +168,10 @@ def _pose_dtype(t: torch.Tensor) -> torch.dtype:
 
 
 def _as(t: torch.Tensor, dev: torch.device, dtype: torch.dtype) -> torch.Tensor:
-    """t.detach().to(dev, dtype).contiguous() without dispatching the ops that would be no-ops (each costs
-    microseconds of host time, and a training step through autograd is host-bound)."""
+    """A tensor on `dev` of `dtype`, contiguous, for the kernels to READ (only its data pointer is used: no autograd
+    history is created on it).  Already the case -- the usual one -- : the tensor itself, no dispatch at all."""
+    if t.device == dev and t.dtype == dtype and t.is_contiguous():
+        return t
     t = t.detach()
     if t.device != dev or t.dtype != dtype:
         t = t.to(device=dev, dtype=dtype)
@@ -127,11 +179,11 @@ def _as(t: torch.Tensor, dev: torch.device, dtype: torch.dtype) -> torch.Tensor:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None        # ctypes turns the int into the void* of the signature
 
 
-def _stream(dev) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+def _stream(dev) -> int:
+    return _stream_id(dev)
 
 
 def brick_volume(volume: torch.Tensor) -> torch.Tensor:
@@ -140,7 +192,7 @@ def brick_volume(volume: torch.Tensor) -> torch.Tensor:
     dev = _device_for(volume)
     v = volume.detach().to(device=dev, dtype=torch.float32).contiguous()
     d0, d1, d2 = v.shape
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         out = torch.empty(lib.diffus_bricked_floats(d0, d1, d2), dtype=torch.float32, device=dev)
         rc = lib.diffus_brick_volume(_ptr(v), d0, d1, d2, _ptr(out), _stream(dev))
     _lib.check(rc, "diffus_brick_volume")
@@ -153,7 +205,7 @@ def pair_volume(volume: torch.Tensor) -> torch.Tensor:
     dev = _device_for(volume)
     v = volume.detach().to(device=dev, dtype=torch.float32).contiguous()
     d0, d1, d2 = v.shape
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         out = torch.empty(lib.diffus_paired_floats(d0, d1, d2), dtype=torch.float32, device=dev)
         rc = lib.diffus_pair_volume(_ptr(v), d0, d1, d2, _ptr(out), _stream(dev))
     _lib.check(rc, "diffus_pair_volume")
@@ -165,7 +217,7 @@ def unbrick_volume(bricked: torch.Tensor, shape, out: Optional[torch.Tensor] = N
     lib = _lib.load()
     d0, d1, d2 = (int(x) for x in shape)
     dev = bricked.device
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         if out is None:
             out = torch.empty((d0, d1, d2), dtype=torch.float32, device=dev)
             accumulate = False
@@ -254,10 +306,13 @@ class _Problem:
             self.vol = _as(volume, self.dev, torch.float32)
             self.bricked = None
         self._layout_req, self._vol_src = layout, volume
+        self._common = None
         sd, dd = _pose_dtype(sources), _pose_dtype(directions)
-        self.src = _as(sources, self.dev, sd).reshape(-1, 3)
-        if not self.src.is_contiguous():
-            self.src = self.src.contiguous()
+        self.src = _as(sources, self.dev, sd)
+        if self.src.dim() != 2 or self.src.shape[1] != 3:
+            self.src = self.src.reshape(-1, 3)
+            if not self.src.is_contiguous():
+                self.src = self.src.contiguous()
         d = _as(directions, self.dev, dd)
         if d.dim() == 1:
             d = d.unsqueeze(0)
@@ -279,14 +334,16 @@ class _Problem:
             self.layout = _lib.BRICKED
 
     def common(self):
-        d0, d1, d2 = self.shape
-        v = self.bricked if self.layout != _lib.CANONICAL else self.vol
-        return (_ptr(v), d0, d1, d2, self.layout, _ptr(self.src), self.src_dt, _ptr(self.dirs), self.dir_dt,
-                self.P, self.R, self.S, self.start, self.alpha, self.sampler)
+        c = self._common
+        if c is None:
+            d0, d1, d2 = self.shape
+            v = self.bricked if self.layout != _lib.CANONICAL else self.vol
+            c = self._common = (_ptr(v), d0, d1, d2, self.layout, _ptr(self.src), self.src_dt, _ptr(self.dirs), self.dir_dt,
+                                self.P, self.R, self.S, self.start, self.alpha, self.sampler)
+        return c
 
     def workspace(self):
-        n = _lib.load().diffus_workspace_bytes(self.P, self.R, self.S, self.start)
-        return _workspace(self.dev, n)
+        return _workspace(self.dev, _render_ws_bytes(self.P, self.R, self.S, self.start))
 
 
 class _RenderFn(torch.autograd.Function):
@@ -296,7 +353,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, volume, sources, directions, S, start, alpha, sampler, want_idx, layout, shape):
         lib = _lib.load()
         pb = _Problem(volume, sources, directions, S, start, alpha, sampler, layout, shape)
-        with torch.cuda.device(pb.dev):
+        with _Scope(pb.dev):
             frame = torch.empty((pb.P, pb.R, pb.N1), dtype=torch.float32, device=pb.dev)
             idx = torch.empty((3, pb.P, pb.R, pb.N1), dtype=torch.int64, device=pb.dev) if want_idx else None
             ws = pb.workspace()
@@ -306,7 +363,15 @@ class _RenderFn(torch.autograd.Function):
         # The backward recomputes the forward from the tensors as they are THEN (nothing is stashed by value): it is
         # only right if they are unchanged, so their in-place version counters are checked like autograd checks saved
         # tensors.
-        ctx.versions = (volume, volume._version, sources, sources._version, directions, directions._version)
+        # Checked only for the inputs the kernels will actually READ AGAIN through the caller's storage: a private copy
+        # made above (device / dtype conversion, the cached bricked or paired volume) keeps the forward's values whatever
+        # the caller does to the original afterwards.
+        reads_vol = pb.vol is not None and pb.layout == _lib.CANONICAL and pb.vol.data_ptr() == volume.data_ptr()
+        reads_bricked = pb.vol is None and pb.bricked.data_ptr() == volume.data_ptr()          # a BrickedVolume's own data
+        ctx.versions = tuple((name, t, t._version) for name, t, aliased in (
+            ("volume", volume, reads_vol or reads_bricked),
+            ("sources", sources, pb.src.data_ptr() == sources.data_ptr()),
+            ("directions", directions, pb.dirs.data_ptr() == directions.data_ptr())) if aliased)
         ctx.meta = (volume.device, volume.dtype, sources.device, sources.dtype, tuple(sources.shape),
                     directions.device, directions.dtype, tuple(directions.shape))
         if idx is None:
@@ -319,14 +384,13 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, gframe, _gidx):
         lib = _lib.load()
         pb = ctx.pb
-        tv, vv, ts, vs, td, vd = ctx.versions
-        for name, t, ver in (("volume", tv, vv), ("sources", ts, vs), ("directions", td, vd)):
+        for name, t, ver in ctx.versions:
             if t._version != ver:
                 raise RuntimeError(f"diffus_amd: `{name}` was modified in place between the forward and this backward "
                                    f"(version {ver} -> {t._version}); the backward recomputes the forward from its inputs")
         vdev, vdt, sdev, sdt, sshape, ddev, ddt, dshape = ctx.meta
         need_v, need_s, need_d = ctx.needs_input_grad[:3]
-        with torch.cuda.device(pb.dev):
+        with _Scope(pb.dev):
             g = _as(gframe, pb.dev, torch.float32)
             gvol = touched = None
             sparse = False
@@ -344,9 +408,9 @@ class _RenderFn(torch.autograd.Function):
             rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(touched), _ptr(gsrc), _ptr(gdirs),
                                        _lib.BWD_ALL, _ptr(ws), ws.numel(), _stream(pb.dev))
             _lib.check(rc, "diffus_render_bwd")
-            if sparse:      # only the bricks the fans touched travel back to the caller's (d0,d1,d2)
-                dense = torch.zeros(pb.shape, dtype=torch.float32, device=pb.dev)
-                rc = lib.diffus_gradbuf_flush(_ptr(gvol), _ptr(touched), *pb.shape, _ptr(dense), 0, _stream(pb.dev))
+            if sparse:      # a fresh dense (d0,d1,d2) gradient in ONE launch: touched bricks' values, zeros elsewhere
+                dense = torch.empty(pb.shape, dtype=torch.float32, device=pb.dev)
+                rc = lib.diffus_gradbuf_flush(_ptr(gvol), _ptr(touched), *pb.shape, _ptr(dense), _lib.FLUSH_DENSE, _stream(pb.dev))
                 _lib.check(rc, "diffus_gradbuf_flush")
                 gvol = dense
         out_v = (gvol if (gvol.device == vdev and gvol.dtype == vdt) else gvol.to(device=vdev, dtype=vdt)) if need_v else None
@@ -395,7 +459,7 @@ def trace_rays(volume, sources, directions, num_samples, sampler="nearest", want
     """Stage 1 alone (diffus_trace_rays): -> dict with imp (P,R,S), refl (P,R,S-1), idx (3,P,R,S)."""
     lib = _lib.load()
     pb = _Problem(volume, sources, directions, num_samples, 0, 0.0, sampler, layout)
-    with torch.cuda.device(pb.dev):
+    with _Scope(pb.dev):
         imp = torch.empty((pb.P, pb.R, pb.S), dtype=torch.float32, device=pb.dev) if "imp" in want else None
         refl = torch.empty((pb.P, pb.R, pb.S - 1), dtype=torch.float32, device=pb.dev) if "refl" in want else None
         idx = torch.empty((3, pb.P, pb.R, pb.S), dtype=torch.int64, device=pb.dev) if "idx" in want else None
@@ -405,34 +469,79 @@ def trace_rays(volume, sources, directions, num_samples, sampler="nearest", want
     return {"imp": imp, "refl": refl, "idx": idx}
 
 
+class _EchoFn(torch.autograd.Function):
+    """echo = diffus_echo_traces(r); backward = diffus_echo_traces_bwd (the O(N) adjoint of SURVEY App. A.4) -- what torch
+    autograd does through the reference's N+1 linalg.solve nodes (src/renderer.py:407,430,454).  `cumulate`: the running
+    sum of propagate_full_rays_batched (:435) on top (its adjoint is a reversed running sum of the incoming gradient)."""
+
+    @staticmethod
+    def forward(ctx, refLR, cumulate):
+        lib = _lib.load()
+        dev = _device_for(refLR)
+        r = _as(refLR, dev, torch.float32)
+        B, N = r.shape
+        with _Scope(dev):
+            out = torch.empty((B, N + 1), dtype=torch.float32, device=dev)
+            if B:
+                fn, name = (lib.diffus_propagate_rays, "diffus_propagate_rays") if cumulate else (lib.diffus_echo_traces, "diffus_echo_traces")
+                _lib.check(fn(_ptr(r) if N else None, B, N, _ptr(out), _stream(dev)), name)
+        ctx.r, ctx.cumulate = r, bool(cumulate)
+        ctx.meta = (refLR.device, refLR.dtype if refLR.is_floating_point() else torch.float32)
+        return out.to(device=ctx.meta[0], dtype=ctx.meta[1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        lib = _lib.load()
+        r = ctx.r
+        dev = r.device
+        B, N = r.shape
+        g = _as(gout, dev, torch.float32)
+        if ctx.cumulate:            # d/d echo_n = sum over m >= n of d/d cum_m
+            g = torch.flip(torch.cumsum(torch.flip(g, (1,)), 1), (1,)).contiguous()
+        with _Scope(dev):
+            gr = torch.zeros((B, N), dtype=torch.float32, device=dev)
+            if B and N:
+                nws = lib.diffus_echo_bwd_workspace_bytes(B, N)
+                ws = torch.empty(nws, dtype=torch.uint8, device=dev)    # own buffer: (N+1) x B x 36 bytes can be large
+                _lib.check(lib.diffus_echo_traces_bwd(_ptr(r), B, N, _ptr(g), _ptr(gr), _ptr(ws), ws.numel(), _stream(dev)),
+                           "diffus_echo_traces_bwd")
+        return gr.to(device=ctx.meta[0], dtype=ctx.meta[1]), None
+
+
 def compute_echo_traces(refLR: torch.Tensor, spacing: float = 1.0, c: float = 1.54e3):
-    """Mirror of reference src/renderer.py:439-457: (echo_signals (B,N+1), delays_us (N+1,))."""
-    lib = _lib.load()
+    """Mirror of reference src/renderer.py:439-457: (echo_signals (B,N+1), delays_us (N+1,)).  Differentiable in refLR
+    like the reference's (diffus_echo_traces_bwd: the O(N) adjoint instead of N+1 LinalgSolveBackward nodes)."""
     if refLR.dim() != 2:
         raise ValueError("not enough values to unpack (expected 2, got %d)" % refLR.dim())  # B, N = refLR.shape
-    dev = _device_for(refLR)
-    r = refLR.detach().to(device=dev, dtype=torch.float32).contiguous()
-    B, N = r.shape
-    with torch.cuda.device(dev):
-        echo = torch.empty((B, N + 1), dtype=torch.float32, device=dev)
-        rc = lib.diffus_echo_traces(_ptr(r) if N else None, B, N, _ptr(echo), _stream(dev))
-    _lib.check(rc, "diffus_echo_traces")
+    N = refLR.shape[1]
+    echo = _EchoFn.apply(refLR, False)
     delays_us = 2 * spacing * torch.arange(N + 1, device=refLR.device) / c
-    return echo.to(device=refLR.device, dtype=refLR.dtype if refLR.is_floating_point() else torch.float32), delays_us
+    return echo, delays_us
 
 
 def prop_single_ray(refLR: torch.Tensor, traLR: torch.Tensor = None, traRL: torch.Tensor = None) -> torch.Tensor:
     """Mirror of reference src/renderer.py:367-410: refLR (B,N) -> w (B, 2(N+1)) = [g0,d0,...,gN,dN], the solution of
     the dense interface system of every ray -- evaluated in closed form on the GPU (diffus_prop_single_ray) instead of
-    torch.linalg.solve.  `traLR` / `traRL` are accepted and ignored, as in the reference (:380-381 overwrite them)."""
+    torch.linalg.solve.  `traLR` / `traRL` are accepted and ignored, as in the reference (:380-381 overwrite them).
+
+    Two differences from the reference, both loud or documented: (1) the FULL solution vector has no backward here --
+    a `refLR` that requires grad raises instead of silently returning a tensor without grad_fn (the echo series, i.e.
+    w[:, 1] of every truncation, IS differentiable: compute_echo_traces / propagate_full_rays_batched);  (2) the
+    reference's nan_to_num(nan=0.0) (:408) maps +-inf entries of a solved system to +-float max, this closed form
+    returns an all-zero row whenever a coefficient is non-finite (the reference's LU then yields NaN -> 0 everywhere as
+    well; only an overflow INSIDE a solve with finite coefficients would differ)."""
     lib = _lib.load()
     if refLR.dim() != 2:
         raise ValueError("not enough values to unpack (expected 2, got %d)" % refLR.dim())  # B, N = refLR.shape
+    if refLR.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("diffus_amd.prop_single_ray has no backward for the full solution vector; use "
+                                  "compute_echo_traces / propagate_full_rays_batched (differentiable) or detach refLR")
     dev = _device_for(refLR)
     dt = torch.float64 if refLR.dtype == torch.float64 else torch.float32
     r = _as(refLR, dev, dt)
     B, N = r.shape
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         w = torch.empty((B, 2 * (N + 1)), dtype=dt, device=dev)
         if B:
             rc = lib.diffus_prop_single_ray(_ptr(r) if N else None, _lib.DIFFUS_F64 if dt == torch.float64 else _lib.DIFFUS_F32,
@@ -443,18 +552,11 @@ def prop_single_ray(refLR: torch.Tensor, traLR: torch.Tensor = None, traRL: torc
 
 def propagate_full_rays_batched(refLR: torch.Tensor) -> torch.Tensor:
     """Mirror of reference src/renderer.py:412-436: refLR (B,N) -> (B,N+1), the surface return d0 of every truncation
-    depth, cumulated along the depth (diffus_propagate_rays: the O(N) echo series + a running sum)."""
-    lib = _lib.load()
+    depth, cumulated along the depth (diffus_propagate_rays: the O(N) echo series + a running sum).  Differentiable in
+    refLR like the reference's."""
     if refLR.dim() != 2:
         raise ValueError("not enough values to unpack (expected 2, got %d)" % refLR.dim())
-    dev = _device_for(refLR)
-    r = _as(refLR, dev, torch.float32)
-    B, N = r.shape
-    with torch.cuda.device(dev):
-        out = torch.empty((B, N + 1), dtype=torch.float32, device=dev)
-        if B:
-            _lib.check(lib.diffus_propagate_rays(_ptr(r) if N else None, B, N, _ptr(out), _stream(dev)), "diffus_propagate_rays")
-    return out.to(device=refLR.device, dtype=refLR.dtype if refLR.is_floating_point() else torch.float32)
+    return _EchoFn.apply(refLR, True)
 
 
 def custom_nearest_sampler(Z: torch.Tensor, points: torch.Tensor, visualize: bool = True, sampler: str = "prop",
@@ -476,7 +578,7 @@ def custom_nearest_sampler(Z: torch.Tensor, points: torch.Tensor, visualize: boo
     b, ns, _ = pts.shape
     n = b * ns
     d0, d1, d2 = vol.shape
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         val = torch.empty((b, ns), dtype=torch.float32, device=dev)
         idx = torch.empty((3, b, ns), dtype=torch.int64, device=dev)
         if n:
@@ -514,7 +616,7 @@ def compute_gaussian_pulse(refLR: torch.Tensor, spacing: float = 1.0, c: float =
     M = N + 2 * pad - L + 1
     if M <= 0:
         raise RuntimeError("Kernel size can't be greater than actual input size")     # what F.conv1d raises
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         out = torch.empty((B, M), dtype=torch.float32, device=dev)
         _lib.check(lib.diffus_rows_conv1d(_ptr(e), B, N, _ptr(taps), L, pad, _ptr(out), _stream(dev)), "diffus_rows_conv1d")
     return out.to(echo.device)
@@ -522,11 +624,8 @@ def compute_gaussian_pulse(refLR: torch.Tensor, spacing: float = 1.0, c: float =
 
 class UltrasoundRenderer:
     def __init__(self, num_samples: int, attenuation_coeff: float = 0.5):
-        """
-        num_samples: how many points to sample along each ray
-        attenuation_coeff: controls exponential decay of echoes with depth
-        (reference src/renderer.py:19-25)
-        """
+        """Constructor of reference src/renderer.py:19-25: `num_samples` steps are taken along every ray (one voxel
+        apart), and the echo of step k is damped by exp(-attenuation_coeff * k)."""
         self.num_samples = num_samples
         self.attenuation_coeff = attenuation_coeff
 
@@ -583,7 +682,11 @@ class UltrasoundRenderer:
             from .artifacts import apply_artifacts
             frame = apply_artifacts(frame, std_radial=std_radial, std_local=std_local, max_sigma=max_sigma,
                                     alpha=alpha, seed=seed)
+        if frame.device != dev:
+            frame = frame.to(dev)
         if return_indices:
-            idx = res[1][:, 0].to(dev)
-            return idx[0], idx[1], idx[2], frame.to(dev)
-        return None, None, None, frame.to(dev)
+            idx = res[1]
+            if idx.device != dev:
+                idx = idx.to(dev)
+            return idx[0, 0], idx[1, 0], idx[2, 0], frame
+        return None, None, None, frame

@@ -13,19 +13,46 @@ import logging
 import torch
 
 from . import _lib
-from .renderer import _device_for, _ptr, _stream, _workspace
+from .renderer import _Scope, _as, _device_for, _ptr, _stream, _workspace
 
 log = logging.getLogger("diffus_amd")
 
 
 def plot_axes(x, y, z):
     """The image plane = the two coordinate axes along which the samples spread most (largest variance first; equal
-    variances keep the axis order) -- the choice the reference makes at src/renderer.py:702-707.  One host sync for the
-    three variances instead of three."""
+    variances keep the axis order) -- the choice the reference makes at src/renderer.py:702-707 --, as Python ints.  This
+    is the HOST form (one sync for the three variances instead of the reference's three); differentiable_splat itself
+    decides on the device (select_axes) and never syncs."""
     import numpy as np
     spread = torch.stack([c.float().var() for c in (x, y, z)]).tolist()
     first, second = np.argsort(-np.asarray(spread), kind="stable")[:2]
     return int(first), int(second)
+
+
+_COORD_DT = {torch.float32: _lib.DIFFUS_F32, torch.float64: _lib.DIFFUS_F64, torch.int64: _lib.DIFFUS_I64}
+
+
+def select_axes(x, y, z, dev=None):
+    """Device-side axis choice of differentiable_splat (reference src/renderer.py:702-710; diffus_splat_axes): the three
+    coordinate planes (any mix of float32 / float64 / int64; other dtypes are cast to float32 first) ->
+    (coords (2, n) float32 = the two planes of largest variance, axes (2,) int32 device tensor).  No host sync."""
+    lib = _lib.load()
+    dev = dev if dev is not None else _device_for(x)
+    planes = []
+    for c in (x, y, z):
+        dt = c.dtype if c.dtype in _COORD_DT else torch.float32
+        planes.append(_as(c, dev, dt).reshape(-1))
+    n = planes[0].numel()
+    if any(p.numel() != n for p in planes):
+        raise ValueError("x, y, z must have the same number of elements")
+    with _Scope(dev):
+        sel = torch.empty((2, n), dtype=torch.float32, device=dev)
+        axes = torch.empty(2, dtype=torch.int32, device=dev)
+        rc = lib.diffus_splat_axes(_ptr(planes[0]), _COORD_DT[planes[0].dtype], _ptr(planes[1]), _COORD_DT[planes[1].dtype],
+                                   _ptr(planes[2]), _COORD_DT[planes[2].dtype], n, _ptr(axes), _ptr(sel[0]), _ptr(sel[1]),
+                                   _stream(dev))
+    _lib.check(rc, "diffus_splat_axes")
+    return sel, axes
 
 
 class _SplatFn(torch.autograd.Function):
@@ -34,10 +61,10 @@ class _SplatFn(torch.autograd.Function):
         lib = _lib.load()
         dev = _device_for(val)
         P, n = val.shape
-        with torch.cuda.device(dev):
-            a = c0.detach().to(device=dev, dtype=torch.float32).contiguous()
-            b = c1.detach().to(device=dev, dtype=torch.float32).contiguous()
-            v = val.detach().to(device=dev, dtype=torch.float32).contiguous()
+        with _Scope(dev):
+            a = _as(c0, dev, torch.float32)
+            b = _as(c1, dev, torch.float32)
+            v = _as(val, dev, torch.float32)
             out = torch.empty((P, W, H), dtype=torch.float32, device=dev)
             nws = lib.diffus_splat_workspace_bytes(P, H, W)
             ws = _workspace(dev, nws)
@@ -55,14 +82,16 @@ class _SplatFn(torch.autograd.Function):
         H, W, sigma, vdev, vdt = ctx.meta
         dev = a.device
         P, n = a.shape
-        with torch.cuda.device(dev):
-            g = gout.detach().to(device=dev, dtype=torch.float32).contiguous()
+        with _Scope(dev):
+            g = _as(gout, dev, torch.float32)
             gval = torch.empty((P, n), dtype=torch.float32, device=dev)
             ws = _workspace(dev, lib.diffus_splat_workspace_bytes(P, H, W))
             rc = lib.diffus_splat_bwd(_ptr(a), _ptr(b), P, n, H, W, sigma, _ptr(g), _ptr(gval), _ptr(ws), ws.numel(),
                                       _stream(dev))
         _lib.check(rc, "diffus_splat_bwd")
-        return None, None, gval.to(device=vdev, dtype=vdt), None, None, None, None
+        if gval.device != vdev or gval.dtype != vdt:
+            gval = gval.to(device=vdev, dtype=vdt)
+        return None, None, gval, None, None, None, None
 
 
 def splat_frames(coord0, coord1, intensities, H=256, W=256, sigma=2.0, cols=0):
@@ -72,29 +101,38 @@ def splat_frames(coord0, coord1, intensities, H=256, W=256, sigma=2.0, cols=0):
 
 
 def differentiable_splat(x, y, z, intensities, H=256, W=256, sigma=2.0):
-    """
-    Differentiable splatting onto the 2D plane of highest variance (reference src/renderer.py:694).
-    - x, y, z: tensors of same shape, coordinates in [0, size-1] for each axis
-    - intensities: tensor of same shape
-    - H, W: output image height and width (for axis0 and axis1)
-    Returns the (W, H) image (the reference returns output[0, 0].T).
-    """
-    coords = [x, y, z]
-    axis0, axis1 = plot_axes(x, y, z)
+    """Scan conversion of one frame (reference src/renderer.py:694-737): the samples are dropped onto the plane spanned
+    by the two coordinate axes they vary most along, each at its nearest pixel of a W x H raster (the last sample to
+    land on a pixel owns it), and the raster and its hit mask are smoothed with a Gaussian of `sigma` and divided.
+    x, y, z, intensities: tensors of one shape; returns the (W, H) float32 image on intensities.device -- what the
+    reference returns as `output[0, 0].T` --, differentiable in `intensities`."""
     dev = intensities.device
+    cdev = _device_for(intensities)
+    sel, _ = select_axes(x, y, z, cdev)              # on the device: no .item() round trips (reference :704)
     cols = intensities.shape[-1] if intensities.dim() == 2 else 0
-    out = splat_frames(coords[axis0].reshape(1, -1), coords[axis1].reshape(1, -1), intensities.reshape(1, -1), H, W, sigma, cols)
-    return out[0].to(dev)
+    out = splat_frames(sel[0:1], sel[1:2], intensities.reshape(1, -1), H, W, sigma, cols)[0]
+    return out if out.device == dev else out.to(dev)
 
 
 def rotate_around_apex(x, z, apex, median):
     """Turn the fan so that its median direction points along +z of the image and put its apex at `apex`: every point
-    (x - 128, z) is rotated by the angle between (0, 1) and `median`, then shifted.  Host-side geometry on the sample
-    coordinates in plain torch, with the values of reference src/renderer.py:655-692 (the 128 is the reference's too).
-    x, z: 1-D coordinate tensors; apex: (x0, z0); median: (dx, dz)."""
-    heading = torch.as_tensor(median, dtype=torch.float32, device=x.device)
-    heading = heading / heading.norm()
-    turn = torch.atan2(heading[0], heading[1])
-    c, s = torch.cos(turn), torch.sin(turn)
-    moved = torch.stack((torch.stack((c, -s)), torch.stack((s, c)))) @ torch.stack((x - 128, z))
-    return moved[0] + apex[0], moved[1] + apex[1]
+    (x - 128, z) is rotated by the angle between (0, 1) and `median`, then shifted -- reference src/renderer.py:655-692
+    (the 128 is the reference's too), one launch on x's device (diffus_rotate_around_apex).
+    x, z: 1-D coordinate tensors; apex: (x0, z0); median: (dx, dz) -- tuples / arrays like in the reference, or tensors
+    already on the device (then nothing is copied from the host and the call can sit inside a captured hipGraph).
+    Coordinates are constants of the fan geometry: like in the reference, no gradient flows through this."""
+    lib = _lib.load()
+    dev = _device_for(x)
+    xs, zs = _as(x, dev, torch.float32).reshape(-1), _as(z, dev, torch.float32).reshape(-1)
+    if xs.numel() != zs.numel():
+        raise ValueError("x and z must have the same number of elements")
+    ap = _as(torch.as_tensor(apex, dtype=torch.float32), dev, torch.float32)
+    md = _as(torch.as_tensor(median, dtype=torch.float32), dev, torch.float32)
+    n = xs.numel()
+    with _Scope(dev):
+        out = torch.empty((2, n), dtype=torch.float32, device=dev)
+        if n:
+            _lib.check(lib.diffus_rotate_around_apex(_ptr(xs), _ptr(zs), n, _ptr(ap), _ptr(md), 128.0, _ptr(out[0]), _ptr(out[1]),
+                                                     _stream(dev)), "diffus_rotate_around_apex")
+    xo, zo = out[0].reshape(x.shape), out[1].reshape(z.shape)
+    return (xo, zo) if x.device == dev else (xo.to(x.device), zo.to(x.device))

@@ -49,6 +49,7 @@ extern "C" {
  * (reference src/renderer.py:119-124, :751; oracle/diffus_oracle.c orc_point) */
 #define DIFFUS_F32 0
 #define DIFFUS_F64 1
+#define DIFFUS_I64 2 /* diffus_splat_axes only: the int64 index planes plot_beam_frame returns */
 
 /* sampler */
 #define DIFFUS_NEAREST   0 /* reference custom_nearest_sampler, src/renderer.py:741-759 */
@@ -114,10 +115,13 @@ size_t diffus_workspace_zbar_offset(int P, int R, int S, int start);
  * written by nothing but this call, always with the same `touched` array): bricks stored by the previous
  * call and not touched since are zeroed in `vol`, so `vol` always equals the dense gradient of the latest
  * step and is never memset.  (`touched` then holds 2 for the bricks `vol` currently has values in.)
+ * Mode DENSE writes EVERY voxel of `vol`: the touched bricks' values and zeros everywhere else -- a fresh dense
+ * gradient in one launch (the drop-in autograd path: no torch.zeros + flush, i.e. one launch and one dispatch fewer).
  */
 #define DIFFUS_FLUSH_STORE      0
 #define DIFFUS_FLUSH_ACCUMULATE 1
 #define DIFFUS_FLUSH_PERSISTENT 2
+#define DIFFUS_FLUSH_DENSE      3
 size_t diffus_brick_count(int d0, int d1, int d2);
 int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, float *vol,
                          int mode, diffus_stream_t stream);
@@ -260,6 +264,17 @@ int diffus_echo_traces(const float *refl, int B, int N, float *echo,
                        diffus_stream_t stream);
 
 /*
+ * Backward of stage 2: what torch autograd computes through the reference's compute_echo_traces (the N+1
+ * LinalgSolveBackward nodes behind src/renderer.py:407, the stack/cumsum/diff of :434-435,454): refl (B,N),
+ * gecho (B,N+1) = dL/d echo -> grefl (B,N) = dL/d refl, by the O(N) adjoint sweep, float64
+ * inside.  An echo that nan_to_num (:408) turned into the constant 0 passes no gradient.  `workspace`: device
+ * scratch of diffus_echo_bwd_workspace_bytes(B, N) bytes (the forward's running products).
+ */
+size_t diffus_echo_bwd_workspace_bytes(int B, int N);
+int diffus_echo_traces_bwd(const float *refl, int B, int N, const float *gecho, float *grefl,
+                           void *workspace, size_t workspace_bytes, diffus_stream_t stream);
+
+/*
  * The remaining module functions `from src.renderer import *` gives the notebooks:
  *   diffus_prop_single_ray  replaces prop_single_ray (reference src/renderer.py:367-410): refl (B,N), float32 or
  *                           float64 like the caller's tensor -> w (B, 2N+2) = [g0,d0,...,gN,dN], the full solution of
@@ -300,6 +315,44 @@ int diffus_rows_conv1d(const float *in, int B, int N, const float *kernel, int L
  * gradient of its pixel, exactly as torch autograd does through the reference.
  * sigma <= 8 (kernel half-width <= 24).
  */
+/*
+ * The loss of the reference's training notebook (notebooks/[DEMO] Train MRI to Impedance MLP - GPU.ipynb cell 16,
+ * `UltrasoundSynthesisModel.loss`), which attaches to differentiable_splat's image:
+ *     synth = (img - img.min()) / (img.max() - img.min() + 1e-8)        [normalise != 0]
+ *     loss  = 1 - ssim(synth, ref)
+ * with the SSIM of Wang et al. (IEEE TIP 2004) as piq.ssim(x, y, data_range=1.0) evaluates it: a win x win Gaussian
+ * window of `sigma` ('valid' correlation), constants (k1, k2), mean over the map -- piq's defaults are win 11, sigma
+ * 1.5, k1 0.01, k2 0.03.  img, ref: (H,W) float32; loss: device scalar.  diffus_ssim_loss_bwd: gloss (device scalar,
+ * nullable = 1) -> gimg (H,W) = dL/dimg, including what img.min() / img.max() hand back to the pixels that attain them
+ * (shared equally among ties, like torch).  reuse_stats != 0: `workspace` is the forward's, untouched since, and `img` is
+ * unchanged -- the minimum / maximum pass is skipped.  win odd, <= 15.
+ */
+size_t diffus_ssim_workspace_bytes(int H, int W, int win);
+int diffus_ssim_loss_fwd(const float *img, const float *ref, int H, int W, int normalise, int win, float sigma, float k1,
+                         float k2, float *loss, void *workspace, size_t workspace_bytes, diffus_stream_t stream);
+int diffus_ssim_loss_bwd(const float *img, const float *ref, int H, int W, int normalise, int win, float sigma, float k1,
+                         float k2, const float *gloss, float *gimg, int reuse_stats, void *workspace,
+                         size_t workspace_bytes, diffus_stream_t stream);
+
+/*
+ * rotate_around_apex (reference src/renderer.py:655-692): x, z (n float32 each) -> x_rot, z_rot: every point
+ * (x - shift, z) -- shift is the reference's hard-wired 128 -- turned by the angle between (0, 1) and `median`, then
+ * moved by `apex`.  apex, median: DEVICE pointers to two floats each, so that the call needs nothing from the host.
+ */
+int diffus_rotate_around_apex(const float *x, const float *z, long n, const float *apex, const float *median, float shift,
+                              float *x_rot, float *z_rot, diffus_stream_t stream);
+
+/*
+ * The axis choice of differentiable_splat (reference src/renderer.py:702-710), on the device: x, y, z are the three
+ * coordinate planes of the n samples (each float32, float64 or int64: *_dtype = DIFFUS_F32 / F64 / I64); axes[0..1]
+ * (device int32) get the two axes of largest variance, largest first, ties in axis order -- the variance of the values
+ * cast to float32, like the reference's `c.float().var()`, accumulated in float64 --, and c0 / c1 (nullable pair,
+ * n float32 each) those two planes cast to float32, ready for diffus_splat_fwd.  No host round trip (the reference
+ * syncs three times for `.item()`): the chain render -> splat -> loss is capturable.
+ */
+int diffus_splat_axes(const void *x, int x_dtype, const void *y, int y_dtype, const void *z, int z_dtype, long n, int *axes,
+                      float *c0, float *c1, diffus_stream_t stream);
+
 size_t diffus_splat_workspace_bytes(int P, int H, int W);
 int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, long n, int cols,
                      int H, int W, float sigma, float *out,

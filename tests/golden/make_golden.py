@@ -451,6 +451,26 @@ def main():
         save("g17_grazing_rays", picks=np.array(picks, dtype=np.int64), Z=Z, r=r32.numpy(), echo32=e32.numpy(),
              echo64=e64.numpy())
 
+    # ---- G18: the reference's OWN autograd through compute_echo_traces / propagate_full_rays_batched -------------
+    # (N+1 LinalgSolveBackward nodes each; fp64 so that the values are the algorithm's, not the LU's noise)
+    if want("g18"):
+        g = torch.Generator().manual_seed(18)
+        r = (torch.rand(5, 40, generator=g, dtype=torch.float64) - 0.5) * 1.2
+        r[1, 17] = 0.9995                      # a nearly singular interface
+        r[2, 25:] = 0.0                        # homogeneous tail
+        r[3, 11] = float("nan")                # nan_to_num(nan=0) zeroes every echo from here on (:408)
+        w_e = torch.linspace(0.3, 1.7, 41, dtype=torch.float64)[None, :] * torch.tensor([1.0, -0.5, 2.0, 1.0, 0.25], dtype=torch.float64)[:, None]
+        out = {"r": r.numpy(), "w": w_e.numpy()}
+        with torch.enable_grad():
+            for name, fn in (("echo", lambda x: ref.compute_echo_traces(x)[0]), ("prop", ref.propagate_full_rays_batched)):
+                x = r.clone().requires_grad_(True)
+                with quiet():
+                    y = fn(x)
+                (y * w_e).sum().backward()
+                out[name] = y.detach().numpy()
+                out["g_" + name] = x.grad.numpy()
+        save("g18_echo_autograd", **out)
+
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):
         v = torch.from_numpy(phantom(256))

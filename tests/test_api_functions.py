@@ -105,3 +105,45 @@ def test_trace_ray_and_simulate_rays_mirrors_vs_reference(g16):
     # one ray: R comes back 1-D (the reference's R.squeeze(0))
     _, _, _, r1 = rr.simulate_rays(vol, s, d[:1])
     assert r1.shape == (39,) and torch.equal(r1, r[0])
+
+
+@pytest.mark.gpu
+def test_echo_series_is_differentiable_like_the_reference():
+    """compute_echo_traces / propagate_full_rays_batched return tensors WITH a grad_fn (the reference's are
+    differentiable through torch.linalg.solve); gradients against the reference's own autograd (golden G18, fp64) and, for
+    the row that holds a NaN coefficient -- where the reference's whole gradient row is NaN -- against float64 autograd
+    over the valid prefix (non-finite contributions are dropped, like in the fused backward).  prop_single_ray, whose
+    full solution vector has no backward here, raises instead of silently returning a constant."""
+    import diffus_amd as da
+    from oracle import autograd_ref as ar
+    g = load_golden("g18_echo_autograd")
+    w = torch.from_numpy(g["w"]).cuda()
+    fin = [0, 1, 2, 4]
+    for name, fn in (("echo", lambda x: da.compute_echo_traces(x)[0]), ("prop", da.propagate_full_rays_batched)):
+        for dt, tol in ((torch.float64, 1e-5), (torch.float32, 2e-5)):        # the kernel reads float32 coefficients (row 1: r = 0.9995)
+            r = torch.from_numpy(g["r"]).to(dt).cuda().requires_grad_(True)
+            y = fn(r)
+            assert y.grad_fn is not None and y.dtype == dt
+            (y * w.to(dt)).sum().backward()
+            got = r.grad.cpu().numpy()
+            assert np.all(np.isfinite(got))
+            for i in fin:
+                assert maxnorm_rel(got[i], g["g_" + name][i]) < tol, (name, dt, i)
+                assert maxnorm_rel(y[i].detach().cpu().numpy(), g[name][i]) < 1e-5
+            # the NaN row: the echoes before the NaN still carry gradient to the coefficients before it; nothing else does
+            k = 11
+            rp = torch.from_numpy(g["r"][3:4, :k]).requires_grad_(True)
+            e = ar.echo_scan(rp)
+            if name == "prop":
+                # cum_m for m > k repeats cum_k (later echoes are 0): every later weight lands on the prefix sums too
+                wk = torch.from_numpy(g["w"][3:4]).clone()
+                e = torch.cumsum(e, 1)
+                tail = wk[:, k + 1:].sum()
+                ((e * wk[:, :k + 1]).sum() + tail * e[:, k]).backward()
+            else:
+                (e * torch.from_numpy(g["w"][3:4, :k + 1])).sum().backward()
+            assert maxnorm_rel(got[3, :k], rp.grad.numpy()[0]) < tol, (name, dt)
+            assert np.all(got[3, k:] == 0)
+    with pytest.raises(NotImplementedError):
+        da.prop_single_ray(torch.from_numpy(g["r"]).cuda().requires_grad_(True))
+    assert da.prop_single_ray(torch.from_numpy(g["r"]).cuda()).shape == (5, 82)      # detached input: as before

@@ -13,12 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def hot():
-    """The captured-step API of the package (it was bench.py's HotPath in round 1)."""
-    import types
-
+def Step():
+    """The captured-step API of the package."""
     from diffus_amd import CapturedStep
-    return types.SimpleNamespace(HotPath=CapturedStep)
+    return CapturedStep
 
 
 def vp(t):
@@ -26,7 +24,7 @@ def vp(t):
 
 
 @pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
-def test_persistent_flush_equals_fresh_dense_gradient_every_step(hot, sampler):
+def test_persistent_flush_equals_fresh_dense_gradient_every_step(Step, sampler):
     n, R, S = 64, 24, 90
     vol = torch.from_numpy(phantom(n)).cuda()
     src, dirs = pose_ring(n, 12, R)
@@ -36,9 +34,9 @@ def test_persistent_flush_equals_fresh_dense_gradient_every_step(hot, sampler):
     for step, g in enumerate(groups * 2):
         s = torch.from_numpy(src[g]).cuda().contiguous()
         d = torch.from_numpy(dirs[g]).cuda().contiguous()
-        hp_ref = hot.HotPath(vol, s, d, S, 2e-3, sampler, persistent=False)
+        hp_ref = Step(vol, s, d, S, 2e-3, sampler, persistent=False)
         hp_ref.step()
-        hp = hot.HotPath(vol, s, d, S, 2e-3, sampler, persistent=True)
+        hp = Step(vol, s, d, S, 2e-3, sampler, persistent=True)
         if per is not None:                    # carry the persistent tensor, scratch and flags across steps
             hp.gvol, hp.gvol_k, hp.touched = per
         assert hp.persistent
@@ -111,7 +109,7 @@ def test_loss_sumsq_single_launch(P, n):
     assert lib.diffus_loss_sumsq(vp(frame), P, n, vp(loss), None, vp(ws), 256 * P, None) == -4
 
 
-def test_step_is_hipgraph_capturable_and_replays_on_new_inputs(hot):
+def test_step_is_hipgraph_capturable_and_replays_on_new_inputs(Step):
     """The C-ABI never allocates or synchronises: a whole step (forward, loss, backward, persistent flush) is captured
     once and replayed after the poses and the volume were changed IN PLACE; results equal the eager step's."""
     n, P, R, S = 64, 3, 24, 1100                      # S > 1024: the segmented launches are captured too
@@ -119,7 +117,7 @@ def test_step_is_hipgraph_capturable_and_replays_on_new_inputs(hot):
     src, dirs = pose_ring(n, 8, R)
     s = torch.from_numpy(src[:P]).cuda().contiguous()
     d = (torch.from_numpy(dirs[:P]) * 0.05).cuda().contiguous()
-    hp = hot.HotPath(vol, s, d, S, 1e-3, "trilinear", layout="bricked")
+    hp = Step(vol, s, d, S, 1e-3, "trilinear", layout="bricked")
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         for _ in range(2):
@@ -136,7 +134,7 @@ def test_step_is_hipgraph_capturable_and_replays_on_new_inputs(hot):
     g.replay()
     torch.cuda.synchronize()
     got = (hp.frame.clone(), hp.loss.clone(), hp.gvol.clone(), hp.gsrc.clone(), hp.gdirs.clone())
-    ref = hot.HotPath(vol, s, d, S, 1e-3, "trilinear", layout="bricked", persistent=False)
+    ref = Step(vol, s, d, S, 1e-3, "trilinear", layout="bricked", persistent=False)
     ref.step()
     torch.cuda.synchronize()
     assert torch.equal(got[0], ref.frame) and torch.equal(got[1], ref.loss)
@@ -147,7 +145,7 @@ def test_step_is_hipgraph_capturable_and_replays_on_new_inputs(hot):
 
 
 @pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
-def test_start_crop_backward_reuses_the_forwards_median(hot, sampler):
+def test_start_crop_backward_reuses_the_forwards_median(Step, sampler):
     """start > 0: the captured step's backward keeps the median of its own forward (DIFFUS_BWD_KEEP_MEDIAN) and routes the
     median's gradient in extra blocks of the scatter launch; same result as the self-contained backward of the autograd
     path (median recomputed, routing and d/dsource reduction as a launch of their own when there is no scatter)."""
@@ -157,7 +155,7 @@ def test_start_crop_backward_reuses_the_forwards_median(hot, sampler):
     src, dirs = pose_ring(n, P, R)
     s = torch.from_numpy(src).cuda()
     d = torch.from_numpy(dirs).cuda()
-    hp = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False)
+    hp = Step(vol, s, d, S, alpha, sampler, start=start, persistent=False)
     hp.step()
     hp.step()                                           # a second pass: gmed was reset by the first one
     v = vol.clone().requires_grad_(True)
@@ -174,16 +172,67 @@ def test_start_crop_backward_reuses_the_forwards_median(hot, sampler):
         assert float((hp.gdirs - dd.grad).abs().max()) <= 1e-5 * float(dd.grad.abs().max())
     # pose-gradient-only backward (no scatter launch to carry the per-pose epilogue)
     if sampler == "trilinear":
-        hq = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, want_gvol=False)
+        hq = Step(vol, s, d, S, alpha, sampler, start=start, want_gvol=False)
         hq.step()
         torch.cuda.synchronize()
         assert float((hq.gsrc - sa.grad).abs().max()) <= 1e-5 * float(sa.grad.abs().max())
         assert float((hq.gdirs - dd.grad).abs().max()) <= 1e-5 * float(dd.grad.abs().max())
 
 
+def test_stale_median_is_not_reused_after_the_inputs_changed(Step):
+    """forward(), then set_poses() / an in-place volume edit / refresh_volume(), then backward() must NOT route
+    the gradient of the start-crop median through the median of the OLD inputs (DIFFUS_BWD_KEEP_MEDIAN): the backward
+    recomputes it.  Checked against a fresh step on the new inputs; and a frame rendered before the change can no longer
+    be back-propagated through render()."""
+    n, P, R, S, start, alpha = 64, 4, 40, 150, 37, 2e-3
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, 8, R)
+    s0, d0 = torch.from_numpy(src[:P]).cuda(), torch.from_numpy(dirs[:P]).cuda()
+    s1, d1 = torch.from_numpy(src[4:4 + P]).cuda(), torch.from_numpy(dirs[4:4 + P]).cuda()
+    w = torch.linspace(0.5, 2.0, S - start, device="cuda")
+
+    G = (torch.randn(P, R, S - start, generator=torch.Generator().manual_seed(3)) * w.cpu()).cuda()
+
+    def reference(v, s, d):
+        r = Step(v, s.clone(), d.clone(), S, alpha, "trilinear", start=start, persistent=False, fused_loss=False)
+        r.forward()
+        r.gframe.copy_(G)
+        r.backward()
+        torch.cuda.synchronize()
+        return r
+
+    for change in ("poses", "volume", "refresh"):
+        v = vol.clone()
+        hp = Step(v, s0.clone(), d0.clone(), S, alpha, "trilinear", start=start, persistent=False, fused_loss=False,
+                  layout="canonical" if change == "volume" else "paired")
+        hp.forward()
+        assert hp._median_valid()
+        if change == "poses":
+            hp.set_poses(s1, d1)
+        elif change == "volume":
+            v[:, :, : n // 2].mul_(1.5)                      # canonical layout: the kernels read the caller's tensor
+        else:
+            v[:, :, : n // 2].mul_(1.5)
+            hp.refresh_volume()
+        assert not hp._median_valid()
+        hp.gframe.copy_(G)
+        hp.backward()                                        # no forward in between: the workspace median is the OLD inputs'
+        torch.cuda.synchronize()
+        ref = reference(v, s1 if change == "poses" else s0, d1 if change == "poses" else d0)
+        assert float((hp.gsrc - ref.gsrc).abs().max()) <= 1e-5 * float(ref.gsrc.abs().max()), change
+        assert float((hp.gdirs - ref.gdirs).abs().max()) <= 1e-5 * float(ref.gdirs.abs().max()), change
+        assert float((hp.gvol - ref.gvol).abs().max()) <= 2e-5 * float(ref.gvol.abs().max()), change
+    # the autograd node: a frame of the old poses cannot be back-propagated after set_poses
+    hp = Step(vol, s0.clone().requires_grad_(True), d0.clone(), S, alpha, "trilinear", start=start)
+    f = hp.render()
+    hp.set_poses(s1, d1)
+    with pytest.raises(RuntimeError):
+        (f ** 2).sum().backward()
+
+
 @pytest.mark.parametrize("S,start,sampler", [(512, 0, "trilinear"), (700, 30, "trilinear"), (1100, 0, "trilinear"),
                                              (150, 37, "nearest"), (96, 0, "trilinear")])
-def test_fused_mse_backward_equals_loss_kernel_plus_backward(hot, S, start, sampler):
+def test_fused_mse_backward_equals_loss_kernel_plus_backward(Step, S, start, sampler):
     """diffus_render_bwd_mse: loss = scale * sum((frame - target)^2) per pose and its backward, formed from the frame on
     the fly (single launch pair, per-pose loss summed by the call's closing blocks) -- against the unfused sequence
     (torch loss on the frame, diffus_render_bwd with the explicit dL/dframe).  Covers one wave per ray, two waves per ray
@@ -196,11 +245,11 @@ def test_fused_mse_backward_equals_loss_kernel_plus_backward(hot, S, start, samp
     g = torch.Generator().manual_seed(S)
     target = (torch.randn(P, R, S - start, generator=g) * 0.05).cuda()
     for tgt, scale in ((None, 1.0), (target, 0.37)):
-        fused = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale,
+        fused = Step(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale,
                             one_pass=False)
         fused.step()
         # ... and the ONE-PASS step (diffus_render_step_mse: the frame too comes out of the adjoint-scan kernel)
-        one = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale)
+        one = Step(vol, s, d, S, alpha, sampler, start=start, persistent=False, target=tgt, loss_scale=scale)
         one.frame.fill_(float("nan"))
         one.step()
         torch.cuda.synchronize()
@@ -211,7 +260,7 @@ def test_fused_mse_backward_equals_loss_kernel_plus_backward(hot, S, start, samp
         assert float((one.gvol - fused.gvol).abs().max()) <= 1e-4 * float(fused.gvol.abs().max())
         assert torch.allclose(one.gsrc, fused.gsrc, rtol=1e-4, atol=1e-4 * float(fused.gsrc.abs().max()))
         assert torch.allclose(one.gdirs, fused.gdirs, rtol=1e-4, atol=1e-4 * float(fused.gdirs.abs().max()))
-        ref = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, persistent=False, fused_loss=False)
+        ref = Step(vol, s, d, S, alpha, sampler, start=start, persistent=False, fused_loss=False)
         ref.fwd()
         diff = ref.frame if tgt is None else ref.frame - tgt
         ref.gframe.copy_(2 * scale * diff)
@@ -227,14 +276,14 @@ def test_fused_mse_backward_equals_loss_kernel_plus_backward(hot, S, start, samp
             assert float((fused.gdirs - ref.gdirs).abs().max()) <= 1e-5 * float(ref.gdirs.abs().max())
     # pose-gradient-only and loss-only calls
     if sampler == "trilinear":
-        only = hot.HotPath(vol, s, d, S, alpha, sampler, start=start, want_gvol=False)
+        only = Step(vol, s, d, S, alpha, sampler, start=start, want_gvol=False)
         only.step()
         torch.cuda.synchronize()
         assert torch.allclose(only.loss.double(), (only.frame.double() ** 2).sum((1, 2)), rtol=2e-6)
 
 
 @pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
-def test_canonical_volume_with_the_bricked_sparse_gradient(hot, sampler):
+def test_canonical_volume_with_the_bricked_sparse_gradient(Step, sampler):
     """DIFFUS_GRAD_BRICKED: the kernels read the caller's canonical tensor in place, the gradient goes through the bricked
     scratch and the touched-brick hand-back (no memset of the dense tensor) -- same values as the scatter straight into
     the canonical tensor, step after step with fans that move and a volume slice that changes in place."""
@@ -243,8 +292,8 @@ def test_canonical_volume_with_the_bricked_sparse_gradient(hot, sampler):
     src, dirs = pose_ring(n, 12, R)
     s = torch.from_numpy(src[:P]).cuda().contiguous()
     d = torch.from_numpy(dirs[:P]).cuda().contiguous()
-    a = hot.HotPath(vol, s, d, S, 2e-3, sampler, start=start, layout="canonical")
-    b = hot.HotPath(vol, s, d, S, 2e-3, sampler, start=start, layout="canonical", bricked_grad=False)
+    a = Step(vol, s, d, S, 2e-3, sampler, start=start, layout="canonical")
+    b = Step(vol, s, d, S, 2e-3, sampler, start=start, layout="canonical", bricked_grad=False)
     assert a.grad_bricked and a.persistent and a.touched is not None
     assert not b.grad_bricked and b.touched is None and b.gvol_k is b.gvol
     for it in range(4):

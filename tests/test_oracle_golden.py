@@ -93,6 +93,26 @@ def test_g17_grazing_rays_of_the_benchmark_workload(oracle):
         assert maxnorm_rel(g["echo32"][i], f64[0]) < tol            # the reference's own fp32 passes the rule
 
 
+def test_g18_reference_autograd_through_the_echo_series():
+    """The gradient oracle (oracle/autograd_ref.echo_scan, float64 autograd) against the reference's OWN autograd through
+    compute_echo_traces and propagate_full_rays_batched (N+1 LinalgSolveBackward nodes, src/renderer.py:407-454)."""
+    from oracle import autograd_ref as ar
+    g = load_golden("g18_echo_autograd")
+    w = torch.from_numpy(g["w"])
+    r = torch.from_numpy(g["r"]).requires_grad_(True)
+    e = ar.echo_scan(r)
+    (e * w).sum().backward()
+    np.testing.assert_allclose(e.detach().numpy(), g["echo"], atol=1e-12)
+    fin = [0, 1, 2, 4]                                     # row 3 holds a NaN coefficient: the reference's whole row is NaN
+    np.testing.assert_allclose(r.grad.numpy()[fin], g["g_echo"][fin], rtol=1e-7, atol=1e-10)
+    assert np.all(np.isnan(g["g_echo"][3])) and np.all(g["echo"][3, 12:] == 0)
+    r2 = torch.from_numpy(g["r"]).requires_grad_(True)
+    c = torch.cumsum(ar.echo_scan(r2), 1)
+    (c * w).sum().backward()
+    np.testing.assert_allclose(c.detach().numpy(), g["prop"], atol=1e-11)
+    np.testing.assert_allclose(r2.grad.numpy()[fin], g["g_prop"][fin], rtol=1e-7, atol=1e-9)
+
+
 def test_scan_equals_dense_small(oracle):
     # O(N) running product == N+1 dense solves (own C LU, fp64), incl. |r| close to 1
     rng = np.random.default_rng(7)

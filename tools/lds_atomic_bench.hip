@@ -1,4 +1,4 @@
-// Microbenchmark: LDS atomic throughput on gfx950 (ds_add_f32 vs ds_add_u32 vs plain RMW),
+// Microbenchmark: LDS atomic throughput on gfx950 (ds_add_f32 / ds_add_u32 / ds_add_u64 / ds_add_f64 vs plain RMW),
 // for three address patterns.  Diagnostic tool for the scatter design.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,6 +23,9 @@ __global__ __launch_bounds__(256) void k(const int *__restrict__ addr, float *ou
             if (MODE == 0) atomicAdd(&tf[e], 1.0f);
             if (MODE == 1) atomicAdd(&ti[e], 3);
             if (MODE == 2) tf[e] += 1.0f; // racy plain RMW: rate reference only
+            if (MODE == 3) atomicAdd(reinterpret_cast<unsigned long long *>(tf) + (e >> 1), 3ull);   // ds_add_u64
+            if (MODE == 4) atomicAdd(reinterpret_cast<double *>(tf) + (e >> 1), 1.0);                // ds_add_f64
+            if (MODE == 5) atomicMax(&ti[e], it);                                                     // ds_max_i32
         }
     }
     __syncthreads();
@@ -66,6 +69,13 @@ int main()
     run(k<1, 0>, "ds_add_u32 conflict-free");
     run(k<1, 1>, "ds_add_u32 random");
     run(k<1, 2>, "ds_add_u32 4-lanes-same");
+    run(k<3, 0>, "ds_add_u64 conflict-free");
+    run(k<3, 1>, "ds_add_u64 random");
+    run(k<3, 2>, "ds_add_u64 4-lanes-same");
+    run(k<4, 0>, "ds_add_f64 conflict-free");
+    run(k<4, 1>, "ds_add_f64 random");
+    run(k<4, 2>, "ds_add_f64 4-lanes-same");
+    run(k<5, 1>, "ds_max_i32 random");
     run(k<2, 0>, "plain rmw conflict-free");
     run(k<2, 1>, "plain rmw random");
     return 0;
