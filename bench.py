@@ -378,6 +378,34 @@ def callers_legs(args, vol, dev):
         "ms_per_frame_wall": ms_full, "ms_plot_beam_frame_only_wall": ms_render,
         "ray_steps_per_s": R * S / (ms_full * 1e-3),
         "reference_published": "2.54 s/frame on the authors' laptop CPU at 200 rays x 150 samples (BASELINE.md)"}
+    # (a') the drop-in TRAINING step: render_poses -> loss -> .backward() through torch autograd (what a notebook that only
+    #      swaps the import runs, e.g. `[NW] alignement` cells 13-14), wall time per step, 32 poses and 1 pose; and the same
+    #      with the autograd engine kept on the calling thread (torch.autograd.set_multithreading_enabled(False): the
+    #      hand-off to the engine's device thread is ~50 us of a step that has ~100 us of kernels)
+    def autograd_step_ms(P, single_thread):
+        s_all, d_all = pose_ring(n, 32, args.rays)
+        v = vol.detach().clone().requires_grad_(True)
+        sp = torch.from_numpy(s_all[:P]).to(dev).requires_grad_(True)
+        dp = torch.from_numpy(d_all[:P]).to(dev).requires_grad_(True)
+
+        def step():
+            f = diffus_amd.render_poses(v, sp, dp, args.samples, args.alpha, sampler="trilinear")
+            (f * f).sum().backward()
+            v.grad = None; sp.grad = None; dp.grad = None
+
+        if single_thread:
+            with torch.autograd.set_multithreading_enabled(False):
+                return time_wall(step, 50, warm=10)
+        return time_wall(step, 50, warm=10)
+
+    out["autograd_step"] = {
+        "call": "render_poses(volume, sources, directions, 512, 1e-4, sampler='trilinear') -> (f*f).sum().backward(), all three "
+                "inputs require grad, 256^3 volume, 256 rays x 512 steps; wall ms per step (host-bound)",
+        "poses32_ms": autograd_step_ms(32, False), "poses1_ms": autograd_step_ms(1, False),
+        "poses32_single_threaded_engine_ms": autograd_step_ms(32, True),
+        "poses1_single_threaded_engine_ms": autograd_step_ms(1, True),
+        "round2_ms": {"poses32": 0.307, "poses1": 0.241},
+    }
     # the same shape as a batch of 32 captured training steps (forward + loss + backward with the start-crop median)
     src32, dirs32 = pose_ring(n, 32, R)
     s32 = torch.from_numpy(src32).to(dev)

@@ -33,8 +33,8 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
 #ifndef DIFFUS_BWD_MIN_WAVES
 #define DIFFUS_BWD_MIN_WAVES 1
 #endif
-#ifndef DIFFUS_SPLIT_MIN_WAVES // SPLIT kernels: 4 waves per SIMD = 128 VGPRs (13 dwords of scratch) against 3 at 133
-#define DIFFUS_SPLIT_MIN_WAVES 4
+#ifndef DIFFUS_SPLIT_MIN_WAVES // SPLIT kernels: 3 waves per SIMD, 139 VGPRs, no scratch.  (Forced to 4 waves = 128 VGPRs the
+#define DIFFUS_SPLIT_MIN_WAVES 3 // compiler spills 15 dwords: one-pass scan 42.5 against 43.5 us at the config-5 shape, whole step 98.5 against 96 -- a wash; the spill-free build is kept)
 #endif
 // SEG = true: one 1024-sample segment of a longer ray (see diffus_render_bwd); only instantiated for C = 16.
 // SPLIT = 2: the two waves of a 128-thread block take the two halves of ONE ray (64*C samples each) and exchange

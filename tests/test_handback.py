@@ -83,6 +83,38 @@ def test_flush_modes_direct():
     assert torch.all(touched == 0)
 
 
+@pytest.mark.parametrize("d", [(9, 10, 7), (8, 8, 8), (5, 3, 1), (64, 64, 64), (33, 70, 130)])
+def test_flush_mode_dense_writes_every_voxel(d):
+    """DIFFUS_FLUSH_DENSE (the drop-in autograd path's hand-back): the canonical tensor -- uninitialised before -- comes
+    back with the touched bricks' values and ZEROS everywhere else, the scratch and the flags are all-zero afterwards;
+    odd shapes (edge bricks, an odd dim 2) included."""
+    from diffus_amd import _lib
+    lib = _lib.load()
+    nb = lib.diffus_brick_count(*d)
+    nf = lib.diffus_bricked_floats(*d)
+    g = torch.Generator().manual_seed(sum(d))
+    dense = torch.randn(d, generator=g).cuda()
+    bricked = torch.zeros(nf, device="cuda")
+    assert lib.diffus_brick_volume(vp(dense), *d, vp(bricked), None) == 0
+    pick = (torch.rand(nb, generator=g) < 0.3).cuda()
+    stale = (~pick) & (torch.rand(nb, generator=g) < 0.2).cuda()          # flag 2: left by a PERSISTENT flush, scratch zero there
+    touched = pick.to(torch.int32) + 2 * stale.to(torch.int32)
+    keep = bricked.view(nb, 32) * pick[:, None]
+    bricked.copy_(keep.reshape(-1))                                       # only the picked bricks hold values
+    out = torch.full(d, float("nan"), device="cuda")
+    assert lib.diffus_gradbuf_flush(vp(bricked), vp(touched), *d, vp(out), _lib.FLUSH_DENSE, None) == 0
+    torch.cuda.synchronize()
+    # expected: the dense tensor where its brick was picked, zero elsewhere
+    want = torch.zeros(nf, device="cuda")
+    assert lib.diffus_brick_volume(vp(dense), *d, vp(want), None) == 0
+    want = (want.view(nb, 32) * pick[:, None]).reshape(-1).contiguous()
+    back = torch.empty(d, device="cuda")
+    assert lib.diffus_unbrick_volume(vp(want), *d, vp(back), 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.equal(out, back)
+    assert torch.all(bricked == 0) and torch.all(touched == 0)
+
+
 @pytest.mark.parametrize("P,n", [(1, 4), (3, 1000), (32, 256 * 512), (5, 131073)])
 def test_loss_sumsq_single_launch(P, n):
     from diffus_amd import _lib

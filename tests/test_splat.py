@@ -86,3 +86,28 @@ def test_hip_splat_batched_and_full_size():
         assert torch.equal(one, imgs[p])
         o, _ = osp.splat(idx[0, p].cpu().numpy(), idx[1, p].cpu().numpy(), idx[2, p].cpu().numpy(), frames[p].cpu().numpy(), 256, 256, 2.0)
         assert maxnorm_rel(one.cpu().numpy(), o) < 2e-6
+
+
+@pytest.mark.gpu
+def test_device_side_axis_choice_matches_the_host_rule():
+    """diffus_splat_axes = reference src/renderer.py:702-707 without the `.item()` syncs: the two axes of largest variance,
+    largest first, ties in axis order; planes of mixed dtype (int64 index planes, float32 / float64 rotated ones)."""
+    from diffus_amd.splat import plot_axes, select_axes
+    g = torch.Generator().manual_seed(11)
+    n = 5000
+    base = [torch.randn(n, generator=g) * s for s in (3.0, 40.0, 11.0)]
+    cases = [
+        (base[0], base[1], base[2]),                                             # float32: axes (1, 2)
+        (base[1].double(), base[2], (base[0] * 10).long()),                      # mixed dtypes
+        ((base[1] * 2).long(), (base[1] * 2).long(), base[0]),                   # a tie: the first of the equal axes leads
+        (torch.full((n,), 7.0), base[0], base[2].double() + 1e6),                # a constant plane; a plane far from 0
+    ]
+    for x, y, z in cases:
+        want = plot_axes(x.cuda(), y.cuda(), z.cuda())
+        sel, axes = select_axes(x.cuda(), y.cuda(), z.cuda())
+        assert tuple(int(a) for a in axes.cpu()) == want, (want, axes)
+        planes = [x, y, z]
+        for k in range(2):
+            assert torch.equal(sel[k].cpu(), planes[want[k]].float())
+    with pytest.raises(ValueError):
+        select_axes(base[0].cuda(), base[1][:10].cuda(), base[2].cuda())

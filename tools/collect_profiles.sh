@@ -4,11 +4,11 @@
 # copied to profiles/ by tools/summarise_pmc.py afterwards (in the build container).
 # Usage: tools/collect_profiles.sh TAG [bench args that define the workload...]
 set -u
-TAG=${1:-r02_c3}; shift || true
+TAG=${1:-r03_c3}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-COMMON="--no-cpu-baseline --no-callers --eager $*"
+COMMON="--no-cpu-baseline --no-callers --no-scaling-legs --no-verify --eager $*"
 python3 -c "import sys,json; sys.argv=['bench.py']+'$*'.split(); import bench; print(json.dumps(bench.workload_key(bench.parse_args())))" > $OUT/workload.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 30 --warmup 5 $COMMON > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"

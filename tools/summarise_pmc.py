@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_c3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_c3"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 HBM_PEAK_GBS = 8000.0
@@ -136,6 +136,10 @@ for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "gra
         e["limiter"] = f"{kind} ({', '.join(parts)})"
     e["counters"] = {a: b for a, b in sorted(c.items())}
     summary["kernels"][k] = e
+summary["step_valu_wave_insts"] = {k: e["counters"].get("SQ_INSTS_VALU") for k, e in summary["kernels"].items()
+                                   if k in ("render_bwd_kernel", "scatter_patch_kernel", "gradbuf_flush_kernel", "render_fwd_kernel")}
+summary["step_valu_wave_insts"]["one_pass_step_total"] = sum(v for k, v in summary["step_valu_wave_insts"].items()
+                                                            if v and k in ("render_bwd_kernel", "scatter_patch_kernel", "gradbuf_flush_kernel"))
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 print(open(f"profiles/{tag}_kernel_times.txt").read())
 for k, e in summary["kernels"].items():
