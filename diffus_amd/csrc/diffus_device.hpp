@@ -208,13 +208,16 @@ __device__ __forceinline__ Mat mat_lane_next0(const Mat &m) { return mat_dpp_get
 // the rows of 16 (row_shr), then the last lane of a row / of the lower half broadcast to the rows above it.
 // f(has_source, round) is called once per round with every lane active; `fetch` inside it does the DPP moves.
 // Round r of this schedule combines exactly the lanes a shuffle scan with offset 2^r would.
+// The fourth argument says whether the round rescales its product: every SECOND round is enough -- two products of
+// matrices normalised to a largest entry below 1 stay below 8 -- and a rescale is 8 instructions (3 max, frexp, 4 ldexp)
+// plus the exponent bookkeeping.  Power-of-two scalings are exact, so the results do not change by a bit.
 #define DIFFUS_SCAN_UP_ROUNDS(LANE, ROUND)                                   \
-    ROUND(kDppRowShr + 1, 0xf, ((LANE) & 15) >= 1)                           \
-    ROUND(kDppRowShr + 2, 0xf, ((LANE) & 15) >= 2)                           \
-    ROUND(kDppRowShr + 4, 0xf, ((LANE) & 15) >= 4)                           \
-    ROUND(kDppRowShr + 8, 0xf, ((LANE) & 15) >= 8)                           \
-    ROUND(kDppBcast15, 0xa, ((LANE) & 16) != 0)                              \
-    ROUND(kDppBcast31, 0xc, (LANE) >= 32)
+    ROUND(kDppRowShr + 1, 0xf, ((LANE) & 15) >= 1, false)                    \
+    ROUND(kDppRowShr + 2, 0xf, ((LANE) & 15) >= 2, true)                     \
+    ROUND(kDppRowShr + 4, 0xf, ((LANE) & 15) >= 4, false)                    \
+    ROUND(kDppRowShr + 8, 0xf, ((LANE) & 15) >= 8, true)                     \
+    ROUND(kDppBcast15, 0xa, ((LANE) & 16) != 0, false)                       \
+    ROUND(kDppBcast31, 0xc, (LANE) >= 32, true)
 
 // Sum over the wave on the DPP path; the total is valid in lane 63 only.
 __device__ __forceinline__ float wave_sum_to_lane63(float v)
@@ -961,12 +964,12 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
         if (!FAST || (j & 3) == 3 || j == C - 1) mat_renorm(L);
     }
     {
-#define DIFFUS_ROUND(CTRL, RMASK, HAS)             \
+#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)         \
     {                                              \
         const Mat o = mat_dpp_get<CTRL, RMASK>(L); \
         if (HAS) {                                 \
             L = mat_mul(o, L);                     \
-            mat_renorm(L);                         \
+            if (RN) mat_renorm(L);                 \
         }                                          \
     }
         DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)

@@ -158,13 +158,13 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     int iota = lam;       // inclusive prefix exponent
     {
         // six scan rounds on the DPP path (diffus_device.hpp): matrix and exponent move together
-#define DIFFUS_ROUND(CTRL, RMASK, HAS)                   \
+#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)               \
     {                                                    \
         const Mat o = mat_dpp_get<CTRL, RMASK>(L);       \
         const int oe = dpp_get<CTRL, RMASK>(iota);       \
         if (HAS) {                                       \
             L = mat_mul(o, L);                           \
-            iota = oe + iota - mat_renorm(L);            \
+            iota = oe + iota - (RN ? mat_renorm(L) : 0); \
         }                                                \
     }
         DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
@@ -267,23 +267,24 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     // first lane of the row above (lanes 16 / 48, then lane 32) broadcast downwards.  DPP has no broadcast in that
     // direction, so those two rounds read the lane through an SGPR (v_readlane_b32).
     {
-        auto combine = [&](const Mat &oA, const Mat &oB, int ob) {
+        // (the linear part is rescaled every second round only, like the forward scan: exact either way)
+        auto combine = [&](const Mat &oA, const Mat &oB, int ob, bool rn) {
             Mat t = mat_scale(mat_mul_bt(oA, Bn), beta);
             Aacc.a += t.a; Aacc.b += t.b; Aacc.c += t.c; Aacc.d += t.d;
             Bn = mat_mul(Bn, oB);
-            beta = beta + ob + mat_renorm(Bn); // B = Bn * 2^beta: a rescale of Bn by 2^-ex adds ex
+            beta = beta + ob + (rn ? mat_renorm(Bn) : 0); // B = Bn * 2^beta: a rescale of Bn by 2^-ex adds ex
         };
-#define DIFFUS_ROUND_DOWN(N)                                        \
+#define DIFFUS_ROUND_DOWN(N, RN)                                    \
     {                                                               \
         const Mat oA = mat_dpp_get<kDppRowShl + N>(Aacc);           \
         const Mat oB = mat_dpp_get<kDppRowShl + N>(Bn);             \
         const int ob = dpp_get<kDppRowShl + N>(beta);               \
-        if ((lane & 15) + N < 16) combine(oA, oB, ob);              \
+        if ((lane & 15) + N < 16) combine(oA, oB, ob, RN);          \
     }
-        DIFFUS_ROUND_DOWN(1)
-        DIFFUS_ROUND_DOWN(2)
-        DIFFUS_ROUND_DOWN(4)
-        DIFFUS_ROUND_DOWN(8)
+        DIFFUS_ROUND_DOWN(1, false)
+        DIFFUS_ROUND_DOWN(2, true)
+        DIFFUS_ROUND_DOWN(4, false)
+        DIFFUS_ROUND_DOWN(8, true)
 #undef DIFFUS_ROUND_DOWN
         {   // rows 0 and 2 take the row above them (its suffix sits in its first lane)
             const Mat a16 = mat_lane_bcast(Aacc, 16), b16 = mat_lane_bcast(Bn, 16);
@@ -292,12 +293,12 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
             const bool up = lane >= 32;
             if (!(lane & 16))
                 combine(Mat{up ? a48.a : a16.a, up ? a48.b : a16.b, up ? a48.c : a16.c, up ? a48.d : a16.d},
-                        Mat{up ? b48.a : b16.a, up ? b48.b : b16.b, up ? b48.c : b16.c, up ? b48.d : b16.d}, up ? e48 : e16);
+                        Mat{up ? b48.a : b16.a, up ? b48.b : b16.b, up ? b48.c : b16.c, up ? b48.d : b16.d}, up ? e48 : e16, false);
         }
         {   // the lower half takes the upper half
             const Mat a32 = mat_lane_bcast(Aacc, 32), b32 = mat_lane_bcast(Bn, 32);
             const int e32 = __builtin_amdgcn_readlane(beta, 32);
-            if (lane < 32) combine(a32, b32, e32);
+            if (lane < 32) combine(a32, b32, e32, true);
         }
     }
     Mat Uin = mat_lane_next0(Aacc); // lane 63: nothing enters from above (0)

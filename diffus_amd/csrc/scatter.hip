@@ -704,6 +704,9 @@ __global__ __launch_bounds__(kBlock) void brick_convert_kernel(const float *__re
 // A brick stored this step gets flag 2 ("out holds last step's values, scratch is zero"); if the next step does not
 // touch it again (the scatter overwrites the flag with 1) its voxels are zeroed in `out` and the flag cleared.  `out`
 // therefore always equals the dense gradient of the latest step without ever being memset.
+// (Tried in round 3: 256 bricks per wave, one 16-byte flag load per lane, 512 blocks instead of 2048 -- 11.2 -> 12.7 us at
+// 32 poses (each wave's serial loop over its touched bricks gets four times longer), 15.0 -> 13.3 us at 256 poses: the
+// 64-brick waves stay.)
 __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict__ bricked, int *__restrict__ touched,
                                                                float *__restrict__ out, Geom G, long nbricks,
                                                                int mode)
