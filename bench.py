@@ -35,8 +35,10 @@ After the timed region (never inside it) the step CHECKS ITSELF: frames and per-
 pose against the scalar C oracle (`verified`); a mismatch makes the process exit non-zero.
 
 Inputs (volume -- canonical and its converted copy --, poses) are resident in HBM
-before the timed region.  The step (diffus_amd.CapturedStep) is issued either eagerly or, by default, as a
-captured hipGraph replay (the C-ABI never syncs or allocates, so it captures).
+before the timed region.  The step (diffus_amd.CapturedStep) is issued either eagerly (two C-ABI calls, three kernels)
+or as a captured hipGraph replay (the C-ABI never syncs or allocates, so it captures); by default (--issue auto) both are
+timed for a few steps after the warm-up and the faster one runs the timed region -- on this stack that is the eager
+step: kernels of one stream run back to back, two graph LAUNCHES are ~8.6 us apart (tools/graph_gaps.py).
 Kernel durations for the roofline come from HIP events recorded on the launch
 stream (torch's current stream, which is the one handed to the C-ABI).
 
@@ -106,7 +108,13 @@ def parse_args(argv=None):
     ap.add_argument("--two-pass", action="store_true",
                     help="separate forward launch (diffus_render_fwd + diffus_render_bwd_mse) instead of the one-pass "
                          "diffus_render_step_mse")
-    ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph")
+    ap.add_argument("--eager", action="store_true", help="issue launches from Python instead of replaying a hipGraph (= --issue eager)")
+    ap.add_argument("--issue", default="auto", choices=["auto", "eager", "graph"],
+                    help="how a step reaches the GPU: `eager` = the step's launches issued from Python through the C-ABI (two "
+                         "calls, three kernels), `graph` = one captured hipGraph replayed per step, `auto` = both are timed for "
+                         "a few steps after the warm-up (outside the timed region) and the faster one is used.  On this stack "
+                         "consecutive kernels of a stream or of one graph run back to back, but two graph LAUNCHES are ~8.6 us "
+                         "apart (tools/graph_gaps.py), so the eager step is the faster one unless the host is slow")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the `callers` legs (demo shape, learnable volume, moving poses)")
     ap.add_argument("--alpha", type=float, default=1e-4)
@@ -534,6 +542,9 @@ class StepRunner:
     def __init__(self, hp, args, dev, dist=None, world=1, K=1, eager=False):
         import torch
         self.torch, self.hp, self.args, self.dev, self.dist, self.world = torch, hp, args, dev, dist, world
+        issue = "eager" if (eager or args.eager) else args.issue
+        eager = issue == "eager"
+        self.issue_probe = None
         P = hp.P
         self.P = P
         self.nccl = dist is not None and args.dist_backend == "nccl"
@@ -561,6 +572,22 @@ class StepRunner:
                 print(f"hipGraph capture failed ({e!r}); running eagerly", file=sys.stderr)
                 self.graph = None
         hp.loss = self.ring[0][0]
+        if issue == "auto" and self.graph is not None:
+            # both ways, a few steps each, on this box, now: the faster one issues the timed steps
+            def probe(fn, n=60):
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            g_ms = probe(self.graphs[0][0].replay)
+            e_ms = probe(hp.step)
+            self.issue_probe = {"eager_ms_per_step": e_ms, "graph_ms_per_step": g_ms}
+            if e_ms < g_ms:
+                self.graph = None
         # The one collective of the path: all_gather of the per-pose losses over xGMI, on its own stream (an event per
         # ring orders reuse).  Every gather has completed before the closing barrier of the timed region.
         self.overlap = self.nccl and not args.sync_gather
@@ -772,11 +799,11 @@ def worker(args):
         except Exception as e:      # the oracle could not be built or run: say so, never claim a check that did not happen
             verified = {"ok": False, "failed": repr(e)}
 
-    # --- a thicker window: the same step replayed >= 200 times (the driver's own K may be as small as 20) ---
+    # --- a thicker window: the same step 200 more times (the driver's own K may be as small as 20) ---
     extra = {}
     if dist is None and args.steps < 200:
         r200 = run.timed(200, 0)
-        extra["replays_200"] = {"ms_per_step": r200["dt"] / 200 * 1e3, "value": ray_steps * 200 / r200["dt"]}
+        extra["steps_200"] = {"ms_per_step": r200["dt"] / 200 * 1e3, "value": ray_steps * 200 / r200["dt"]}
 
     # --- the other leg of the scaling story, measured in the same run ---
     #   strong (N > 1): the weak figure (--poses per GPU) and the one-GPU leg of the strong curve (all P_total poses on
@@ -918,7 +945,9 @@ def worker(args):
                 "layout": args.layout,
                 "volume_conversion": ("inside every step (learnable volume)" if args.learnable_volume else
                                       "once, outside the timed region (constant volume; see callers.learnable_volume)") if args.layout != "canonical" else "none",
-                "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": "hipGraph replay" if run.graph is not None else "eager",
+                "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": ("one captured hipGraph replayed per step" if run.graph is not None else
+                                   "eager: the step's launches issued from Python through the C-ABI (two calls, three kernels)"),
+                "issue_probe": run.issue_probe,
                 "parallelism": f"poses sharded x{ngpu}, volume replicated" if args.n < 512 else f"one volume per GPU x{ngpu} (replicas only)",
                 "host_enqueue_ms_per_step": res["host_ms"],
                 "loss_gather": ("none (1 GPU)" if dist is None else

@@ -340,9 +340,22 @@ class CapturedStep:
             self.backward()
 
     # -- hipGraph -------------------------------------------------------------------------------------------------
-    def capture(self, what: str = "step", warmup: int = 2):
-        """Capture `what` ("step", "forward" or "backward") on a side stream; returns the torch.cuda.CUDAGraph."""
-        fn = getattr(self, what)
+    def capture(self, what: str = "step", warmup: int = 2, repeat: int = 1):
+        """Capture `what` ("step", "forward" or "backward") on a side stream; returns the torch.cuda.CUDAGraph.
+        `repeat` > 1 captures that many consecutive calls into the one graph.
+
+        When to capture (measured on MI355X / ROCm 7, tools/graph_gaps.py and tools/graph_batching.py): kernels of ONE
+        graph -- like consecutive launches of one stream -- run back to back, but two graph LAUNCHES are ~8.6 us apart.
+        A graph pays off when it replaces many launches or torch ops (a whole training iteration: 0.41 ms eager, 0.073 ms
+        captured); for the bare `step()` -- two C-ABI calls, three kernels, ~15 us of host time -- issuing it eagerly is
+        FASTER than one graph per step (63.8 against 68.6 us), and a graph of `repeat=8` steps equals the eager rate."""
+        one = getattr(self, what)
+        if repeat > 1:
+            def fn():
+                for _ in range(repeat):
+                    one()
+        else:
+            fn = one
         if self._side is None:
             self._side = torch.cuda.Stream(self.dev)
         self._side.wait_stream(torch.cuda.current_stream(self.dev))
