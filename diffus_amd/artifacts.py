@@ -10,7 +10,7 @@ import itertools
 import torch
 
 from . import _lib
-from .renderer import _device_for, _ptr, _stream, _workspace
+from .renderer import _Scope, _as, _device_for, _ptr, _stream, _workspace
 
 _auto_seed = itertools.count(0x5EED)
 
@@ -20,7 +20,7 @@ def apply_artifacts(frames: torch.Tensor, std_radial: float = 0.01, std_local: f
     """frames (R,N) or (P,R,N) float32 -> same shape, float64, on frames.device."""
     lib = _lib.load()
     dev = _device_for(frames)
-    f = frames.detach().to(device=dev, dtype=torch.float32).contiguous()
+    f = _as(frames, dev, torch.float32)
     shape = f.shape
     if f.dim() == 2:
         f = f.unsqueeze(0)
@@ -33,11 +33,12 @@ def apply_artifacts(frames: torch.Tensor, std_radial: float = 0.01, std_local: f
         loc = torch.as_tensor(noise[1], dtype=torch.float64, device=dev).reshape(P, R, N).contiguous()
     if seed is None:
         seed = next(_auto_seed)
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         out = torch.empty((P, R, N), dtype=torch.float64, device=dev)
         ws = _workspace(dev, lib.diffus_artifacts_workspace_bytes(P, R, N))
         rc = lib.diffus_artifacts(_ptr(f), P, R, N, float(std_radial), float(std_local), float(max_sigma), float(alpha),
                                   _ptr(rad), _ptr(loc), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out), _ptr(ws), ws.numel(),
                                   _stream(dev))
     _lib.check(rc, "diffus_artifacts")
-    return out.reshape(shape).to(frames.device)
+    out = out.reshape(shape)
+    return out if out.device == frames.device else out.to(frames.device)

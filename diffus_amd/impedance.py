@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .renderer import _device_for, _ptr, _stream, _workspace
+from .renderer import _Scope, _device_for, _ptr, _stream, _workspace
 
 AIR_IMPEDANCE = 400.0   # reference src/impedance.py:52
 HIDDEN = 32
@@ -30,7 +30,7 @@ class _MlpFn(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, w3, b3, mask, shift, div, out_scale, fill):
         lib = _lib.load()
         dev = _device_for(x)
-        with torch.cuda.device(dev):
+        with _Scope(dev):
             xd = x.detach().to(device=dev, dtype=torch.float32).contiguous()
             params = _pack([t.detach().to(device=dev, dtype=torch.float32) for t in (w1, b1, w2, b2, w3, b3)])
             if params.numel() != 1153:
@@ -52,7 +52,7 @@ class _MlpFn(torch.autograd.Function):
         shift, div, out_scale, xdev, xdt, shapes, devs = ctx.consts
         dev = xd.device
         need_x = ctx.needs_input_grad[0]
-        with torch.cuda.device(dev):
+        with _Scope(dev):
             g = gy.detach().to(device=dev, dtype=torch.float32).contiguous()
             gp = torch.zeros(1153, dtype=torch.float32, device=dev)
             gx = torch.empty_like(xd) if need_x else None
@@ -114,7 +114,7 @@ class ImpedanceEstimator(nn.Module):
         Mask, statistics and the masked MLP all run on the GPU; no gradient (the reference wraps it in no_grad)."""
         lib = _lib.load()
         dev = _device_for(volume)
-        with torch.no_grad(), torch.cuda.device(dev):
+        with torch.no_grad(), _Scope(dev):
             v = volume.detach().to(device=dev, dtype=torch.float32).contiguous()
             mask = create_brain_mask(v, threshold)
             mean, std, _ = masked_stats(v, mask)
@@ -136,7 +136,7 @@ def create_brain_mask(volume, threshold: float = 50, iterations: int = 2) -> tor
     if vt.dim() != 3:
         raise ValueError("create_brain_mask expects a 3-D volume")
     dev = _device_for(vt)
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         v = vt.detach().to(device=dev, dtype=torch.float32).contiguous()
         d0, d1, d2 = v.shape
         mask = torch.empty(v.shape, dtype=torch.uint8, device=dev)
@@ -150,7 +150,7 @@ def masked_stats(volume: torch.Tensor, mask=None):
     """(mean, unbiased std, count) of the voxels inside the mask, accumulated in float64 on the GPU."""
     lib = _lib.load()
     dev = _device_for(volume)
-    with torch.cuda.device(dev):
+    with _Scope(dev):
         v = volume.detach().to(device=dev, dtype=torch.float32).contiguous()
         m = mask.to(device=dev).contiguous().view(torch.uint8) if mask is not None else None
         out = torch.empty(3, dtype=torch.float64, device=dev)
