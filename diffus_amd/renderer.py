@@ -178,6 +178,44 @@ def _as(t: torch.Tensor, dev: torch.device, dtype: torch.dtype) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Small HOST tensors (the notebooks pass `source` and `directions` as CPU tensors, e.g. REUBEN DATA 46 cell 14): each
+# `.to(device)` of pageable memory is a blocking ~15 us copy.  They go up together instead: packed into a slot of a pinned
+# staging ring, ONE asynchronous copy into a fresh device buffer, typed views of that buffer.
+_STAGE_SLOTS, _STAGE_BYTES = 8, 1 << 16
+_staging: dict = {}
+
+
+def _upload_small(dev: torch.device, items):
+    """items: [(cpu tensor, dtype), ...] -> list of device tensors of those dtypes (same shapes), or None when the data is
+    too large for a staging slot (the caller then converts one by one)."""
+    sizes, total = [], 0
+    for t, dt in items:
+        nb = t.numel() * torch.empty((), dtype=dt).element_size()
+        sizes.append((total, nb))
+        total += (nb + 15) & ~15
+    if total == 0 or total > _STAGE_BYTES:
+        return None
+    key = (dev, _stream_id(dev))
+    st = _staging.get(key)
+    if st is None:
+        st = _staging[key] = {"buf": torch.empty((_STAGE_SLOTS, _STAGE_BYTES), dtype=torch.uint8).pin_memory(),
+                              "ev": [None] * _STAGE_SLOTS, "next": 0}
+    k = st["next"]
+    st["next"] = (k + 1) % _STAGE_SLOTS
+    if st["ev"][k] is not None:
+        st["ev"][k].synchronize()            # the copy that last used this slot (eight uploads ago) has long finished
+    slot = st["buf"][k]
+    for (t, dt), (off, nb) in zip(items, sizes):
+        if nb:
+            slot[off:off + nb].view(dt).copy_(t.detach().reshape(-1))      # host-side cast + pack
+    out = torch.empty(total, dtype=torch.uint8, device=dev)
+    out.copy_(slot[:total], non_blocking=True)
+    ev = st["ev"][k] or torch.cuda.Event()
+    ev.record()
+    st["ev"][k] = ev
+    return [out[off:off + nb].view(dt).reshape(t.shape) for (t, dt), (off, nb) in zip(items, sizes)]
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr() if t is not None else None        # ctypes turns the int into the void* of the signature
 
@@ -308,6 +346,11 @@ class _Problem:
         self._layout_req, self._vol_src = layout, volume
         self._common = None
         sd, dd = _pose_dtype(sources), _pose_dtype(directions)
+        if not sources.is_cuda and not directions.is_cuda:       # host poses: one packed, asynchronous upload
+            with _Scope(self.dev):
+                up = _upload_small(self.dev, [(sources, sd), (directions, dd)])
+            if up is not None:
+                sources, directions = up
         self.src = _as(sources, self.dev, sd)
         if self.src.dim() != 2 or self.src.shape[1] != 3:
             self.src = self.src.reshape(-1, 3)
