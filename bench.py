@@ -452,6 +452,28 @@ def callers_legs(args, vol, dev):
 
     ms_move = time_events(moving, 48)["median"]
     ms_fixed = time_events(st.replay, 48)["median"]
+    # (d) the reference's training notebook (`[DEMO] Train MRI to Impedance MLP - GPU` cell 16) as whole captured iterations:
+    #     MLP -> slice -> frame -> loss -> backward -> Adam with the MSE fused into the renderer, and the cell's real chain
+    #     (rotate_around_apex -> differentiable_splat -> min-max -> 1 - SSIM); examples/train_*.py
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        from train_impedance_mlp import Loop
+        from train_ssim_chain import SsimLoop
+        loops = {}
+        for name, mk in (("mlp_mse", Loop), ("mlp_splat_ssim", SsimLoop)):
+            lp = mk()
+            lp.iteration()
+            lp.capture()
+            one = lp.run(200)
+            lp.capture(repeat=8)
+            loops[name] = {"ms_per_iteration_one_graph_each": one, "ms_per_iteration_8_per_graph": lp.run(200),
+                           "final_loss": float(lp.loss)}
+            del lp
+        loops["note"] = ("64 rays x 228 samples, start 110, 256^3 volume, nearest sampling (the reference's), Adam; one hipGraph per "
+                         "iteration, and 8 iterations per graph (two graph launches are ~8.6 us apart on this stack)")
+        out["training_loops"] = loops
+    except Exception as e:
+        out["training_loops"] = {"failed": repr(e)}
     out["moving_poses"] = {"ms_per_step": ms_move, "fixed_poses_ms_per_step": ms_fixed,
                            "note": "16 rings of poses, 0.013 rad apart, cycled: every step the persistent gradient tensor meets "
                                    "bricks the previous step wrote and this one does not (stale-brick clearing is exercised)"}
