@@ -172,3 +172,22 @@ def test_labels_and_pmc_lookup_follow_the_workload(tmp_path, monkeypatch):
     assert bench.find_pmc_summary(key)[1]["kernels"]["k"]["hbm_bytes_per_launch"] == 7
     assert bench.find_pmc_summary(bench.workload_key(a5)) is None
     assert bench.find_pmc_summary(dict(key, n=512)) is None
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_box_strong_scaling_line():
+    """The N > 1 worker end to end on real kernels: `bench.py --gpus 2 --dist-backend gloo` (both ranks on cuda:0, the
+    collectives through gloo -- RCCL refuses two ranks on one device) shards config 4's 256 poses 128 / 128, gathers the
+    losses in pose order, verifies frames and gathered losses against the oracle and reports the strong / weak legs."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["world_size_observed"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["poses_total"] == 256 and out["config"]["poses_per_gpu"] == 128
+    assert out["config"]["workload"].startswith("BASELINE config 4 at 2 of 8 GPUs")
+    v = out["verified"]
+    assert v["ok"] and 255 in [x["pose"] for x in v["losses"]]          # the LAST rank's last pose came back in place
+    assert out["strong"]["one_gpu"]["poses_total"] == 256 and out["strong"]["speedup_vs_one_gpu"] > 0
+    assert out["weak"]["poses_per_gpu"] == 32 and out["value"] > 0
+    assert out["roofline"]["kernel"] in ("render_bwd_kernel", "scatter_patch_kernel") and out["roofline"]["achieved"] > 0
