@@ -400,9 +400,9 @@ __device__ __forceinline__ Axis tri_axis(float p, int dim)
     Axis a;
     float hi = (float)(dim - 1);
     a.m = (p > 0.f && p < hi) ? 1.f : 0.f;
-    float pc = p;
-    if (!(pc > 0.f)) pc = 0.f; // also catches NaN
-    pc = fminf(pc, hi);        // pc is a number here: one v_min_f32 instead of compare + select
+    // clamp(p, 0, hi) with NaN -> 0 in ONE instruction: v_med3_f32 returns min3 of its operands when one of them is a NaN,
+    // and min3 skips the NaN (0 = min(0, hi)); it was compare + select + min
+    const float pc = __builtin_amdgcn_fmed3f(p, 0.f, hi);
     float f = floorf(pc);
     a.i0 = (int)f;
     a.t = pc - f;
