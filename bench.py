@@ -894,7 +894,7 @@ def worker(args):
     achieved = b[dom] * local_rs / (dom_ms * 1e-3) / 1e9
     # HBM-side bytes per launch from the committed PMC passes, only if they were collected on exactly this workload
     traffic = measured = limiter = pmc_file = None
-    evidence = None
+    evidence = issue = None
     found = find_pmc_summary(workload_key(args, P))
     if found is not None:
         pmc_file, pm = found
@@ -906,6 +906,16 @@ def worker(args):
                                       "avg_us") if k in e}
         if "step_valu_wave_insts" in pm:
             evidence["step_valu_wave_insts"] = pm["step_valu_wave_insts"]
+        # What the kernel is actually held to (the counters say "valu-issue", not "hbm"): its own VALU instruction count
+        # against the chip's issue rate -- 1024 SIMDs, one 64-lane VALU instruction per 4 cycles each, 2.4 GHz.
+        vi = e.get("counters", {}).get("SQ_INSTS_VALU")
+        if vi:
+            peak = 1024 * 2.4e9 / 4.0
+            issue = {"bound": "valu-issue", "wave_insts_per_launch": vi, "achieved": vi / (dom_ms * 1e-3), "peak": peak,
+                     "unit": "VALU wave-instructions/s", "frac": vi / (dom_ms * 1e-3) / peak,
+                     "note": "SQ_INSTS_VALU of the committed PMC pass over the live launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles"}
+        else:
+            issue = None
         if traffic is not None:
             measured = traffic / (dom_ms * 1e-3) / 1e9
     if measured is not None and measured / HBM_PEAK_GBS >= 0.4:
@@ -991,6 +1001,7 @@ def worker(args):
                 "measured_hbm_GBs": measured,
                 "measured_hbm_frac": None if measured is None else measured / HBM_PEAK_GBS,
                 "pmc_summary": pmc_file,
+                "issue_roofline": issue,
                 "evidence": evidence,
                 "bytes_per_ray_step": b[dom],
                 "ray_steps_per_launch": local_rs,
