@@ -132,8 +132,10 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
                 if (SPLIT == 1 && !(SEG && A.accum_pose)) lp[1] = 0.f;
             }
         }
+        if (A.mse != 2) { // (the one-pass step forms dL/dframe, attenuation included, in the forward sweep below)
 #pragma unroll
-        for (int j = 0; j < C; ++j) gb[j] *= fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
+            for (int j = 0; j < C; ++j) gb[j] *= fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
+        }
     }
     float zprev = lane_prev(z[C - 1], z[C - 1]);
     if (SPLIT > 1) { // the second half's first coefficient couples to the first half's last sample
