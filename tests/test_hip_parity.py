@@ -577,6 +577,31 @@ def test_fixed_point_scatter_error_bound_per_voxel(da, alpha, sampler):
         assert int((g[deep] != 0).sum()) > 0.9 * int(deep.sum())
 
 
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
+@pytest.mark.parametrize("step", [1.0, 1.7, 2.6, 6.0])
+def test_planar_scatter_long_steps_every_tile_grouping(da, sampler, step):
+    """The planar scatter keeps a patch (32 rays x 32 steps) in one LDS tile when its bounding box fits (unit steps: always),
+    splits the patch's waves into 2 or 4 groups when it does not, and adds straight to memory when even one wave's strip
+    is too wide.  Step lengths 1.7 / 2.6 / 6 voxels in a wide slice walk through all of these; every one of them against
+    float64 autograd of the same render (the reference accepts any direction norm: renderer.py:94-110)."""
+    rng = np.random.default_rng(11)
+    v = (1.5e6 + 2e5 * rng.standard_normal((320, 320, 4))).astype(np.float32)
+    R, S = 64, 96
+    ang = np.linspace(0.35, 1.2, R)
+    dirs = (step * np.stack([np.cos(ang), np.sin(ang), np.zeros(R)], 1)).astype(np.float32)
+    src = np.array([6.3, 9.1, 1.4], np.float32)
+    f_ref, up, gv_ref, _, _ = _autograd_case(v, src, dirs, S, 2e-3, 0, sampler)
+    for layout in ("paired", "canonical"):
+        vol = cuda(v).requires_grad_(True)
+        f = da.render_poses(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), S, 2e-3, sampler=sampler,
+                            layout=layout)[0]
+        assert maxnorm_rel(f.detach().cpu().numpy(), f_ref) < 2e-5
+        (f * up.cuda()).sum().backward()
+        assert maxnorm_rel(vol.grad.cpu().numpy(), gv_ref) < 1e-3, (layout, step)
+        # and the total is conserved to float32 rounding: no contribution lost between groups
+        assert abs(float(vol.grad.double().sum()) - gv_ref.sum()) <= 1e-4 * np.abs(gv_ref).sum()
+
+
 def test_wide_slices_fall_back_to_a_layout_that_fits(da, oracle):
     """Bricked / paired records address a brick row with a 24-bit multiply: slices wider than ~2^17 bricks do not fit.
     `layout="auto"` then stays canonical (same frames), an explicit request is refused with the ABI's error."""
