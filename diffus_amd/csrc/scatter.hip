@@ -241,7 +241,7 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
 #pragma unroll
         for (int q = 0; q < kSPT; ++q) {
             const bool on = mine && zb[q] != 0.f;
-            const int r0 = x0[q] * BY + org, r1 = x1[q] * BY + org;
+            const int r0 = __mul24(x0[q], BY) + org, r1 = __mul24(x1[q], BY) + org; // v_mad_i32_i24: full rate (indices < 2^23)
             const int e00 = r0 + y0[q], e11 = r1 + y1[q];
             float c00, c01 = 0.f, c10 = 0.f, c11 = 0.f;
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
@@ -255,11 +255,11 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
             asm volatile("" :: "v"(c00), "v"(c01), "v"(c10), "v"(c11), "v"(e00), "v"(e11));
             continue;
 #endif
-            const unsigned long long act = __ballot(on);
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(on); // (HIP's __ballot goes through an int: 2 VALU more)
             if (act == 0ull) continue; // wave-uniform
             const int lead = __builtin_ctzll(act);
             const int f00 = __builtin_amdgcn_readlane(e00, lead), f11 = __builtin_amdgcn_readlane(e11, lead);
-            const bool same = __ballot(on && e00 == f00 && e11 == f11) == act;
+            const bool same = __builtin_amdgcn_ballot_w64(on && e00 == f00 && e11 == f11) == act;
             if (same && __builtin_popcountll(act) > 4) { // wave-uniform: one cell for every live lane
                 const int f01 = __builtin_amdgcn_readlane(r0 + y1[q], lead), f10 = __builtin_amdgcn_readlane(r1 + y0[q], lead);
                 const double t00 = wave_sum_to_lane63((double)c00);
@@ -292,40 +292,65 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
         STAMP(4);
         // flush: a half-wave = one brick column = the 32 floats (x & 3, y & 3, z) of its brick(s); two lanes share a
         // tile entry and apply the two depth weights.  z0 even: one brick, a contiguous 128-B atomic run.
-        const int ncols = b0 * b1;
-        const float rb1 = __frcp_rn((float)b1);
-        const int o = tid & 31, msub = tid >> 5, mstep = kSB / 32;
-        const int zz = (o & 1) ? iz1 : iz0;
-        const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
-        const unsigned zpart = (unsigned)(zz >> 1) * kBrickFloats + (unsigned)((o >> 1) << 1) + (unsigned)(zz & 1);
-        const int lane_off = (o >> 3) * BY + ((o >> 1) & 3); // this lane's voxel inside its brick column
-        constexpr int FU2 = 4; // tile reads in flight per thread
-        for (int q0 = msub; q0 < ncols; q0 += mstep * FU2) {
-            double v[FU2];
-            int ei[FU2], ci[FU2], cj[FU2];
+        // A WAVE takes two adjacent columns (cj = 2 cp + h, h = lane >> 5) of one brick row ci, so everything that depends
+        // on (ci, cp) is wave-uniform and stays on the scalar unit: the tile address is a scalar base + a per-lane
+        // constant, the memory addresses a scalar 64-bit base + a per-lane 32-bit offset.  (Round 3 first had every
+        // half-wave derive its own column from a flat index: a float division, two quarter-rate v_mul_lo_u32 and two
+        // v_mad_u64_u32 per column per lane -- 24 VALU instructions per wave-atomic, a third of the kernel's VALU count.)
+        {
+            const int npr = (b1 + 1) >> 1, npairs = b0 * npr; // column pairs per brick row, in the box
+            const int lane = tid & 63, o = lane & 31, h = lane >> 5;
+            const int zz = (o & 1) ? iz1 : iz0;
+            const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
+            const bool adds = wz != 0.f, h0 = h == 0;
+            const unsigned lc_tile = (unsigned)(((o >> 3) * BY + 4 * h + ((o >> 1) & 3)) * 8);      // bytes, tile
+            const unsigned lc_g = ((unsigned)h * (unsigned)A.G.nb2 + (unsigned)(zz >> 1)) * kBrickFloats * 4u
+                                  + (unsigned)(((o >> 1) << 1) + (zz & 1)) * 4u;                     // bytes, gradient
+            const unsigned lc_t = ((unsigned)h * (unsigned)A.G.nb2 + (unsigned)(zz >> 1)) * 4u;     // bytes, touched flags
+            unsigned lc_tile_o = lc_tile;
+            asm volatile("" : "+v"(lc_tile_o)); // opaque: or else (4 ci + x) * BY is re-associated into a per-column v_mul_lo_u32
+            const char *tile_b = reinterpret_cast<const char *>(tile);
+            constexpr int FU2 = 4; // tile reads in flight per thread
+            // pair p = ci * npr + cp; this wave's pairs are wv, wv + kSW, ...: advanced by carry, no division
+            const int wv = __builtin_amdgcn_readfirstlane(wib);
+            int ci = 0, cp = wv;
+            auto carry = [&]() {
+                while (cp >= npr) { cp -= npr; ++ci; } // at most kSW trips (wave-uniform)
+            };
+            carry();
+            for (int p0 = wv; p0 < npairs; p0 += kSW * FU2) {
+                double v[FU2];
+                unsigned ta[FU2];
+                int sci[FU2], scp[FU2];
 #pragma unroll
-            for (int u = 0; u < FU2; ++u) {
-                const int q = q0 + u * mstep;
-                ci[u] = __float2int_rz(((float)q + 0.5f) * rb1); // exact: q < 2^14, i * b1 <= q
-                cj[u] = q - ci[u] * b1;
-                ei[u] = (4 * ci[u]) * BY + 4 * cj[u] + lane_off;
-                v[u] = (q < ncols) ? tile[ei[u]] : 0.0;
-            }
-            if (nsub > 1) { // leave the tile clean for the next group (after both lanes of a pair have read their entry)
+                for (int u = 0; u < FU2; ++u) {
+                    sci[u] = ci; scp[u] = cp;
+                    const bool in = p0 + u * kSW < npairs;            // wave-uniform
+                    const bool second = 2 * cp + 1 < b1;              // wave-uniform: the pair's second column exists
+                    ta[u] = (unsigned)((4 * ci) * BY + 8 * cp) * 8u + lc_tile_o;
+                    v[u] = (in && (h0 || second)) ? *reinterpret_cast<const double *>(tile_b + ta[u]) : 0.0;
+                    cp += kSW;
+                    carry();
+                }
+                if (nsub > 1) { // leave the tile clean for the next group (after both lanes of a pair have read their entry)
 #pragma unroll
-                for (int u = 0; u < FU2; ++u)
-                    if (v[u] != 0.0 && !(o & 1)) tile[ei[u]] = 0.0;
-            }
+                    for (int u = 0; u < FU2; ++u)
+                        if (v[u] != 0.0 && !(o & 1)) *reinterpret_cast<double *>(const_cast<char *>(tile_b) + ta[u]) = 0.0;
+                }
 #pragma unroll
-            for (int u = 0; u < FU2; ++u) {
-                const bool any = (unsigned)(__ballot(v[u] != 0.0) >> (tid & 32)) != 0u;
-                if (any) {
-                    const unsigned g = ((unsigned)(l0 + ci[u]) * (unsigned)A.G.nb1 + (unsigned)(l1 + cj[u])) * (unsigned)A.G.nb2 * kBrickFloats + zpart;
+                for (int u = 0; u < FU2; ++u) {
+                    const bool nz = v[u] != 0.0 && adds;
+                    if (__builtin_amdgcn_ballot_w64(nz) == 0ull) continue; // wave-uniform
+                    const size_t g0 = ((size_t)((unsigned)(l0 + sci[u]) * (unsigned)A.G.nb1 + (unsigned)(l1 + 2 * scp[u]))) * (size_t)A.G.nb2;
 #ifdef DIFFUS_ABLATE_SC_FLUSH
-                    asm volatile("" :: "v"(g), "v"((float)v[u] * wz));
+                    asm volatile("" :: "s"(g0), "v"((float)v[u] * wz));
 #else
-                    if (A.gtouched && o < 2) A.gtouched[g >> 5] = 1; // lanes 0 and 1: the brick of z0 and the brick of z1
-                    if (v[u] != 0.0 && wz != 0.f) atomicAdd(A.gvol + g, (float)v[u] * wz);
+                    if (nz) {
+                        // every adding lane marks its brick (lanes of a brick store the same word: one write)
+                        if (A.gtouched) *reinterpret_cast<int *>(reinterpret_cast<char *>(A.gtouched + g0) + (size_t)lc_t) = 1;
+                        atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(A.gvol + g0 * kBrickFloats) + (size_t)lc_g),
+                                  (float)v[u] * wz);
+                    }
 #endif
                 }
             }
@@ -377,7 +402,9 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         const unsigned Lb = xcd_remap(bid % (unsigned)per_sg, (unsigned)per_sg);
         const int rg = Lb % ray_groups;
         pose = Lb / ray_groups;
-        // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..)
+        // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..).  (Tried: a wave taking every 4th ray of the
+        // patch instead of 8 adjacent ones, so that near the apex -- adjacent rays less than a voxel apart -- fewer lanes of
+        // one LDS atomic share an address: 29.9 -> 30.5 us.)
         const int ray = rg * kScRays + tid / (kScSteps / kSPT);
         nbase = sg * kScSteps + (tid % (kScSteps / kSPT)) * kSPT;
         ray_ok = ray < A.R;
