@@ -71,13 +71,15 @@ constexpr int kCapD = kTileCap / 2; // 64-bit entries in the tile
 // general 3-D path); true when the patch is done.
 template <int SAMPLER, int PM>
 __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile, int (*s_box)[4], int *s_planar, const Pose &ps,
-                                                     long w, bool ray_ok, int nbase, int tid)
+                                                     const float *rows, unsigned row_off, bool ray_ok, int nbase, int tid)
 {
+    // rows: zbar at the block's first ray (block-uniform, a scalar base); row_off: this thread's ray and first step in
+    // BYTES from there (32 bits: no 64-bit multiply per lane)
     const int wib = tid >> 6;
     // ---- loads first: a thread's kSPT consecutive zbar values (one 16-byte load when the row allows it) ...
     float zb[kSPT];
     {
-        const float *row = A.zbar + w * A.N1;
+        const char *rb = reinterpret_cast<const char *>(rows);
 #ifdef DIFFUS_ABLATE_SC_LOAD // timing probes (tools/): the zbar values are made up, nothing is loaded
         if (true) {
 #pragma unroll
@@ -86,15 +88,15 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
 #endif
         if (ray_ok && nbase + kSPT <= A.N1) {
             if constexpr (kSPT == 4) {
-                const F4a4 t = *reinterpret_cast<const F4a4 *>(row + nbase);
+                const F4a4 t = *reinterpret_cast<const F4a4 *>(rb + (size_t)row_off);
                 zb[0] = t.x; zb[1] = t.y; zb[2] = t.z; zb[3] = t.w;
             } else {
 #pragma unroll
-                for (int q = 0; q < kSPT; ++q) zb[q] = row[nbase + q];
+                for (int q = 0; q < kSPT; ++q) zb[q] = ldb_f32(rows, row_off + 4u * q);
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < kSPT; ++q) zb[q] = (ray_ok && nbase + q < A.N1) ? row[nbase + q] : 0.f;
+            for (int q = 0; q < kSPT; ++q) zb[q] = (ray_ok && nbase + q < A.N1) ? ldb_f32(rows, row_off + 4u * q) : 0.f;
         }
     }
     // ... and the WHOLE tile is cleared while they are in flight (6 ds_write_b128 per thread)
@@ -238,17 +240,22 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
         // of the LDS pipe's time).  So each sample first asks whether the wave's lanes all sit in the same cell (two
         // readfirstlanes and compares); if so the four contributions are summed over the wave (DPP, in double) and ONE
         // lane adds them.
+        // byte offsets throughout: corner address = (row base) + 8 y in ONE v_lshl_add_u32
+        const int BY8 = BY * 8, org8 = org * 8;
+        char *tile_c = reinterpret_cast<char *>(tile);
+        auto add_at = [&](int byte_off, double v) { atomicAdd(reinterpret_cast<double *>(tile_c + byte_off), v); };
+        if (mine) { // wave-uniform (a wave belongs to one group)
 #pragma unroll
         for (int q = 0; q < kSPT; ++q) {
-            const bool on = mine && zb[q] != 0.f;
-            const int r0 = __mul24(x0[q], BY) + org, r1 = __mul24(x1[q], BY) + org; // v_mad_i32_i24: full rate (indices < 2^23)
-            const int e00 = r0 + y0[q], e11 = r1 + y1[q];
+            const bool on = zb[q] != 0.f; // a zero zbar makes every contribution below an exact zero: no select needed
+            const int r0 = __mul24(x0[q], BY8) + org8, r1 = __mul24(x1[q], BY8) + org8; // v_mad_i32_i24: full rate (indices < 2^20)
+            const int e00 = r0 + 8 * y0[q], e11 = r1 + 8 * y1[q];
             float c00, c01 = 0.f, c10 = 0.f, c11 = 0.f;
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
-                c00 = on ? zb[q] : 0.f;
+                c00 = zb[q];
             } else {
                 const float wa1 = tx[q], wa0 = 1.f - wa1, wb1 = ty[q], wb0 = 1.f - wb1;
-                const float s0 = on ? zb[q] * wa0 : 0.f, s1 = on ? zb[q] * wa1 : 0.f;
+                const float s0 = zb[q] * wa0, s1 = zb[q] * wa1;
                 c00 = s0 * wb0; c01 = s0 * wb1; c10 = s1 * wb0; c11 = s1 * wb1;
             }
 #ifdef DIFFUS_ABLATE_SC_ADD
@@ -259,9 +266,11 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
             if (act == 0ull) continue; // wave-uniform
             const int lead = __builtin_ctzll(act);
             const int f00 = __builtin_amdgcn_readlane(e00, lead), f11 = __builtin_amdgcn_readlane(e11, lead);
-            const bool same = __builtin_amdgcn_ballot_w64(on && e00 == f00 && e11 == f11) == act;
+            // (one ballot per compare: a ballot of the conjunction goes through a v_cndmask and a second compare)
+            const unsigned long long eq = __builtin_amdgcn_ballot_w64(e00 == f00) & __builtin_amdgcn_ballot_w64(e11 == f11);
+            const bool same = (eq & act) == act;
             if (same && __builtin_popcountll(act) > 4) { // wave-uniform: one cell for every live lane
-                const int f01 = __builtin_amdgcn_readlane(r0 + y1[q], lead), f10 = __builtin_amdgcn_readlane(r1 + y0[q], lead);
+                const int f01 = __builtin_amdgcn_readlane(r0 + 8 * y1[q], lead), f10 = __builtin_amdgcn_readlane(r1 + 8 * y0[q], lead);
                 const double t00 = wave_sum_to_lane63((double)c00);
                 double t01 = 0.0, t10 = 0.0, t11 = 0.0;
                 if constexpr (SAMPLER != DIFFUS_NEAREST) {
@@ -270,23 +279,24 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
                     t11 = wave_sum_to_lane63((double)c11);
                 }
                 if ((tid & 63) == 63) {
-                    if (t00 != 0.0) atomicAdd(&tile[f00], t00);
-                    if (t01 != 0.0) atomicAdd(&tile[f01], t01);
-                    if (t10 != 0.0) atomicAdd(&tile[f10], t10);
-                    if (t11 != 0.0) atomicAdd(&tile[f11], t11);
+                    if (t00 != 0.0) add_at(f00, t00);
+                    if (t01 != 0.0) add_at(f01, t01);
+                    if (t10 != 0.0) add_at(f10, t10);
+                    if (t11 != 0.0) add_at(f11, t11);
                 }
             } else {
                 // clamped samples (outside the volume: more than half of a typical fan) have zero weights on half or
                 // more of their corners: no LDS atomic is spent on a zero
-                if (c00 != 0.f) atomicAdd(&tile[e00], (double)c00);
+                if (c00 != 0.f) add_at(e00, (double)c00);
                 if constexpr (SAMPLER != DIFFUS_NEAREST) {
-                    if (c01 != 0.f) atomicAdd(&tile[r0 + y1[q]], (double)c01);
-                    if (c10 != 0.f) atomicAdd(&tile[r1 + y0[q]], (double)c10);
-                    if (c11 != 0.f) atomicAdd(&tile[e11], (double)c11);
+                    if (c01 != 0.f) add_at(r0 + 8 * y1[q], (double)c01);
+                    if (c10 != 0.f) add_at(r1 + 8 * y0[q], (double)c10);
+                    if (c11 != 0.f) add_at(e11, (double)c11);
                 }
             }
             // one sample at a time: left alone the scheduler converts all 16 contributions to doubles first (32 VGPRs)
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         __syncthreads();
         STAMP(4);
@@ -303,10 +313,10 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
             const int zz = (o & 1) ? iz1 : iz0;
             const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
             const bool adds = wz != 0.f, h0 = h == 0;
-            const unsigned lc_tile = (unsigned)(((o >> 3) * BY + 4 * h + ((o >> 1) & 3)) * 8);      // bytes, tile
-            const unsigned lc_g = ((unsigned)h * (unsigned)A.G.nb2 + (unsigned)(zz >> 1)) * kBrickFloats * 4u
+            const unsigned lc_tile = (unsigned)((__mul24(o >> 3, BY) + 4 * h + ((o >> 1) & 3)) * 8);      // bytes, tile
+            const unsigned lc_g = (__umul24((unsigned)h, (unsigned)A.G.nb2) + (unsigned)(zz >> 1)) * kBrickFloats * 4u
                                   + (unsigned)(((o >> 1) << 1) + (zz & 1)) * 4u;                     // bytes, gradient
-            const unsigned lc_t = ((unsigned)h * (unsigned)A.G.nb2 + (unsigned)(zz >> 1)) * 4u;     // bytes, touched flags
+            const unsigned lc_t = (__umul24((unsigned)h, (unsigned)A.G.nb2) + (unsigned)(zz >> 1)) * 4u;     // bytes, touched flags
             unsigned lc_tile_o = lc_tile;
             asm volatile("" : "+v"(lc_tile_o)); // opaque: or else (4 ci + x) * BY is re-associated into a per-column v_mul_lo_u32
             const char *tile_b = reinterpret_cast<const char *>(tile);
@@ -395,7 +405,8 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     const int tid = threadIdx.x;
     int pose, nbase;
     bool ray_ok;
-    long w;
+    long w, w0;        // this thread's ray, the block's first ray (block-uniform)
+    unsigned row_off;  // bytes from zbar[w0][0] to the thread's first sample
     auto decode = [&](unsigned bid) {
         const int per_sg = (int)(npatch / (unsigned)step_groups);
         const int sg = (int)(bid / (unsigned)per_sg);
@@ -405,19 +416,32 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..).  (Tried: a wave taking every 4th ray of the
         // patch instead of 8 adjacent ones, so that near the apex -- adjacent rays less than a voxel apart -- fewer lanes of
         // one LDS atomic share an address: 29.9 -> 30.5 us.)
-        const int ray = rg * kScRays + tid / (kScSteps / kSPT);
+        const int rl = tid / (kScSteps / kSPT);
         nbase = sg * kScSteps + (tid % (kScSteps / kSPT)) * kSPT;
-        ray_ok = ray < A.R;
-        w = (long)pose * A.R + (ray_ok ? ray : 0);
+        ray_ok = rg * kScRays + rl < A.R;
+        w0 = (long)pose * A.R + (long)rg * kScRays;
+        w = w0 + (ray_ok ? rl : 0);
+        row_off = (__umul24((unsigned)(ray_ok ? rl : 0), (unsigned)A.N1) + (unsigned)nbase) * 4u; // N1 < 2^24, rl < 2^6
     };
     unsigned bid = blockIdx.x;
     decode(bid);
 
     STAMP(0);
     Pose ps;
-    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    if constexpr (PM == 0) { // float32 pose: the source from the scalar unit, the direction at a 32-bit offset from a scalar base
+        const float *sp = (const float *)A.src + (long)pose * 3, *dp = (const float *)A.dirs + w0 * 3;
+        const unsigned doff = (unsigned)(w - w0) * 12u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ps.sf[c] = sp[c];
+            ps.df[c] = ldb_f32(dp, doff + 4u * c);
+        }
+        ps.pmode = 0;
+    } else {
+        load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    }
     if constexpr (kCanPlanar) {
-        if (scatter_patch_planar<SAMPLER, PM>(A, reinterpret_cast<double *>(tile), s_box, s_planar, ps, w, ray_ok, nbase, tid)) return;
+        if (scatter_patch_planar<SAMPLER, PM>(A, reinterpret_cast<double *>(tile), s_box, s_planar, ps, A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid)) return;
 #ifdef DIFFUS_SC_PLANAR_ONLY // timing probe: the general path compiled out (register budget of the planar path alone)
         return;
 #endif
