@@ -48,9 +48,24 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
 #ifndef DIFFUS_SC_MIN_BLOCKS
 #define DIFFUS_SC_MIN_BLOCKS 6
 #endif
+// stage probe (tools/): -DDIFFUS_SC_EXIT=n makes the planar path return after stage n with its values forced live
+#ifdef DIFFUS_SC_EXIT
+#define SC_EXIT(n)                                                                                                      \
+    if (DIFFUS_SC_EXIT == (n)) {                                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < kSPT; ++q_)                                                             \
+            asm volatile("" ::"v"(zb[q_]), "v"(tx[q_]), "v"(ty[q_]), "v"(x0[q_]), "v"(y0[q_]), "v"(x1[q_]), "v"(y1[q_])); \
+        return true;                                                                                                    \
+    }
+#else
+#define SC_EXIT(n) ((void)0)
+#endif
 constexpr int kScRays = DIFFUS_SC_PATCH_RAYS, kScSteps = DIFFUS_SC_PATCH_STEPS;
 constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kScRays * kScSteps / kSB;
 constexpr int kCapD = kTileCap / 2; // 64-bit entries in the tile
+#ifndef DIFFUS_SC_ROW_PAD
+#define DIFFUS_SC_ROW_PAD 1
+#endif
+constexpr unsigned kRowPad = DIFFUS_SC_ROW_PAD; // planar tile: padding entries per row (bank spread)
 
 // ---- PLANAR patches (bricked gradient) -----------------------------------------------------------------------------
 // No ray of the patch moves along dim 2 -- every fan of the reference (src/cone.py:258) -- so all its samples share ONE
@@ -70,7 +85,7 @@ constexpr int kCapD = kTileCap / 2; // 64-bit entries in the tile
 // Returns false -- nothing added, tile clear -- when some ray of the block is not planar (the caller then runs the
 // general 3-D path); true when the patch is done.
 template <int SAMPLER, int PM>
-__device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile, int (*s_box)[4], int *s_planar, const Pose &ps,
+__device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile, int (*s_box)[4], int *s_planar, int *s_live, const Pose &ps,
                                                      const float *rows, unsigned row_off, bool ray_ok, int nbase, int tid)
 {
     // rows: zbar at the block's first ray (block-uniform, a scalar base); row_off: this thread's ray and first step in
@@ -127,19 +142,19 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
     }
     // ---- bounding box of the thread's samples.  A ray is a straight line and every step of the chain p -> clamp -> floor
     // is monotone in the step index, so the extremes sit at the first and the last of its consecutive samples.
-    unsigned nz = 0;
-#pragma unroll
-    for (int q = 0; q < kSPT; ++q) {
-        if (!finitef(zb[q])) zb[q] = 0.f;
-        nz |= __float_as_uint(zb[q]) & 0x7fffffffu;
-    }
-    const bool live = nz != 0u;
+    // The box takes every sample the patch HAS (ray < R, step < N1), whatever its zbar: nothing before the first barrier
+    // waits for the loads (round 3 first boxed the samples with zbar != 0 only: every wave sat on its load before the
+    // reduction, and then on the barrier for the slowest wave's).  Whether the patch has anything to add at all is
+    // settled later, through one LDS flag.
+    const bool has = ray_ok && nbase < A.N1;
     int bx[4];
-    bx[0] = live ? min(x0[0], x0[kSPT - 1]) : 0x7fffffff;
-    bx[1] = live ? max(x1[0], x1[kSPT - 1]) : -1;
-    bx[2] = live ? min(y0[0], y0[kSPT - 1]) : 0x7fffffff;
-    bx[3] = live ? max(y1[0], y1[kSPT - 1]) : -1;
+    bx[0] = has ? min(x0[0], x0[kSPT - 1]) : 0x7fffffff;
+    bx[1] = has ? max(x1[0], x1[kSPT - 1]) : -1;
+    bx[2] = has ? min(y0[0], y0[kSPT - 1]) : 0x7fffffff;
+    bx[3] = has ? max(y1[0], y1[kSPT - 1]) : -1;
+    if (tid == 0) *s_live = 0;
     STAMP(1);
+    SC_EXIT(1);
     bx[0] = wave_reduce_minmax<true>(bx[0]);
     bx[1] = wave_reduce_minmax<false>(bx[1]);
     bx[2] = wave_reduce_minmax<true>(bx[2]);
@@ -151,6 +166,7 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
     }
     __syncthreads(); // also: the tile is clear
     STAMP(2);
+    SC_EXIT(2);
     // ---- block-uniform bookkeeping, on the scalar unit (readfirstlane): the boxes in BRICK units
     int wb[kSW][4];
     int all_planar = 1;
@@ -174,7 +190,7 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
         l0 = mn0; l1 = mn1; b0 = mx0 - mn0 + 1; b1 = mx1 - mn1 + 1;
         if (mx0 < 0 || mx1 < 0) return 0;
         const unsigned e0 = (unsigned)min(b0, 0x3fff), e1 = (unsigned)min(b1, 0x3fff); // saturate: only "> kCapD" matters
-        return (int)min(16u * e0 * e1, (unsigned)kCapD + 1u);
+        return (int)min(4u * e0 * (4u * e1 + kRowPad), (unsigned)kCapD + 1u); // rows of 4 e1 (+ pad) entries
     };
     static_assert(kSW == 4 || kSW == 8, "wave grouping below: 1, 2 or 4 groups of waves");
     int nsub = 1, l0, l1, b0, b1;
@@ -200,6 +216,16 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
         tz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tz)));
     }
     const int wpg = kSW / nsub;
+    // ---- now the zbar values are needed
+    {
+        unsigned nz = 0;
+#pragma unroll
+        for (int q = 0; q < kSPT; ++q) {
+            if (!finitef(zb[q])) zb[q] = 0.f;
+            nz |= __float_as_uint(zb[q]) & 0x7fffffffu;
+        }
+        if (__builtin_amdgcn_ballot_w64(nz != 0u) != 0ull && (tid & 63) == 63) *s_live = 1;
+    }
 #pragma unroll 1
     for (int sp = 0; sp < nsub; ++sp) { // block-uniform trip count and branches
         if (nsub > 1) need = box_of(sp * wpg, wpg, l0, l1, b0, b1);
@@ -230,8 +256,12 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
             continue;
         }
         STAMP(3);
-        // tile entry of voxel (x, y) = (x - 4 l0) * BY + (y - 4 l1), BY = 4 b1 voxels per row
-        const int BY = 4 * b1;
+    SC_EXIT(3);
+        // tile entry of voxel (x, y) = (x - 4 l0) * BY + (y - 4 l1), BY = 4 b1 voxels per row + 1 of padding: an ODD
+        // row stride.  A thread's neighbours in the wave sit 4 steps further along the ray; for a ray that runs along
+        // dim 0 that is 4 rows, and 4 rows of 4 b1 doubles are a multiple of the 64 banks whenever b1 is even: the 8
+        // step groups of a ray on one bank pair (PMC: 29 % of the LDS pipe's active cycles were bank conflicts).
+        const int BY = 4 * b1 + kRowPad;
         const int org = -(4 * l0) * BY - 4 * l1;
         // Same-address lanes of one LDS atomic are served one after the other (ds_add_f64: 21 cycles per wave-instruction
         // with distinct addresses, +23 per duplicate).  The worst case is also a common one: a ray that has left the
@@ -300,6 +330,8 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
         }
         __syncthreads();
         STAMP(4);
+    SC_EXIT(4);
+        if (__builtin_amdgcn_readfirstlane(*s_live) == 0) continue; // no wave had a nonzero zbar: the tile is still clear (block-uniform)
         // flush: a half-wave = one brick column = the 32 floats (x & 3, y & 3, z) of its brick(s); two lanes share a
         // tile entry and apply the two depth weights.  z0 even: one brick, a contiguous 128-B atomic run.
         // A WAVE takes two adjacent columns (cj = 2 cp + h, h = lane >> 5) of one brick row ci, so everything that depends
@@ -391,6 +423,7 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     __shared__ float s_sum[kSW];
     __shared__ int s_planar[kSW];
     __shared__ int s_box[kSW][4];
+    __shared__ int s_live; // planar path: some wave of the block has a nonzero zbar
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
     constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED); // nearest sampling too: one add per sample, one depth
 
@@ -427,6 +460,20 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     decode(bid);
 
     STAMP(0);
+#ifdef DIFFUS_SC_SALU_PAD // issue-rate probe (tools/): N extra scalar instructions per wave
+    {
+        int pad = 0;
+        asm volatile(".rept %1\n s_add_u32 %0, %0, 1\n .endr" : "+s"(pad) : "n"(DIFFUS_SC_SALU_PAD));
+        asm volatile("" :: "s"(pad));
+    }
+#endif
+#ifdef DIFFUS_SC_VALU_PAD // issue-rate probe (tools/): N extra vector instructions per wave
+    {
+        int pad = tid;
+        asm volatile(".rept %1\n v_add_u32 %0, %0, 1\n .endr" : "+v"(pad) : "n"(DIFFUS_SC_VALU_PAD));
+        asm volatile("" :: "v"(pad));
+    }
+#endif
     Pose ps;
     if constexpr (PM == 0) { // float32 pose: the source from the scalar unit, the direction at a 32-bit offset from a scalar base
         const float *sp = (const float *)A.src + (long)pose * 3, *dp = (const float *)A.dirs + w0 * 3;
@@ -441,7 +488,7 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     }
     if constexpr (kCanPlanar) {
-        if (scatter_patch_planar<SAMPLER, PM>(A, reinterpret_cast<double *>(tile), s_box, s_planar, ps, A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid)) return;
+        if (scatter_patch_planar<SAMPLER, PM>(A, reinterpret_cast<double *>(tile), s_box, s_planar, &s_live, ps, A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid)) return;
 #ifdef DIFFUS_SC_PLANAR_ONLY // timing probe: the general path compiled out (register budget of the planar path alone)
         return;
 #endif
