@@ -427,8 +427,11 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     constexpr int UNIT = (LAYOUT == DIFFUS_CANONICAL) ? 1 : kBrickFloats; // floats per tile unit
     constexpr bool kCanPlanar = (LAYOUT == DIFFUS_BRICKED); // nearest sampling too: one add per sample, one depth
 
-    if (blockIdx.x >= npatch) { // tail blocks of the launch, one per pose: median routing (start > 0) and d/dsource
-        pose_finish_block<SAMPLER, LAYOUT>(A, (int)(blockIdx.x - npatch), reinterpret_cast<float *>(tile));
+    // the FIRST blocks of the launch, one per pose: median routing (start > 0) and d/dsource.  They need nothing from the
+    // patches, and at the head of the grid their serial reductions run beside the first patches instead of after the last.
+    const unsigned nfin = gridDim.x - npatch;
+    if (blockIdx.x < nfin) {
+        pose_finish_block<SAMPLER, LAYOUT>(A, (int)blockIdx.x, reinterpret_cast<float *>(tile));
         return;
     }
     // patch -> (step group, pose, ray group), step group SLOWEST: the blocks in flight at any time are then the same
@@ -456,7 +459,10 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         w = w0 + (ray_ok ? rl : 0);
         row_off = (__umul24((unsigned)(ray_ok ? rl : 0), (unsigned)A.N1) + (unsigned)nbase) * 4u; // N1 < 2^24, rl < 2^6
     };
-    unsigned bid = blockIdx.x;
+    unsigned bid = blockIdx.x - nfin;
+#ifdef DIFFUS_SC_EXIT
+    if (DIFFUS_SC_EXIT == 0) return; // launch + dispatch floor
+#endif
     decode(bid);
 
     STAMP(0);

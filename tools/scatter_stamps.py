@@ -13,13 +13,14 @@ src, dirs = pose_ring(256, 32, 256)
 hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), 512, 1e-4, "trilinear", sparse=False)
 hp.fwd(); hp.loss_and_grad(); hp.zero_grad(); hp.bwd(_lib.BWD_SCAN)
 nblk = 32 * 16 * 8
-st = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
+nfin = 32  # one finishing block per pose, at the head of the grid
+st = torch.zeros((nblk + nfin) * 8, dtype=torch.int64, device="cuda")
 lib.diffus_debug_set_stamps.argtypes = [C.c_void_p]
 assert lib.diffus_debug_set_stamps(C.c_void_p(st.data_ptr())) == 0
 for _ in range(3):
     st.zero_(); hp.zero_grad(); hp.bwd(_lib.BWD_SCATTER)
 torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(nblk, 8)
+s = st.cpu().numpy().reshape(nblk + nfin, 8)[nfin:]
 done = s[:, 7] == 1
 print("blocks", nblk, "completed-with-tile", done.sum(), "early-exit/fallback", (~done).sum())
 d = np.diff(s[done][:, :6].astype(np.int64), axis=1)
