@@ -563,32 +563,26 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblk)
     return base + (b >> 3);
 }
 
-// gsrc[pose,:] = extra + sum over rays of part[pose,:,:] in a fixed order (deterministic): one block of >= kBlock
-// threads, sm = 3*kBlock floats of LDS.
-__device__ __forceinline__ void reduce_gsrc_block(const float *__restrict__ part, float *__restrict__ gsrc, int R, int pose,
-                                                  float *sm, float ex0 = 0.f, float ex1 = 0.f, float ex2 = 0.f)
+// Sums of N per-thread values over the block, in a fixed order (deterministic), valid in EVERY thread afterwards: DPP sum
+// inside each wave, one LDS word per wave and value, one barrier, then every thread adds the waves' words in wave order.
+// (Round 1-2: a log2(256)-step LDS tree with a barrier per step, once per quantity -- 20 barriers and ~8 us for the
+// per-pose epilogue, the whole latency of a one-pose backward's last launch.)  sm: N * (blockDim.x / 64) floats.
+template <int N>
+__device__ __forceinline__ void block_sums(float (&a)[N], float *sm)
 {
-    // the first kBlock threads of the block do the work; a larger block only has to reach the barriers
-    const bool act = threadIdx.x < kBlock;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    if (act)
-        for (int i = threadIdx.x; i < R; i += kBlock) {
-            const float *q = part + ((long)pose * R + i) * 3;
-            a0 += q[0]; a1 += q[1]; a2 += q[2];
-        }
-    if (act) {
-        sm[threadIdx.x] = a0; sm[kBlock + threadIdx.x] = a1; sm[2 * kBlock + threadIdx.x] = a2;
+    const int nw = (int)(blockDim.x >> 6), wib = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float t = wave_sum_to_lane63(a[n]);
+        if ((threadIdx.x & 63) == 63) sm[n * nw + wib] = t;
     }
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            sm[threadIdx.x] += sm[threadIdx.x + s];
-            sm[kBlock + threadIdx.x] += sm[kBlock + threadIdx.x + s];
-            sm[2 * kBlock + threadIdx.x] += sm[2 * kBlock + threadIdx.x + s];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += sm[n * nw + w];
+        a[n] = t;
     }
-    if (threadIdx.x < 3) gsrc[pose * 3 + threadIdx.x] = sm[threadIdx.x * kBlock] + (threadIdx.x == 0 ? ex0 : (threadIdx.x == 1 ? ex1 : ex2));
 }
 
 // ----------------------------------------------------------------------------
@@ -1069,26 +1063,25 @@ __device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
 template <int SAMPLER, int GLAYOUT>
 __device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float *sm)
 {
-    __shared__ float s_extra[3];
-    __shared__ float s_gm;
-    if (A.start > 0) { // d/d median = fixed-order sum of the rays' shares (deterministic)
-        float a = 0.f;
-        if (threadIdx.x < kBlock)
-            for (int i = threadIdx.x; i < A.R; i += kBlock) a += A.gmed[(long)pose * A.R + i];
-        if (threadIdx.x < kBlock) sm[threadIdx.x] = a;
-        __syncthreads();
-        for (int s = kBlock / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-            __syncthreads();
+    // every sum of the epilogue at once: d/dsource partials (3), loss partials, the median's gradient shares; all loads
+    // are issued before the one barrier
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+    if (A.gsrc_out)
+        for (int i = tid; i < A.R; i += nt) {
+            const float *q = A.gsrc_part + ((long)pose * A.R + i) * 3;
+            a[0] += q[0]; a[1] += q[1]; a[2] += q[2];
         }
-        if (threadIdx.x == 0) s_gm = sm[0];
-        __syncthreads();
-    }
+    if (A.loss_out)
+        for (int i = tid; i < 2 * A.R; i += nt) a[3] += A.loss_part[(long)pose * 2 * A.R + i];
+    if (A.start > 0)
+        for (int i = tid; i < A.R; i += nt) a[4] += A.gmed[(long)pose * A.R + i];
+    block_sums<5>(a, sm);
     if (threadIdx.x == 0) {
         float gs[3] = {0.f, 0.f, 0.f};
         if (A.start > 0) {
             const int i = A.who[pose];
-            const float gm = s_gm;
+            const float gm = a[4];
             if (i >= 0 && gm != 0.f && finitef(gm)) {
                 const long w = (long)pose * A.R + i;
                 Pose ps;
@@ -1103,9 +1096,9 @@ __device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float
                     const int k = A.start + q;
                     if (A.gvol) {
                         Cell c = cell_of<SAMPLER>(A, ps, k);
-                        for_each_corner<SAMPLER>(c, zb[q], [&](int a, int b, int cc, float v) {
+                        for_each_corner<SAMPLER>(c, zb[q], [&](int ci, int cj, int ck, float v) {
                             if (v != 0.f) {
-                                unsigned g = vox_off<GLAYOUT>(A.G, a, b, cc);
+                                unsigned g = vox_off<GLAYOUT>(A.G, ci, cj, ck);
                                 atomicAdd(A.gvol + g, v);
                                 if (GLAYOUT == DIFFUS_BRICKED && A.gtouched) A.gtouched[g >> 5] = 1;
                             }
@@ -1124,22 +1117,9 @@ __device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float
                     for (int c = 0; c < 3; ++c) A.gdirs[w * 3 + c] += gd[c]; // this block is the only writer now
             }
         }
-        s_extra[0] = gs[0]; s_extra[1] = gs[1]; s_extra[2] = gs[2];
-    }
-    __syncthreads();
-    if (A.gsrc_out) reduce_gsrc_block(A.gsrc_part, A.gsrc_out, A.R, pose, sm, s_extra[0], s_extra[1], s_extra[2]);
-    if (A.loss_out) { // fused loss: fixed-order sum of the rays' partial sums (deterministic)
-        __syncthreads();
-        float a = 0.f;
-        if (threadIdx.x < kBlock)
-            for (int i = threadIdx.x; i < 2 * A.R; i += kBlock) a += A.loss_part[(long)pose * 2 * A.R + i];
-        if (threadIdx.x < kBlock) sm[threadIdx.x] = a;
-        __syncthreads();
-        for (int s = kBlock / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) A.loss_out[pose] = sm[0];
+        if (A.gsrc_out)
+            for (int c = 0; c < 3; ++c) A.gsrc_out[pose * 3 + c] = a[c] + gs[c];
+        if (A.loss_out) A.loss_out[pose] = a[3];
     }
 }
 
