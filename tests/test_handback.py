@@ -342,3 +342,29 @@ def test_canonical_volume_with_the_bricked_sparse_gradient(Step, sampler):
         assert torch.equal(a.frame, b.frame) and torch.equal(a.loss, b.loss)
         assert torch.equal(a.gsrc, b.gsrc) and torch.equal(a.gdirs, b.gdirs)
         assert torch.all(a.gvol_k == 0)
+
+
+def test_a_graph_of_several_steps_leaves_what_one_step_leaves(Step):
+    """capture(repeat=m): m consecutive steps in ONE hipGraph (two graph launches are ~8.6 us apart on this stack; DESIGN
+    fact 22).  With the inputs unchanged every step rewrites the same results -- frame, per-pose losses and pose
+    gradients bit for bit, the volume gradient up to the order of its float atomics, nothing of earlier steps left in
+    the persistent tensor, scratch and flags consistent for the next replay."""
+    n, R, S = 64, 40, 130
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, 5, R)
+    s, d = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+    one = Step(vol, s, d, S, 2e-3, "trilinear")
+    one.step()
+    torch.cuda.synchronize()
+    many = Step(vol, s, d, S, 2e-3, "trilinear")
+    g = many.capture("step", repeat=3)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(many.frame, one.frame) and torch.equal(many.loss, one.loss)
+    assert torch.equal(many.gsrc, one.gsrc) and torch.equal(many.gdirs, one.gdirs)
+    assert torch.equal(many.gvol != 0, one.gvol != 0)
+    assert float((many.gvol - one.gvol).abs().max()) <= 1e-5 * float(one.gvol.abs().max())
+    assert torch.all(many.gvol_k == 0)
+    with pytest.raises(AttributeError):
+        many.capture("no_such_stage")
