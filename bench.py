@@ -14,7 +14,7 @@ Metric (BASELINE.json): ray-steps/s, forward + backward, 256^3 volume, 256 rays 
 512 steps.  One *step* = one pass of the hot path over one batch of poses:
   forward frame, loss_p = sum(frame_p^2) and the backward of it in ONE call (diffus_render_step_mse: the adjoint-scan
      kernel recomputes the forward per ray anyway, so it also writes the frame and forms dL/dframe = 2 frame on the
-     spot; the per-pose loss is summed by the call's closing blocks.  --two-pass runs diffus_render_fwd +
+     spot; the per-pose loss is summed by the call's per-pose blocks.  --two-pass runs diffus_render_fwd +
      diffus_render_bwd_mse, --unfused-loss diffus_render_fwd + the loss kernel diffus_loss_sumsq + diffus_render_bwd):
      frame, loss, d/d volume, d/d source, d/d directions
   -> touched bricks of the gradient scratch -> the caller's canonical (d0,d1,d2) volume-gradient tensor
@@ -977,7 +977,7 @@ def worker(args):
                              f"{args.sampler} sampling; forward + sum-of-squares loss + backward ({grads}) "
                              f"+ canonical gradient + per-pose loss gather"),
                 "loss": ("separate kernel (diffus_loss_sumsq)" if args.unfused_loss else
-                         "fused: dL/dframe formed inside the backward, per-pose loss summed by its closing blocks"),
+                         "fused: dL/dframe formed inside the backward, per-pose loss summed by its per-pose blocks"),
                 "passes": ("one (diffus_render_step_mse: the adjoint-scan kernel also writes the frame; no forward launch)"
                            if one_pass else "two (diffus_render_fwd, then the backward)"),
                 "poses_per_gpu": P, "poses_total": P_total, "rays": args.rays, "samples": args.samples,

@@ -1051,7 +1051,7 @@ __device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
 }
 
 
-// What is left of a pose's backward once every ray's adjoint scan has run (one block per pose; the tail blocks of the
+// What is left of a pose's backward once every ray's adjoint scan has run (one block per pose; the first blocks of the
 // scatter launch, or pose_finish_kernel when there is no scatter):
 //   * start > 0: the first kept reflection coefficient of every ray was replaced by the per-pose median (reference
 //     src/renderer.py:243-244), so their gradients were summed into gmed[pose]; torch.median routes that sum to the
