@@ -714,29 +714,33 @@ __device__ __forceinline__ unsigned part_z(int z)
     return (((unsigned)z >> 1) << 7) | (((unsigned)z & 1u) << 2);
 }
 
-// lerps of one trilinear sample from its 8 corner values (order 000,001,010,011,100,101,110,111 =
-// dim0,dim1,dim2 bits), lerp order dim 2, dim 1, dim 0 like oracle/diffus_oracle.c orc_sample_trilinear.  Each lerp
-// is ONE fused multiply-add, a + t (b - a) rounded once: the fused kernels are VALU-issue-bound (PMC: VALU pipes
-// 60-80 % busy) and the separate multiply and add of the oracle's sequence were 7 (11 with the gradient) of a
-// sample's ~100 instructions.  The result differs from the oracle's by at most the rounding of t (b - a), ~1e-7
-// relative, inside the 1e-5 frame tolerance; the stage-wise kernels (tri_sample) keep the oracle's exact sequence.
+// lerps of one trilinear sample from its 8 corner values (order 000,001,010,011,100,101,110,111 = dim0,dim1,dim2 bits).
+// Each lerp is ONE fused multiply-add, a + t (b - a) rounded once, and the lerps run dim 0 first, then dim 1, then dim 2
+// -- the oracle (oracle/diffus_oracle.c orc_sample_trilinear) does dim 2, dim 1, dim 0 with a separate multiply and add.
+// Why: the corners arrive as two 16-byte rows (x0 and x1: y0z0, y0z1, y1z0, y1z1 -- a PAIRED record, or two canonical
+// pairs), i.e. in register PAIRS (z0, z1).  Dim 0 first keeps every operand in those pairs: the value is 3 v_pk_add +
+// 3 v_pk_fma + 2 scalar instructions, all three gradient components 9 more -- 17 against the 25 of the dim-2-first
+// order (which hipcc's SLP pass packed too, but behind ~20 register moves per sample: the fused kernels are
+// VALU-issue-bound).  Same trilinear polynomial, other rounding: <= 2e-7 relative from the oracle's sequence, inside the
+// 1e-5 frame tolerance; the stage-wise kernels (tri_sample) keep the oracle's exact sequence.
+typedef float V2f __attribute__((ext_vector_type(2)));
 template <bool GRAD>
 __device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a, const Axis &b, const Axis &c)
 {
-    float e00 = v[1] - v[0], e01 = v[3] - v[2], e10 = v[5] - v[4], e11 = v[7] - v[6];
-    float c00 = __builtin_fmaf(c.t, e00, v[0]), c01 = __builtin_fmaf(c.t, e01, v[2]);
-    float c10 = __builtin_fmaf(c.t, e10, v[4]), c11 = __builtin_fmaf(c.t, e11, v[6]);
-    float f0 = c01 - c00, f1 = c11 - c10;
-    float q0 = __builtin_fmaf(b.t, f0, c00), q1 = __builtin_fmaf(b.t, f1, c10);
-    float g = q1 - q0;
+    const V2f r0a = {v[0], v[1]}, r0b = {v[2], v[3]}, r1a = {v[4], v[5]}, r1b = {v[6], v[7]}; // (x, y): its (z0, z1)
+    const V2f ta = {a.t, a.t}, tb = {b.t, b.t};
+    const V2f da = r1a - r0a, db = r1b - r0b;                                   // d/d dim0 at y0, y1
+    const V2f xa = __builtin_elementwise_fma(ta, da, r0a), xb = __builtin_elementwise_fma(ta, db, r0b);
+    const V2f ey = xb - xa;                                                     // d/d dim1 at z0, z1
+    const V2f yv = __builtin_elementwise_fma(tb, ey, xa);
+    const float ez = yv.y - yv.x;                                               // d/d dim2
     TriSample s;
-    s.v = __builtin_fmaf(a.t, g, q0);
+    s.v = __builtin_fmaf(c.t, ez, yv.x);
     if (GRAD) {
-        float h0 = __builtin_fmaf(b.t, e01 - e00, e00);
-        float h1 = __builtin_fmaf(b.t, e11 - e10, e10);
-        s.g0 = g * a.m;
-        s.g1 = __builtin_fmaf(a.t, f1 - f0, f0) * b.m;
-        s.g2 = __builtin_fmaf(a.t, h1 - h0, h0) * c.m;
+        const V2f dy = __builtin_elementwise_fma(tb, db - da, da);
+        s.g0 = __builtin_fmaf(c.t, dy.y - dy.x, dy.x) * a.m;
+        s.g1 = __builtin_fmaf(c.t, ey.y - ey.x, ey.x) * b.m;
+        s.g2 = ez * c.m;
     } else {
         s.g0 = s.g1 = s.g2 = 0.f;
     }

@@ -6,7 +6,7 @@ against
   * the oracle (oracle/diffus_oracle.c, restating reference src/renderer.py:201-275), echo series in float64: frames
     <= 2e-5 max-norm-relative -- on the poses whose fan grazes the skull (echo = b/d with d nearly cancelled, |echo| > 100)
     <= 16 input roundings' worth (oracle/conditioning.py; the reference's own float32 LU is 3.3e-5 / 1.4e-4 from its
-    float64 result on two such rays, golden G17) --, per-pose losses <= 1e-4;
+    float64 result on two such rays, golden G17) --, per-pose losses <= 1e-4 (twice the frame tolerance on those poses);
   * the two-call `render_poses` autograd path (diffus_render_fwd + diffus_render_bwd): gsrc / gdirs / gvol <= 1e-4;
   * float64 torch autograd over oracle/autograd_ref.py for one pose: <= 1e-3.
 The same at 256 poses (BASELINE config 4 at 1 of 8 GPUs): forward + loss."""
@@ -54,8 +54,10 @@ def test_config3_one_pass_step_values(oracle, vol256):
         f64, tol, _ = frame64_and_tolerance(vol256, src[p], dirs[p], S, ALPHA)
         tols[p] = tol
         assert maxnorm_rel(frames[p], f64) < tol, (p, tol)
+        # the loss: 1e-4, or twice the frame tolerance where that is larger -- a grazing interface scales every LATER echo
+        # of its ray by the same ill-conditioned factor, and a systematic relative error eps is 2 eps in a sum of squares
         want = float((f64 ** 2).sum())
-        assert abs(losses[p] - want) <= 1e-4 * want, (p, losses[p], want)
+        assert abs(losses[p] - want) <= max(1e-4, 2 * tol) * want, (p, losses[p], want, tol)
     assert tols[0] == tols[9] == tols[27] == tols[31] == 2e-5 and tols[18] > 1e-4      # the tolerance is earned, not blanket
     for p in (0, 9, 27, 31):                            # ... and the float32 oracle itself on the well-conditioned ones
         fo = oracle.plot_beam_frame(vol256, src[p], dirs[p], S, ALPHA, 0, sampler="trilinear")[3]
@@ -124,7 +126,7 @@ def test_config4_one_gpu_leg_256_poses(oracle, vol256):
         f64, tol, _ = frame64_and_tolerance(vol256, src[p], dirs[p], S, ALPHA)
         assert maxnorm_rel(step.frame[p].cpu().numpy(), f64) < tol, (p, tol)
         want = float((f64 ** 2).sum())
-        assert abs(losses[p] - want) <= 1e-4 * want, (p, losses[p], want)
+        assert abs(losses[p] - want) <= max(1e-4, 2 * tol) * want, (p, losses[p], want, tol)
     own = (step.frame.double() ** 2).sum((1, 2)).cpu().numpy()
     assert np.all(np.abs(losses - own) <= 1e-5 * own)
     # sharding invariance (what the strong-scaling curve relies on): the pose gradients of poses [64, 96) are the same

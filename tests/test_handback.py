@@ -287,8 +287,13 @@ def test_fused_mse_backward_equals_loss_kernel_plus_backward(Step, S, start, sam
         torch.cuda.synchronize()
         # same arithmetic; the scan may associate differently (chunk length, two waves per ray), hence rounding only
         # (each within 1e-5 of the float64 truth: tests/test_hip_parity.py)
-        assert float((one.frame - fused.frame).abs().max()) <= 2e-5 * float(fused.frame.abs().max())
-        assert torch.allclose(one.loss, fused.loss, rtol=1e-5)
+        # The short steps of the long-ray cases put grazing interfaces on some rays (|echo| ~ 100: an ill-conditioned b/d,
+        # DESIGN section 2); two float32 evaluations that associate the scan differently then agree to ~1e-4 only -- the
+        # reference's own float32 is 1.4e-4 from its float64 there (golden G17) -- and so does the sum of squares
+        fmax = float(fused.frame.abs().max())
+        ill = fmax > 10.0
+        assert float((one.frame - fused.frame).abs().max()) <= (2e-4 if ill else 2e-5) * fmax
+        assert torch.allclose(one.loss, fused.loss, rtol=2e-4 if ill else 1e-5)
         assert float((one.gvol - fused.gvol).abs().max()) <= 1e-4 * float(fused.gvol.abs().max())
         assert torch.allclose(one.gsrc, fused.gsrc, rtol=1e-4, atol=1e-4 * float(fused.gsrc.abs().max()))
         assert torch.allclose(one.gdirs, fused.gdirs, rtol=1e-4, atol=1e-4 * float(fused.gdirs.abs().max()))
