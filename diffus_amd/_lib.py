@@ -23,7 +23,7 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
            "diffus_echo_bwd_workspace_bytes", "diffus_echo_traces_bwd", "diffus_splat_axes", "diffus_rotate_around_apex",
            "diffus_ssim_workspace_bytes", "diffus_ssim_loss_fwd", "diffus_ssim_loss_bwd")
 
-ABI_VERSION = 3          # include/diffus_hip.h DIFFUS_ABI_VERSION
+ABI_VERSION = 4          # include/diffus_hip.h DIFFUS_ABI_VERSION
 DIFFUS_F32, DIFFUS_F64, DIFFUS_I64 = 0, 1, 2
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
@@ -114,11 +114,11 @@ def load():
     lib.diffus_artifacts.restype = i
     lib.diffus_artifacts.argtypes = [vp, i, i, i, d, d, d, d, vp, vp, C.c_uint64, vp, vp, sz, vp]
     lib.diffus_mlp_fwd.restype = i
-    lib.diffus_mlp_fwd.argtypes = [vp, vp, sz, vp, f, f, f, f, vp, vp]
+    lib.diffus_mlp_fwd.argtypes = [vp, vp, sz, vp, f, f, f, f, vp, sz, vp]
     lib.diffus_mlp_workspace_bytes.restype = sz
     lib.diffus_mlp_workspace_bytes.argtypes = []
     lib.diffus_mlp_bwd.restype = i
-    lib.diffus_mlp_bwd.argtypes = [vp, vp, sz, vp, f, f, f, vp, vp, vp, vp, sz, vp]
+    lib.diffus_mlp_bwd.argtypes = [vp, vp, sz, vp, f, f, f, vp, sz, vp, vp, vp, sz, vp]
     lib.diffus_brain_mask_workspace_bytes.restype = sz
     lib.diffus_brain_mask_workspace_bytes.argtypes = [i, i, i]
     lib.diffus_brain_mask.restype = i

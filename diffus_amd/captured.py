@@ -68,9 +68,18 @@ class _CapturedRender(torch.autograd.Function):
         if ctx.stamp != step._stamp:
             raise RuntimeError("CapturedStep.render: backward of a frame whose buffers a later render() has overwritten "
                                "(one forward, one backward, in that order)")
-        if gframe.data_ptr() != step.gframe.data_ptr():
-            step.gframe.copy_(gframe)
-        step._run("backward")
+        own = step.gframe
+        if gframe.data_ptr() != own.data_ptr():
+            # eager launches take dL/dframe where it lies (no copy); a captured backward graph holds the step's own buffer
+            if (step._graphs.get("backward") is None and gframe.is_contiguous() and gframe.dtype == own.dtype
+                    and gframe.device == own.device and gframe.numel() == own.numel()):
+                step.gframe = gframe
+            else:
+                own.copy_(gframe)
+        try:
+            step._run("backward")
+        finally:
+            step.gframe = own
         need_v, need_s, need_d = ctx.needs_input_grad[1:4]
         keep = (lambda t: t) if step.alias_grads else (lambda t: t.clone())
         return (None, keep(step.gvol) if (need_v and step.gvol is not None) else None,
@@ -84,7 +93,10 @@ class _CapturedMSE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, step, volume, sources, directions, slice_values, dim, index):
         if slice_values is not None:
-            step.vol.select(dim, index).copy_(slice_values)
+            sl = step.vol.select(dim, index)
+            if not (slice_values.data_ptr() == sl.data_ptr() and slice_values.shape == sl.shape
+                    and slice_values.stride() == sl.stride() and slice_values.dtype == sl.dtype):
+                sl.copy_(slice_values)  # (values written straight into slice_view(dim, index) are already in place)
         step._run("step")
         ctx.step = step
         ctx.where = None if slice_values is None else (dim, index)
@@ -100,6 +112,12 @@ class _CapturedMSE(torch.autograd.Function):
             raise RuntimeError("CapturedStep.mse_loss: backward of a loss whose buffers a later call has overwritten")
         need_v, need_s, need_d, need_sl = ctx.needs_input_grad[1:5]
         have_v = step.gvol is not None
+        if g.data_ptr() == step.unit.data_ptr():
+            # `loss.backward(step.unit)`: the upstream gradient IS the step's resident 1.0 -- the gradients are handed over as
+            # they are (views of the step's buffers; the slice a strided one) instead of through four multiply launches
+            return (None, step.gvol if (need_v and have_v) else None, step.gsrc.reshape(step._src_shape) if need_s else None,
+                    step.gdirs if need_d else None,
+                    step.gvol.select(*ctx.where) if (need_sl and have_v and ctx.where is not None) else None, None, None)
         return (None, step.gvol * g if (need_v and have_v) else None,
                 (step.gsrc * g).reshape(step._src_shape) if need_s else None, step.gdirs * g if need_d else None,
                 step.gvol.select(*ctx.where) * g if (need_sl and have_v and ctx.where is not None) else None, None, None)
@@ -110,7 +128,10 @@ class _SliceIntoVolume(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, step, values, dim, index):
-        step.vol.select(dim, index).copy_(values)
+        sl = step.vol.select(dim, index)
+        if not (values.data_ptr() == sl.data_ptr() and values.shape == sl.shape and values.stride() == sl.stride()
+                and values.dtype == sl.dtype):
+            sl.copy_(values)            # (values written straight into slice_view(dim, index) are already in place)
         ctx.where = (dim, index)
         return step.vol.detach()
 
@@ -118,7 +139,7 @@ class _SliceIntoVolume(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gvol):
         dim, index = ctx.where
-        return None, gvol.select(dim, index).contiguous(), None, None
+        return None, gvol.select(dim, index), None, None      # a strided view: consumers that need it packed pack it
 
 
 class CapturedStep:
@@ -170,6 +191,7 @@ class CapturedStep:
         self.loss_scale = float(loss_scale)
         self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
         self.gframe = torch.empty_like(self.frame)
+        self.unit = torch.ones((), dtype=torch.float32, device=dev)     # `loss.backward(step.unit)`: see _CapturedMSE.backward
         d0, d1, d2 = (int(x) for x in volume.shape)
         self.dims = (d0, d1, d2)
         # canonical gradient, what the caller gets.  persistent: the tensor is kept across steps and
@@ -398,6 +420,11 @@ class CapturedStep:
             raise _lib.DiffusError("volume_with_slice(): the converted copy must follow the volume: use layout='canonical' "
                                    "or learnable_volume=True")
         return _SliceIntoVolume.apply(self, values, int(dim), int(index))
+
+    def slice_view(self, dim: int, index: int) -> torch.Tensor:
+        """The step's volume at `index` along `dim`, as a view (no gradient): somewhere for a producer to write a slice in
+        place -- `model(x, scale, out=step.slice_view(2, k))` -- before `volume_with_slice()` / `mse_loss()` get it."""
+        return self.vol.detach().select(int(dim), int(index))
 
     def _adopt(self, volume, sources, directions, what: str):
         """Copy arguments that are not the step's own tensors into them, in place; returns the three graph inputs."""

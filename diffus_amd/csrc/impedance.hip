@@ -37,6 +37,7 @@ struct MlpArgs {
     float shift, div, out_scale, fill;
     float *y;
     const float *gy;
+    size_t y_stride, gy_stride; // elements between consecutive outputs / upstream gradients (1 = contiguous)
     float *gx;      // nullable
     float *partial; // (gridDim.x, kNP)
 };
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kBlock, DIFFUS_MLP_FWD_WAVES) void mlp_fwd_kernel(M
         float xv = live ? xn : A.shift;
         fetch(g + nwaves, xn, mkn);
         if (__ballot(live) == 0) { // all air: nothing to evaluate (most of a head volume)
-            if (in) A.y[i0] = A.fill;
+            if (in) A.y[i0 * A.y_stride] = A.fill;
             continue;
         }
         xv = __fdiv_rn(xv - A.shift, A.div); // zscore_normalize, reference src/utils.py:38
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kBlock, DIFFUS_MLP_FWD_WAVES) void mlp_fwd_kernel(M
         s0 += __shfl_xor(s0, 32, kWave);
         s1 += __shfl_xor(s1, 32, kWave);
         const float yv = ((h ? s1 : s0) + b3) * A.out_scale;
-        if (in) A.y[i0] = live ? yv : A.fill;
+        if (in) A.y[i0 * A.y_stride] = live ? yv : A.fill;
     }
 }
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void mlp_bwd_kernel(MlpArgs A)
         size_t i = t * 32 + r;
         i = i < A.n ? i : A.n - 1;
         xv = A.x[i];
-        gv = A.gy[i];
+        gv = A.gy[i * A.gy_stride];
         mk = has_mask ? A.mask[i] : 1u;
     };
     float xnx, gnx;
@@ -360,13 +361,13 @@ unsigned grid_for(size_t n)
 extern "C" {
 
 int diffus_mlp_fwd(const float *x, const unsigned char *mask, size_t n, const float *params, float in_shift, float in_div,
-                   float out_scale, float fill, float *y, diffus_stream_t stream)
+                   float out_scale, float fill, float *y, size_t y_stride, diffus_stream_t stream)
 {
-    if (!x || !params || !y || n == 0) return DIFFUS_EINVAL;
+    if (!x || !params || !y || n == 0 || y_stride == 0) return DIFFUS_EINVAL;
     if (!(in_div != 0.f)) return DIFFUS_EINVAL;
     MlpArgs A{};
     A.x = x; A.mask = mask; A.n = n; A.params = params;
-    A.shift = in_shift; A.div = in_div; A.out_scale = out_scale; A.fill = fill; A.y = y;
+    A.shift = in_shift; A.div = in_div; A.out_scale = out_scale; A.fill = fill; A.y = y; A.y_stride = y_stride;
     const size_t ngroups = (n + 63) / 64;
     static const unsigned resident = resident_blocks(mlp_fwd_kernel);
     const size_t want = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -378,16 +379,16 @@ int diffus_mlp_fwd(const float *x, const unsigned char *mask, size_t n, const fl
 size_t diffus_mlp_workspace_bytes(void) { return align256(sizeof(float) * (size_t)kMlpMaxBlocks * kNP); }
 
 int diffus_mlp_bwd(const float *x, const unsigned char *mask, size_t n, const float *params, float in_shift, float in_div,
-                   float out_scale, const float *gy, float *gparams, float *gx, void *workspace, size_t workspace_bytes,
-                   diffus_stream_t stream)
+                   float out_scale, const float *gy, size_t gy_stride, float *gparams, float *gx, void *workspace,
+                   size_t workspace_bytes, diffus_stream_t stream)
 {
-    if (!x || !params || !gy || !gparams || n == 0) return DIFFUS_EINVAL;
+    if (!x || !params || !gy || !gparams || n == 0 || gy_stride == 0) return DIFFUS_EINVAL;
     if (!(in_div != 0.f)) return DIFFUS_EINVAL;
     if (!workspace || workspace_bytes < diffus_mlp_workspace_bytes()) return DIFFUS_EWORKSPACE;
     MlpArgs A{};
     A.x = x; A.mask = mask; A.n = n; A.params = params;
     A.shift = in_shift; A.div = in_div; A.out_scale = out_scale;
-    A.gy = gy; A.gx = gx; A.partial = (float *)workspace;
+    A.gy = gy; A.gy_stride = gy_stride; A.gx = gx; A.partial = (float *)workspace;
     const size_t ntiles = (n + 31) / 32;
     static const unsigned resident = resident_blocks(mlp_bwd_kernel);
     const size_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;

@@ -316,6 +316,24 @@ __device__ __forceinline__ float coord_f32(const void *p, int dtype, long i)
     return (float)((const long long *)p)[i]; // DIFFUS_I64
 }
 
+__device__ __forceinline__ void axes_from_variances(const double (&var)[3], int *__restrict__ axes)
+{
+    // stable descending order of three keys; a NaN variance (NaN coordinates) sorts last
+    int o[3] = {0, 1, 2};
+    auto before = [&](int a, int b) { // a strictly before b
+        const double va = var[a], vb = var[b];
+        if (va != va) return false;
+        if (vb != vb) return true;
+        return va > vb;
+    };
+    for (int i = 1; i < 3; ++i)
+        for (int j = i; j > 0 && before(o[j], o[j - 1]); --j) {
+            const int t = o[j]; o[j] = o[j - 1]; o[j - 1] = t;
+        }
+    axes[0] = o[0];
+    axes[1] = o[1];
+}
+
 constexpr int kAxesThreads = 1024;
 __global__ __launch_bounds__(kAxesThreads) void splat_axes_kernel(const void *x, const void *y, const void *z, int dx, int dy,
                                                                   int dz, long n, int *__restrict__ axes)
@@ -349,20 +367,54 @@ __global__ __launch_bounds__(kAxesThreads) void splat_axes_kernel(const void *x,
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // stable descending order of three keys; a NaN variance (NaN coordinates) sorts last
-        int o[3] = {0, 1, 2};
-        auto before = [&](int a, int b) { // a strictly before b
-            const double va = var[a], vb = var[b];
-            if (va != va) return false;
-            if (vb != vb) return true;
-            return va > vb;
-        };
-        for (int i = 1; i < 3; ++i)
-            for (int j = i; j > 0 && before(o[j], o[j - 1]); --j) {
-                const int t = o[j]; o[j] = o[j - 1]; o[j - 1] = t;
-            }
-        axes[0] = o[0];
-        axes[1] = o[1];
+        const double v3[3] = {var[0], var[1], var[2]};
+        axes_from_variances(v3, axes);
+    }
+}
+
+// The same in two launches for large n (one 1024-thread block walking 37 k int64 samples took 25-45 us, the longest kernel of
+// the demo frame): kAxesBlocks blocks leave six partial sums each (same pivot: element 0), a 64-thread block adds them in
+// block order and sorts.  `part` is borrowed from the c0 plane, which splat_select_kernel overwrites afterwards.
+constexpr int kAxesBlocks = 64;
+__global__ __launch_bounds__(kBlock) void splat_axes_partial_kernel(const void *x, const void *y, const void *z, int dx, int dy,
+                                                                    int dz, long n, double *__restrict__ part)
+{
+    __shared__ double sm[6][kWavesPerBlock];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double p0 = (double)coord_f32(x, dx, 0), p1 = (double)coord_f32(y, dy, 0), p2 = (double)coord_f32(z, dz, 0);
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)kAxesBlocks * kBlock) {
+        const double a = (double)coord_f32(x, dx, i) - p0, b = (double)coord_f32(y, dy, i) - p1, c = (double)coord_f32(z, dz, i) - p2;
+        acc[0] += a; acc[1] += a * a;
+        acc[2] += b; acc[3] += b * b;
+        acc[4] += c; acc[5] += c * c;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        acc[k] = wave_sum_to_lane63(acc[k]);
+        if (lane == kWave - 1) sm[k][wv] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double t = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) t += sm[threadIdx.x][w];
+        part[blockIdx.x * 6 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kWave) void splat_axes_final_kernel(const double *__restrict__ part, long n, int *__restrict__ axes)
+{
+    // one wave: lane b holds block b's six sums (all loads in flight at once), a DPP tree adds them -- a fixed order
+    static_assert(kAxesBlocks == kWave, "one lane per partial");
+    double t[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = part[threadIdx.x * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = wave_sum_to_lane63(t[k]);
+    if (threadIdx.x == kWave - 1) {
+        double var[3];
+        for (int a = 0; a < 3; ++a) var[a] = (n > 1) ? (t[2 * a + 1] - t[2 * a] * t[2 * a] / (double)n) / (double)(n - 1) : 0.0;
+        axes_from_variances(var, axes);
     }
 }
 
@@ -489,7 +541,13 @@ int diffus_splat_axes(const void *x, int x_dtype, const void *y, int y_dtype, co
         if (d != DIFFUS_F32 && d != DIFFUS_F64 && d != DIFFUS_I64) return DIFFUS_EINVAL;
     if ((c0 == nullptr) != (c1 == nullptr)) return DIFFUS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(splat_axes_kernel, dim3(1), dim3(kAxesThreads), 0, st, x, y, z, x_dtype, y_dtype, z_dtype, n, axes);
+    if (c0 && n >= (long)kAxesBlocks * 6 * 2 && n >= 8192 && (reinterpret_cast<size_t>(c0) & 7) == 0) {
+        double *part = reinterpret_cast<double *>(c0); // kAxesBlocks x 6 doubles fit (n floats), rewritten by the select below
+        hipLaunchKernelGGL(splat_axes_partial_kernel, dim3(kAxesBlocks), dim3(kBlock), 0, st, x, y, z, x_dtype, y_dtype, z_dtype, n, part);
+        hipLaunchKernelGGL(splat_axes_final_kernel, dim3(1), dim3(kWave), 0, st, part, n, axes);
+    } else {
+        hipLaunchKernelGGL(splat_axes_kernel, dim3(1), dim3(kAxesThreads), 0, st, x, y, z, x_dtype, y_dtype, z_dtype, n, axes);
+    }
     if (c0) {
         unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splat_select_kernel, dim3(nb), dim3(kBlock), 0, st, x, y, z, x_dtype, y_dtype, z_dtype, n, axes, c0, c1);

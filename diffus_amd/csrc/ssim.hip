@@ -29,30 +29,47 @@ struct SsimArgs {
 };
 
 // lo / hi of the image and how many pixels attain them (torch's min() / max() backward shares the gradient equally
-// among ties -- and a splat image has thousands of exact zeros); also clears the accumulators of the other kernels
-__global__ __launch_bounds__(1024) void ssim_minmax_kernel(SsimArgs A)
+// among ties -- and a splat image has thousands of exact zeros); also clears the accumulators of the other kernels.
+// One block; its time is the latency of its load chain.  Images of up to 64 Ki pixels (the notebook's 256 x 256) are read
+// ONCE: sixteen independent 16-byte loads per thread, all in flight together, and the values stay in registers for the
+// tie count (round 3 first walked the image twice, four dwords per trip: 12 us for 65 536 pixels; a launch costs ~5).
+constexpr int kMmThreads = 1024, kMmVec = 16; // 1024 threads x 16 float4
+__global__ __launch_bounds__(kMmThreads) void ssim_minmax_kernel(SsimArgs A)
 {
     __shared__ float s_lo[16], s_hi[16];
     __shared__ int s_cl[16], s_ch[16];
     __shared__ float b_lo, b_hi;
     const long n = (long)A.H * A.W;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool in_regs = n <= (long)kMmThreads * kMmVec * 4 && (reinterpret_cast<size_t>(A.img) & 15) == 0;
+    float4 keep[kMmVec];
     float lo = __builtin_inff(), hi = -__builtin_inff();
     bool nan = false;
-    // four independent loads per trip: one block walks the whole image, so its time is the latency of its load chain
     const long n4 = n & ~3L;
-    for (long i = 4L * threadIdx.x; i < n4; i += 4096) {
-        const float v0 = A.img[i], v1 = A.img[i + 1], v2 = A.img[i + 2], v3 = A.img[i + 3];
-        nan |= (v0 != v0) | (v1 != v1) | (v2 != v2) | (v3 != v3);
-        lo = fminf(fminf(lo, v0), fminf(fminf(v1, v2), v3));
-        hi = fmaxf(fmaxf(hi, v0), fmaxf(fmaxf(v1, v2), v3));
-    }
-    for (long i = n4 + threadIdx.x; i < n; i += 1024) {
-        const float v = A.img[i];
+    auto see = [&](float v) {
         nan |= v != v;
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
+    };
+    if (in_regs) {
+        const float4 *img4 = reinterpret_cast<const float4 *>(A.img);
+#pragma unroll
+        for (int k = 0; k < kMmVec; ++k) {
+            const long i = 4L * (threadIdx.x + (long)k * kMmThreads);
+            // outside the image: a copy of pixel 0..3 region is not available in general -- use NaN-free neutral values
+            keep[k] = (i < n4) ? img4[i >> 2] : make_float4(__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff());
+        }
+#pragma unroll
+        for (int k = 0; k < kMmVec; ++k) {
+            const long i = 4L * (threadIdx.x + (long)k * kMmThreads);
+            if (i < n4) { see(keep[k].x); see(keep[k].y); see(keep[k].z); see(keep[k].w); }
+        }
+    } else {
+        for (long i = 4L * threadIdx.x; i < n4; i += 4L * kMmThreads) {
+            see(A.img[i]); see(A.img[i + 1]); see(A.img[i + 2]); see(A.img[i + 3]);
+        }
     }
+    for (long i = n4 + threadIdx.x; i < n; i += kMmThreads) see(A.img[i]);
     if (nan) lo = hi = __builtin_nanf(""); // torch.min / max propagate NaN
     for (int o = 32; o > 0; o >>= 1) {
         const float l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
@@ -72,16 +89,22 @@ __global__ __launch_bounds__(1024) void ssim_minmax_kernel(SsimArgs A)
     __syncthreads();
     lo = b_lo; hi = b_hi;
     int cl = 0, ch = 0;
-    for (long i = 4L * threadIdx.x; i < n4; i += 4096) {
-        const float v0 = A.img[i], v1 = A.img[i + 1], v2 = A.img[i + 2], v3 = A.img[i + 3];
-        cl += (v0 == lo) + (v1 == lo) + (v2 == lo) + (v3 == lo);
-        ch += (v0 == hi) + (v1 == hi) + (v2 == hi) + (v3 == hi);
-    }
-    for (long i = n4 + threadIdx.x; i < n; i += 1024) {
-        const float v = A.img[i];
+    auto count = [&](float v) {
         cl += v == lo;
         ch += v == hi;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kMmVec; ++k) {
+            const long i = 4L * (threadIdx.x + (long)k * kMmThreads);
+            if (i < n4) { count(keep[k].x); count(keep[k].y); count(keep[k].z); count(keep[k].w); }
+        }
+    } else {
+        for (long i = 4L * threadIdx.x; i < n4; i += 4L * kMmThreads) {
+            count(A.img[i]); count(A.img[i + 1]); count(A.img[i + 2]); count(A.img[i + 3]);
+        }
     }
+    for (long i = n4 + threadIdx.x; i < n; i += kMmThreads) count(A.img[i]);
     for (int o = 32; o > 0; o >>= 1) { cl += __shfl_xor(cl, o); ch += __shfl_xor(ch, o); }
     if (lane == 0) { s_cl[wv] = cl; s_ch[wv] = ch; }
     __syncthreads();
@@ -281,7 +304,7 @@ int diffus_ssim_loss_fwd(const float *img, const float *ref, int H, int W, int n
     if (!loss) return DIFFUS_EINVAL;
     A.loss = loss;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(1024), 0, st, A); // (also clears the accumulators: needed without normalisation too)
+    hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(kMmThreads), 0, st, A); // (also clears the accumulators: needed without normalisation too)
     dim3 grid((A.Wm + kSsimTile - 1) / kSsimTile, (A.Hm + kSsimTile - 1) / kSsimTile);
     hipLaunchKernelGGL(ssim_map_kernel<false>, grid, dim3(kSsimTile * kSsimTile), 0, st, A);
     return last_launch();
@@ -299,7 +322,7 @@ int diffus_ssim_loss_bwd(const float *img, const float *ref, int H, int W, int n
     A.reuse_stats = (reuse_stats != 0) && A.normalise;
     hipStream_t st = (hipStream_t)stream;
     // min / max and the tie counts: recomputed, unless the caller vouches that `workspace` still holds the forward's
-    if (A.normalise && !A.reuse_stats) hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(1024), 0, st, A);
+    if (A.normalise && !A.reuse_stats) hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(kMmThreads), 0, st, A);
     dim3 gm((A.Wm + kSsimTile - 1) / kSsimTile, (A.Hm + kSsimTile - 1) / kSsimTile);
     hipLaunchKernelGGL(ssim_map_kernel<true>, gm, dim3(kSsimTile * kSsimTile), 0, st, A);
     dim3 gi((W + kSsimTile - 1) / kSsimTile, (H + kSsimTile - 1) / kSsimTile);

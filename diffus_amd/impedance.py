@@ -23,26 +23,72 @@ def _pack(params) -> torch.Tensor:
     return torch.cat([p.reshape(-1) for p in params])
 
 
+def _uniform_stride(t: torch.Tensor):
+    """Elements between consecutive entries of `t` read in row-major order, if that is ONE number (a contiguous tensor: 1;
+    `volume[:, :, k]` of a contiguous volume: volume.shape[2]); else None."""
+    if t.numel() <= 1:
+        return 1
+    step = None
+    expect = None
+    for size, stride in zip(reversed(t.shape), reversed(t.stride())):
+        if size == 1:
+            continue
+        if step is None:
+            step, expect = stride, stride * size
+        else:
+            if stride != expect:
+                return None
+            expect = stride * size
+    return step if step and step > 0 else None
+
+
+def _flat_view(params, dev):
+    """The six parameter tensors as ONE (1153,) float32 tensor WITHOUT a copy, when they already lie back to back in one
+    storage on `dev` (ImpedanceEstimator keeps them that way: `_flatten`); else None.  The kernels read one packed
+    array; `torch.cat` per forward was a launch of its own in every training iteration."""
+    first = params[0]
+    if first.device != dev:
+        return None
+    base, end = first.untyped_storage().data_ptr(), first.data_ptr()
+    for t in params:
+        if (t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() or t.untyped_storage().data_ptr() != base
+                or t.data_ptr() != end):
+            return None
+        end += 4 * t.numel()
+    return first.as_strided((sum(t.numel() for t in params),), (1,), first.storage_offset())
+
+
 class _MlpFn(torch.autograd.Function):
     """y = out_scale * mlp((x - shift) / div) elementwise over x (any shape); mask (uint8, same shape) optional."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, mask, shift, div, out_scale, fill):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, mask, shift, div, out_scale, fill, out=None):
         lib = _lib.load()
         dev = _device_for(x)
+        ystride = 1
+        if out is not None:
+            ystride = _uniform_stride(out)
+            if (out.device != dev or out.dtype != torch.float32 or out.numel() != x.numel() or ystride is None):
+                raise ValueError("out= must be a float32 tensor on the HIP device with x.numel() elements a uniform stride "
+                                 "apart (contiguous, or one slice of a contiguous volume)")
         with _Scope(dev):
             xd = x.detach().to(device=dev, dtype=torch.float32).contiguous()
-            params = _pack([t.detach().to(device=dev, dtype=torch.float32) for t in (w1, b1, w2, b2, w3, b3)])
+            ps = [t.detach() for t in (w1, b1, w2, b2, w3, b3)]
+            params = _flat_view(ps, dev)
+            if params is None:
+                params = _pack([t.to(device=dev, dtype=torch.float32) for t in ps])
             if params.numel() != 1153:
                 raise ValueError("the fused MLP is 1 -> 32 -> 32 -> 1 (reference src/impedance.py:10-14)")
             md = mask.to(device=dev, dtype=torch.uint8).contiguous() if mask is not None else None
-            y = torch.empty_like(xd)
+            y = torch.empty_like(xd) if out is None else out.detach()
             if xd.numel():
                 _lib.check(lib.diffus_mlp_fwd(_ptr(xd), _ptr(md), xd.numel(), _ptr(params), shift, div, out_scale, fill,
-                                              _ptr(y), _stream(dev)), "diffus_mlp_fwd")
+                                              _ptr(y), ystride, _stream(dev)), "diffus_mlp_fwd")
         ctx.save_for_backward(xd, params, md)
         ctx.consts = (shift, div, out_scale, x.device, x.dtype, [t.shape for t in (w1, b1, w2, b2, w3, b3)],
                       [t.device for t in (w1, b1, w2, b2, w3, b3)])
+        if out is not None:
+            return y                    # a fresh tensor object on out's memory (detach(): no view bookkeeping)
         return y.to(x.device)
 
     @staticmethod
@@ -53,13 +99,17 @@ class _MlpFn(torch.autograd.Function):
         dev = xd.device
         need_x = ctx.needs_input_grad[0]
         with _Scope(dev):
-            g = gy.detach().to(device=dev, dtype=torch.float32).contiguous()
-            gp = torch.zeros(1153, dtype=torch.float32, device=dev)
+            g = gy.detach().to(device=dev, dtype=torch.float32)
+            gstride = _uniform_stride(g)          # e.g. the slice of d/dvolume the renderer hands back: read in place
+            if gstride is None:
+                g, gstride = g.contiguous(), 1
+            # (mlp_reduce_kernel stores every one of the 1153 sums: nothing to zero first unless there is no sample at all)
+            gp = torch.empty(1153, dtype=torch.float32, device=dev) if xd.numel() else torch.zeros(1153, dtype=torch.float32, device=dev)
             gx = torch.empty_like(xd) if need_x else None
             if xd.numel():
                 ws = _workspace(dev, lib.diffus_mlp_workspace_bytes())
                 _lib.check(lib.diffus_mlp_bwd(_ptr(xd), _ptr(md), xd.numel(), _ptr(params), shift, div, out_scale, _ptr(g),
-                                              _ptr(gp), _ptr(gx), _ptr(ws), ws.numel(), _stream(dev)), "diffus_mlp_bwd")
+                                              gstride, _ptr(gp), _ptr(gx), _ptr(ws), ws.numel(), _stream(dev)), "diffus_mlp_bwd")
             elif need_x:
                 gx.zero_()
         outs, o = [], 0
@@ -69,7 +119,7 @@ class _MlpFn(torch.autograd.Function):
                 nel *= s
             outs.append(gp[o:o + nel].reshape(shp).to(d) if need else None)
             o += nel
-        return (gx.to(device=xdev, dtype=xdt) if need_x else None, *outs, None, None, None, None, None)
+        return (gx.to(device=xdev, dtype=xdt) if need_x else None, *outs, None, None, None, None, None, None)
 
 
 class ImpedanceEstimator(nn.Module):
@@ -89,10 +139,29 @@ class ImpedanceEstimator(nn.Module):
         m = self.model
         return m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias
 
-    def forward(self, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    def _flatten(self):
+        """Re-seat the six parameters as views of one flat buffer (same Parameter objects, names, shapes and values: state
+        dicts and optimizers are unaffected), so that the kernels can read them in place.  `Module.to()` gives every
+        parameter a storage of its own again; the next forward outside a stream capture re-flattens."""
+        ps = self._params()
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in ps])
+            o = 0
+            for p in ps:
+                p.data = flat[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+
+    def forward(self, x: torch.Tensor, scale: float = 1.0, out: torch.Tensor = None) -> torch.Tensor:
         """x (..., 1) (or any shape: the MLP is applied to every element) -> same shape.  `scale` multiplies the output
-        inside the kernel (the notebooks' `model(x) * 1e6` without the extra elementwise pass, forward and backward)."""
-        return _MlpFn.apply(x, *self._params(), None, 0.0, 1.0, float(scale), 0.0)
+        inside the kernel (the notebooks' `model(x) * 1e6` without the extra elementwise pass, forward and backward).
+        `out`: write the result there and return it -- a float32 device tensor of x.numel() elements a uniform stride
+        apart, e.g. `CapturedStep.slice_view(2, k)`: the slice of the volume the prediction is for (the notebook's
+        `Z_vol[:, :, k] = Z_slice` without the copy)."""
+        ps = self._params()
+        if (ps[0].is_cuda and ps[0].dtype == torch.float32 and _flat_view([p.detach() for p in ps], ps[0].device) is None
+                and not torch.cuda.is_current_stream_capturing()):
+            self._flatten()
+        return _MlpFn.apply(x, *ps, None, 0.0, 1.0, float(scale), 0.0, out)
 
     @classmethod
     def train_model(cls, X: torch.Tensor, y: torch.Tensor, input_dim: int = 1, lr: float = 1e-3,
@@ -124,7 +193,7 @@ class ImpedanceEstimator(nn.Module):
             div = (torch.tensor(std, dtype=torch.float32) + 1e-8).item()
             _lib.check(lib.diffus_mlp_fwd(_ptr(v), _ptr(mask.view(torch.uint8)), v.numel(), _ptr(params),
                                           torch.tensor(mean, dtype=torch.float32).item(), div, 1e6, AIR_IMPEDANCE,
-                                          _ptr(out), _stream(dev)), "diffus_mlp_fwd")
+                                          _ptr(out), 1, _stream(dev)), "diffus_mlp_fwd")
         return out.to(device=volume.device, dtype=volume.dtype if volume.dtype.is_floating_point else torch.float32)
 
 

@@ -110,7 +110,8 @@ def differentiable_splat(x, y, z, intensities, H=256, W=256, sigma=2.0):
     cdev = _device_for(intensities)
     sel, _ = select_axes(x, y, z, cdev)              # on the device: no .item() round trips (reference :704)
     cols = intensities.shape[-1] if intensities.dim() == 2 else 0
-    out = splat_frames(sel[0:1], sel[1:2], intensities.reshape(1, -1), H, W, sigma, cols)[0]
+    # (squeeze, not [0]: indexing's backward is a zero-filled (1, W, H) tensor plus a copy into it -- two launches)
+    out = splat_frames(sel[0:1], sel[1:2], intensities.reshape(1, -1), H, W, sigma, cols).squeeze(0)
     return out if out.device == dev else out.to(dev)
 
 

@@ -45,19 +45,23 @@ class Loop:
         self.one_pass = one_pass
         self.step.set_target(self.target, 1.0 / self.target.numel())
         self.loss = torch.zeros((), device=dev)
+        self.one = torch.ones((), device=dev)
         self.graph, self.repeat = None, 1
 
     def iteration(self):
-        z_slice = self.model(self.mri, scale=1e6)
+        # the prediction lands in its slice of the step's volume (no copy launch), its gradient is read from there
+        z_slice = self.model(self.mri, scale=1e6, out=self.step.slice_view(2, self.k))
         if self.one_pass:
             loss = self.step.mse_loss(slice_values=z_slice, slice_dim=2, slice_index=self.k)
         else:
             frame = self.step.render(self.step.volume_with_slice(z_slice, 2, self.k))
             loss = torch.nn.functional.mse_loss(frame, self.target)
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        # a resident 1.0 as the upstream gradient: `backward()` alone fills a fresh one every iteration (a launch), and the
+        # step's own unit lets mse_loss hand its gradients over unscaled (no multiply launches)
+        loss.backward(self.step.unit if self.one_pass else self.one)
         self.opt.step()
-        self.loss.copy_(loss.detach())
+        self.loss = loss.detach()           # no copy: inside a captured graph this tensor is rewritten by every replay
 
     def capture(self, repeat=1):
         """One hipGraph of `repeat` whole iterations (two graph LAUNCHES are ~8.6 us apart on this stack, kernels inside one

@@ -55,6 +55,7 @@ class SsimLoop:
                                     alias_grads=True)
         self.real = minmax01(self.splat_of(self.frame_of_truth())).detach()   # the "real" ultrasound image, normalised
         self.loss = torch.zeros((), device=dev)
+        self.one = torch.ones((), device=dev)
         self.graph, self.repeat = None, 1
 
     def frame_of_truth(self):
@@ -74,11 +75,12 @@ class SsimLoop:
         return 1.0 - ssim(minmax01(img)[None, None], self.real[None, None], data_range=1.0, window=self.window)
 
     def iteration(self):
-        loss = self.loss_of(self.model(self.mri, scale=1e6))
+        # the prediction lands in its slice of the step's volume (no copy launch), its gradient is read from there
+        loss = self.loss_of(self.model(self.mri, scale=1e6, out=self.step.slice_view(2, self.k)))
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(self.one)             # a resident 1.0: `backward()` alone fills a fresh one every iteration (a launch)
         self.opt.step()
-        self.loss.copy_(loss.detach())
+        self.loss = loss.detach()           # no copy: inside a captured graph this tensor is rewritten by every replay
 
     def capture(self, repeat=1):
         """One hipGraph of `repeat` whole iterations (two graph LAUNCHES are ~8.6 us apart on this stack, kernels inside one

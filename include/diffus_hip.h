@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DIFFUS_ABI_VERSION 3 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points */
+#define DIFFUS_ABI_VERSION 4 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd */
 
 /* error codes */
 #define DIFFUS_OK            0
@@ -399,22 +399,25 @@ int diffus_loss_sumsq(const float *frame, int P, long n, float *loss, float *gfr
 #define DIFFUS_MLP_PARAMS 1153
 
 /*
- * y[i] = (mask == NULL || mask[i]) ? out_scale * mlp((x[i] - in_shift) / in_div) : fill        i < n
+ * y[i * y_stride] = (mask == NULL || mask[i]) ? out_scale * mlp((x[i] - in_shift) / in_div) : fill        i < n
+ * (y_stride in elements, 1 = contiguous: a stride lets the result land where it is used -- e.g. one slice of the
+ * volume, `Z_vol[:, :, k] = model(x) * 1e6` of the reference's training notebook, cell 16 -- without a copy launch).
  * Replaces ImpedanceEstimator.forward (:16-17; in_shift 0, in_div 1, out_scale 1, mask NULL) and, with the
  * z-score constants, the 1e6 scale and fill = 400, the body of compute_impedance_volume (:45-53) in one pass;
  * the hidden layer runs on the f32 matrix cores, activations stay in registers.
  */
 int diffus_mlp_fwd(const float *x, const unsigned char *mask, size_t n, const float *params,
-                   float in_shift, float in_div, float out_scale, float fill, float *y,
+                   float in_shift, float in_div, float out_scale, float fill, float *y, size_t y_stride,
                    diffus_stream_t stream);
 
 /*
- * Backward of the above for upstream gy (n floats): gparams (1153 floats, overwritten) = d/dparams of
- * sum(y * gy); gx (nullable, n floats) = d/dx.  Deterministic (fixed-order reductions).
+ * Backward of the above for upstream gy (n floats, gy_stride elements apart: the matching slice of d/dvolume is read
+ * in place): gparams (1153 floats, overwritten) = d/dparams of sum(y * gy); gx (nullable, n floats) = d/dx.
+ * Deterministic (fixed-order reductions).
  */
 size_t diffus_mlp_workspace_bytes(void);
 int diffus_mlp_bwd(const float *x, const unsigned char *mask, size_t n, const float *params,
-                   float in_shift, float in_div, float out_scale, const float *gy,
+                   float in_shift, float in_div, float out_scale, const float *gy, size_t gy_stride,
                    float *gparams, float *gx, void *workspace, size_t workspace_bytes,
                    diffus_stream_t stream);
 

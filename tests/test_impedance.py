@@ -52,7 +52,7 @@ def test_mlp_sizes_masks_and_affine_vs_oracle(da, n):
     pd = torch.from_numpy(params).cuda()
     y = torch.full((n,), -7.0, device="cuda")
     rc = lib.diffus_mlp_fwd(xd.data_ptr(), md.data_ptr(), n, pd.data_ptr(), float(shift), float(div), scale, fill,
-                            y.data_ptr(), None)
+                            y.data_ptr(), 1, None)
     assert rc == 0
     ref = np.where(mask, oi.mlp_forward((x - shift) / div, params, np.float64) * scale, fill)
     assert maxnorm_rel(y.cpu().numpy(), ref) < 5e-6
@@ -66,7 +66,7 @@ def test_mlp_sizes_masks_and_affine_vs_oracle(da, n):
         gp = torch.full((1153,), 3.0, device="cuda")
         gx = torch.full((n,), 3.0, device="cuda")
         rc = lib.diffus_mlp_bwd(xd.data_ptr(), md.data_ptr(), n, pd.data_ptr(), float(shift), float(div), scale,
-                                gyd.data_ptr(), gp.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(), None)
+                                gyd.data_ptr(), 1, gp.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(), None)
         assert rc == 0
         outs.append((gp.cpu().numpy(), gx.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
@@ -135,3 +135,36 @@ def test_train_model_and_render_through_the_estimator(da):
     (f ** 2).sum().backward()
     gs = [p.grad for p in m.parameters()]
     assert all(g_ is not None and torch.isfinite(g_).all() for g_ in gs) and any(float(g_.abs().max()) > 0 for g_ in gs)
+
+
+def test_mlp_writes_into_a_slice_and_reads_a_strided_gradient(da):
+    """`model(x, scale, out=slice of a volume)`: the prediction lands in place (y_stride = the volume's last dimension), the
+    upstream gradient -- the same slice of d/dvolume, a strided view -- is read in place (gy_stride); both against the
+    contiguous path, bit for bit.  The six parameters become views of one flat buffer (no torch.cat per forward), values,
+    names and state_dict unchanged."""
+    torch.manual_seed(3)
+    net = da.ImpedanceEstimator().cuda()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(24, 40, device="cuda")
+    vol = torch.full((24, 40, 7), -1.0, device="cuda")
+    gvol = torch.randn(24, 40, 7, device="cuda")
+    y0 = net(x, scale=1e3)                                       # contiguous path (also flattens the parameters)
+    ps = net._params()
+    assert all(p.untyped_storage().data_ptr() == ps[0].untyped_storage().data_ptr() for p in ps)
+    assert all(torch.equal(before[k], v) for k, v in net.state_dict().items()) and list(before) == list(net.state_dict())
+    (y0 * gvol[:, :, 3].contiguous()).sum().backward()
+    g0 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    y1 = net(x, scale=1e3, out=vol[:, :, 3])
+    assert y1.data_ptr() == vol[:, :, 3].data_ptr() and y1.stride() == vol[:, :, 3].stride()
+    assert torch.equal(vol[:, :, 3], y0) and torch.all(vol[:, :, 2] == -1) and torch.all(vol[:, :, 4] == -1)
+    (y1 * gvol[:, :, 3]).sum().backward()                        # mul's backward hands a strided gradient: read in place
+    for a, b in zip(g0, [p.grad for p in net.parameters()]):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        net(x, out=torch.empty(24, 41, device="cuda"))
+    with pytest.raises(ValueError):
+        net(x, out=vol[:, 1, :40].t())                           # not a uniform stride over 24 x 40 elements
+    # a Module.to() round trip gives every parameter its own storage again; the next forward re-flattens, same values
+    net = net.cpu().cuda()
+    assert torch.equal(net(x, scale=1e3), y0)

@@ -91,6 +91,13 @@ def test_mse_loss_node_matches_the_drop_in_autograd_path():
     torch.nn.functional.mse_loss(f2, target).backward()
     assert float(sl2.grad.abs().max()) > 0
     assert float((sl.grad - sl2.grad).abs().max()) <= 1e-4 * float(sl2.grad.abs().max())
+    # loss.backward(step.unit): the step's resident 1.0 as the upstream gradient hands the same gradients over unscaled
+    # (no multiply launches); and a slice written in place through slice_view() is not copied again
+    sl3 = sl.detach().clone().requires_grad_(True)
+    step.mse_loss(slice_values=sl3, slice_dim=2, slice_index=k).backward(step.unit)
+    assert torch.equal(sl3.grad, sl.grad)
+    view = step.slice_view(2, k)
+    assert view.data_ptr() == step.vol.select(2, k).data_ptr() and not view.requires_grad
     with pytest.raises(RuntimeError):                   # a stale loss cannot be back-propagated
         la = step.mse_loss(slice_values=sl, slice_dim=2, slice_index=k)
         step.mse_loss(slice_values=sl, slice_dim=2, slice_index=k)

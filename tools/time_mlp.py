@@ -34,11 +34,11 @@ def timeit(fn, reps=10):
 
 def fwd(msk=None):
     lib.diffus_mlp_fwd(x.data_ptr(), msk.data_ptr() if msk is not None else None, N, params.data_ptr(), 0.0, 1.0, 1.0, 400.0,
-                       y.data_ptr(), None)
+                       y.data_ptr(), 1, None)
 
 
 def bwd(want_gx=True):
-    lib.diffus_mlp_bwd(x.data_ptr(), None, N, params.data_ptr(), 0.0, 1.0, 1.0, gy.data_ptr(), gp.data_ptr(),
+    lib.diffus_mlp_bwd(x.data_ptr(), None, N, params.data_ptr(), 0.0, 1.0, 1.0, gy.data_ptr(), 1, gp.data_ptr(),
                        gx.data_ptr() if want_gx else None, ws.data_ptr(), ws.numel(), None)
 
 
