@@ -95,7 +95,8 @@ def test_mse_loss_node_matches_the_drop_in_autograd_path():
     # (no multiply launches); and a slice written in place through slice_view() is not copied again
     sl3 = sl.detach().clone().requires_grad_(True)
     step.mse_loss(slice_values=sl3, slice_dim=2, slice_index=k).backward(step.unit)
-    assert torch.equal(sl3.grad, sl.grad)
+    # (two executions of the step: the volume gradient is summed by float atomics, equal up to their order)
+    assert float((sl3.grad - sl.grad).abs().max()) <= 1e-5 * float(sl.grad.abs().max())
     view = step.slice_view(2, k)
     assert view.data_ptr() == step.vol.select(2, k).data_ptr() and not view.requires_grad
     with pytest.raises(RuntimeError):                   # a stale loss cannot be back-propagated
