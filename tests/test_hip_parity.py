@@ -172,6 +172,28 @@ def test_cpu_tensors_are_accepted_like_the_reference(da, vols):
     assert maxnorm_rel(f.numpy(), g[f"{t}_frame"]) < 1e-4
 
 
+def test_host_poses_through_the_staging_ring(da, oracle, vols):
+    """Host-resident poses go up in one packed asynchronous copy through a ring of pinned staging slots.  Same pose again:
+    same frame, bit for bit; a pose that differs in one component: its own frame (against the oracle); back to the first:
+    the first; the caller's tensor modified in place: seen."""
+    n, S = 64, 90
+    vol = cuda(vols[n])
+    src, dirs = pose_ring(n, 4, 12)
+    s0, d0 = torch.from_numpy(src[0].astype(np.float64)), torch.from_numpy(dirs[0])
+    s1 = s0.clone(); s1[1] += 0.75
+    R = da.UltrasoundRenderer(S, 1e-3)
+    fa = R.plot_beam_frame(vol, s0, d0)[3].clone()
+    fb = R.plot_beam_frame(vol, s0, d0)[3].clone()
+    fc = R.plot_beam_frame(vol, s1, d0)[3].clone()
+    fd = R.plot_beam_frame(vol, s0, d0)[3].clone()
+    assert torch.equal(fa, fb) and torch.equal(fa, fd) and not torch.equal(fa, fc)
+    for f, s in ((fa, s0), (fc, s1)):
+        fo = oracle.plot_beam_frame(vols[n], s.numpy(), dirs[0], S, 1e-3, 0)[3]
+        assert maxnorm_rel(f.cpu().numpy(), fo) < 2e-5
+    s0[1] += 0.75                                      # the caller's tensor modified in place
+    assert torch.equal(R.plot_beam_frame(vol, s0, d0)[3], fc)
+
+
 def test_config1_golden(da, vol256):
     g = load_golden("g6_config1")
     R = da.UltrasoundRenderer(256, 1e-4)

@@ -14,6 +14,7 @@ def frame():
 for _ in range(10): frame()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(300): frame()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+for _ in range(N): frame()
 torch.cuda.synchronize()
-print("wall per frame: %.1f us" % ((time.perf_counter() - t0) / 300 * 1e6))
+print("wall per frame: %.1f us" % ((time.perf_counter() - t0) / N * 1e6))
