@@ -23,7 +23,7 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
            "diffus_echo_bwd_workspace_bytes", "diffus_echo_traces_bwd", "diffus_splat_axes", "diffus_rotate_around_apex",
            "diffus_ssim_workspace_bytes", "diffus_ssim_loss_fwd", "diffus_ssim_loss_bwd")
 
-ABI_VERSION = 4          # include/diffus_hip.h DIFFUS_ABI_VERSION
+ABI_VERSION = 5          # include/diffus_hip.h DIFFUS_ABI_VERSION
 DIFFUS_F32, DIFFUS_F64, DIFFUS_I64 = 0, 1, 2
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
@@ -105,9 +105,9 @@ def load():
     lib.diffus_splat_axes.restype = i
     lib.diffus_splat_axes.argtypes = [vp, i, vp, i, vp, i, C.c_long, vp, vp, vp, vp]
     lib.diffus_splat_fwd.restype = i
-    lib.diffus_splat_fwd.argtypes = [vp, vp, vp, i, C.c_long, i, i, i, f, vp, vp, sz, vp]
+    lib.diffus_splat_fwd.argtypes = [vp, vp, vp, i, C.c_long, i, i, i, f, vp, vp, vp, sz, vp]
     lib.diffus_splat_bwd.restype = i
-    lib.diffus_splat_bwd.argtypes = [vp, vp, i, C.c_long, i, i, f, vp, vp, vp, sz, vp]
+    lib.diffus_splat_bwd.argtypes = [vp, vp, i, C.c_long, i, i, f, vp, vp, vp, vp, sz, vp]
     d = C.c_double
     lib.diffus_artifacts_workspace_bytes.restype = sz
     lib.diffus_artifacts_workspace_bytes.argtypes = [i, i, i]

@@ -260,6 +260,122 @@ int launch_blur(const float *in, float *out, int H, int W, int half, float sigma
     return last_launch();
 }
 
+// The tail of the splat in ONE launch per direction (half-widths up to 8): a graph node costs ~4.8 us on this stack
+// whatever it does, and compose -> blur -> divide were three of them (mark -> blur -> divide in the backward).
+//   FWD: image and weight planes straight from the winner raster (val[winner] / 1 where a sample landed), both blurred in
+//        LDS, out[p, x, y] = bimg / (bw + 1e-8), stored transposed.
+//   BWD: the weight plane from the winner raster the forward kept, blurred, q[p, y, x] = gout[p, x, y] / (bw + 1e-8).
+// Same operations in the same order per output as splat_compose / blur2d_tiled / splat_divide: bit-identical.
+template <int HALF, bool BWD>
+__global__ __launch_bounds__(kBlock) void splat_fused_kernel(const int *__restrict__ winner, const float *__restrict__ val, long n,
+                                                             const float *__restrict__ gout, float *__restrict__ out, int H,
+                                                             int W, float sigma)
+{
+    constexpr int SIZE = 2 * HALF + 1, EXT = kSplatTile + 2 * HALF, NP = BWD ? 1 : 2;
+    __shared__ float kw[SIZE];
+    __shared__ float src[NP][EXT][EXT + 1];
+    __shared__ float mid[NP][EXT][kSplatTile + 1];
+    __shared__ float t[kSplatTile][kSplatTile + 1];
+    const long pz = blockIdx.z, hw = (long)H * W;
+    const int x0 = blockIdx.x * kSplatTile, y0 = blockIdx.y * kSplatTile;
+    const int tid = threadIdx.x;
+    if (tid < SIZE) {
+        float c = (float)(tid - HALF) / sigma;
+        kw[tid] = expf(-0.5f * c * c);
+    }
+    for (int e = tid; e < EXT * EXT; e += kBlock) {
+        int r = e / EXT, c = e - r * EXT;
+        int y = y0 + r - HALF, x = x0 + c - HALF;
+        const int wn = (y >= 0 && y < H && x >= 0 && x < W) ? winner[pz * hw + (long)y * W + x] : -1;
+        if (BWD) {
+            src[0][r][c] = wn >= 0 ? 1.f : 0.f;
+        } else {
+            src[0][r][c] = wn >= 0 ? (val ? val[pz * n + wn] : 0.f) : 0.f;
+            src[NP - 1][r][c] = wn >= 0 ? 1.f : 0.f;
+        }
+    }
+    if (BWD) { // gout arrives transposed (p, x, y): through the tile, both sides coalesced
+        for (int e = tid; e < kSplatTile * kSplatTile; e += kBlock) {
+            int c = e / kSplatTile, r = e - c * kSplatTile, y = y0 + r, x = x0 + c;
+            t[r][c] = (y < H && x < W) ? gout[pz * hw + (long)x * H + y] : 0.f;
+        }
+    }
+    __syncthreads();
+    float k[SIZE], ksum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SIZE; ++i) ksum += kw[i];
+#pragma unroll
+    for (int i = 0; i < SIZE; ++i) k[i] = kw[i] / ksum;
+    for (int item = tid; item < NP * EXT * (kSplatTile / 8); item += kBlock) { // x pass: EXT rows x 4 groups of 8 columns, per plane
+        const int pl = item / (EXT * (kSplatTile / 8)), it = item - pl * (EXT * (kSplatTile / 8));
+        const int r = it / (kSplatTile / 8), c0 = (it - r * (kSplatTile / 8)) * 8;
+        float win[8 + 2 * HALF];
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * HALF; ++i) win[i] = src[pl][r][c0 + i];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < SIZE; ++q) a = __builtin_fmaf(k[q], win[o + q], a);
+            mid[pl][r][c0 + o] = a;
+        }
+    }
+    __syncthreads();
+    {   // y pass: 32 columns x 8 groups of 4 rows
+        const int c = tid & 31, r0 = (tid >> 5) * 4;
+        float res[NP][4];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            float win[4 + 2 * HALF];
+#pragma unroll
+            for (int i = 0; i < 4 + 2 * HALF; ++i) win[i] = mid[pl][r0 + i][c];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < SIZE; ++q) a = __builtin_fmaf(k[q], win[o + q], a);
+                res[pl][o] = a;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int y = y0 + r0 + o, x = x0 + c;
+            if (BWD) {
+                if (y < H && x < W) out[pz * hw + (long)y * W + x] = t[r0 + o][c] / (res[0][o] + 1e-8f);
+            } else {
+                t[r0 + o][c] = res[0][o] / (res[NP - 1][o] + 1e-8f);
+            }
+        }
+    }
+    if (!BWD) {
+        __syncthreads();
+        for (int e = tid; e < kSplatTile * kSplatTile; e += kBlock) {
+            int c = e / kSplatTile, r = e - c * kSplatTile, y = y0 + r, x = x0 + c;
+            if (y < H && x < W) out[pz * hw + (long)x * H + y] = t[r][c];
+        }
+    }
+    static_assert(kBlock == 256 && kSplatTile == 32, "the y pass maps 256 threads to 32 columns x 8 row groups");
+}
+
+template <bool BWD>
+int launch_splat_fused(const int *winner, const float *val, long n, const float *gout, float *out, int H, int W, int half,
+                       float sigma, int P, hipStream_t st)
+{
+    dim3 tiles((W + kSplatTile - 1) / kSplatTile, (H + kSplatTile - 1) / kSplatTile, P);
+#define DIFFUS_FUSED_CASE(HF)                                                                                                   \
+    case HF:                                                                                                                    \
+        hipLaunchKernelGGL((splat_fused_kernel<HF, BWD>), tiles, dim3(kBlock), 0, st, winner, val, n, gout, out, H, W, sigma);  \
+        break;
+    switch (half) {
+        DIFFUS_FUSED_CASE(1) DIFFUS_FUSED_CASE(2) DIFFUS_FUSED_CASE(3) DIFFUS_FUSED_CASE(4)
+        DIFFUS_FUSED_CASE(5) DIFFUS_FUSED_CASE(6) DIFFUS_FUSED_CASE(7) DIFFUS_FUSED_CASE(8)
+    default: return DIFFUS_EUNSUPPORTED;
+    }
+#undef DIFFUS_FUSED_CASE
+    return last_launch();
+}
+constexpr int kSplatFusedMaxHalf = 8;
+
 // forward: out[p, x, y] = bimg[y, x] / (bw[y, x] + 1e-8)          (the .T of reference :737)
 // backward: q[p, y, x]  = gout[p, x, y] / (bw[y, x] + 1e-8)
 template <bool BWD>
@@ -556,7 +672,8 @@ int diffus_splat_axes(const void *x, int x_dtype, const void *y, int y_dtype, co
 }
 
 int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, long n, int cols, int H, int W,
-                     float sigma, float *out, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+                     float sigma, float *out, int *winner_keep, void *workspace, size_t workspace_bytes,
+                     diffus_stream_t stream)
 {
     if (!c0 || !c1 || !val || !out || P <= 0 || n <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f)) return DIFFUS_EINVAL;
     if (cols < 0 || (cols > 0 && n % cols != 0)) return DIFFUS_EINVAL;
@@ -566,7 +683,7 @@ int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, 
     if (!workspace || workspace_bytes < diffus_splat_workspace_bytes(P, H, W)) return DIFFUS_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const long hw = (long)H * W;
-    int *winner = (int *)workspace;
+    int *winner = winner_keep ? winner_keep : (int *)workspace; // kept for the backward when the caller gives it a home
     float *planes = (float *)((char *)workspace + align256(sizeof(int) * (size_t)P * hw));
     float *blurred = (float *)((char *)planes + align256(sizeof(float) * (size_t)P * 2 * hw));
     if (hipMemsetAsync(winner, 0xff, sizeof(int) * (size_t)P * hw, st) != hipSuccess) return DIFFUS_ELAUNCH;
@@ -579,6 +696,8 @@ int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, 
         unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 4096) nb = 4096;
         hipLaunchKernelGGL(splat_winner_kernel, dim3(nb, P), dim3(kBlock), 0, st, c0, c1, n, H, W, winner);
     }
+    if (half <= kSplatFusedMaxHalf) // compose + both blurs + divide in one launch
+        return launch_splat_fused<false>(winner, val, n, nullptr, out, H, W, half, sigma, P, st);
     unsigned pb = (unsigned)((hw + kBlock - 1) / kBlock); if (pb > 4096) pb = 4096;
     hipLaunchKernelGGL(splat_compose_kernel, dim3(pb, P), dim3(kBlock), 0, st, winner, val, n, hw, planes);
     if (launch_blur(planes, blurred, H, W, half, sigma, hw, hw, P * 2, st)) return DIFFUS_ELAUNCH;
@@ -588,7 +707,7 @@ int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, 
 }
 
 int diffus_splat_bwd(const float *c0, const float *c1, int P, long n, int H, int W, float sigma, const float *gout,
-                     float *gval, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
+                     float *gval, const int *winner_kept, void *workspace, size_t workspace_bytes, diffus_stream_t stream)
 {
     if (!c0 || !c1 || !gout || !gval || P <= 0 || n <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f)) return DIFFUS_EINVAL;
     if (n > 0x7fffffffL || (long)H * W > 0x3fffffffL) return DIFFUS_EUNSUPPORTED;
@@ -600,10 +719,19 @@ int diffus_splat_bwd(const float *c0, const float *c1, int P, long n, int H, int
     int *winner = (int *)workspace;
     float *planes = (float *)((char *)workspace + align256(sizeof(int) * (size_t)P * hw));
     float *blurred = (float *)((char *)planes + align256(sizeof(float) * (size_t)P * 2 * hw));
-    // recompute the weight plane and its blur (nothing was saved by the forward)
     (void)winner;
-    if (hipMemsetAsync(planes, 0, sizeof(float) * (size_t)P * 2 * hw, st) != hipSuccess) return DIFFUS_ELAUNCH;
     unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 4096) nb = 4096;
+    if (winner_kept && half <= kSplatFusedMaxHalf) {
+        // the forward's winner raster says where samples landed: weight plane, its blur and q = gout^T / (bw + eps) in one
+        // launch; then blur q and gather per sample
+        int rc = launch_splat_fused<true>(winner_kept, nullptr, n, gout, planes, H, W, half, sigma, P, st);
+        if (rc) return rc;
+        if (launch_blur(planes, blurred, H, W, half, sigma, hw, hw, P, st)) return DIFFUS_ELAUNCH;
+        hipLaunchKernelGGL(splat_gather_kernel, dim3(nb, P), dim3(kBlock), 0, st, c0, c1, n, H, W, blurred, gval);
+        return last_launch();
+    }
+    // no raster kept: recompute the weight plane and its blur
+    if (hipMemsetAsync(planes, 0, sizeof(float) * (size_t)P * 2 * hw, st) != hipSuccess) return DIFFUS_ELAUNCH;
     hipLaunchKernelGGL(splat_mark_kernel, dim3(nb, P), dim3(kBlock), 0, st, c0, c1, n, H, W, planes);
     // only the weight planes (planes[:, 1]) carry anything: blur those alone, into blurred[:, 1]
     if (launch_blur(planes + hw, blurred + hw, H, W, half, sigma, 2 * hw, 2 * hw, P, st)) return DIFFUS_ELAUNCH;

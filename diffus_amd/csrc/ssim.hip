@@ -20,7 +20,9 @@ struct SsimArgs {
     float c1, c2;
     int normalise;
     int reuse_stats; // backward: stats[0..3] still hold the forward's min / max / tie counts of this very image
-    float *stats; // [0] lo [1] hi [2] ties of lo [3] ties of hi [4] sum of the SSIM map [5] dL/dlo [6] dL/dhi [7] block counter (as int)
+    float *stats; // [0] lo [1] hi [2] ties of lo [3] ties of hi; as ints: [8..23] arrival counters of the 16 block groups, [24] of the groups
+    float *part;  // (3, nblk) per-block partial sums: SSIM map | dL/dlo | dL/dhi  (nblk = 16 x 16 tiles of the IMAGE)
+    int nblk;
     float *loss;
     const float *gloss; // nullable: upstream gradient of the loss (device scalar)
     float *gmap;        // (3, Hm, Wm): dL/d mu_x, dL/d E[x^2], dL/d E[xy] per map position
@@ -112,9 +114,8 @@ __global__ __launch_bounds__(kMmThreads) void ssim_minmax_kernel(SsimArgs A)
         int tl = 0, th = 0;
         for (int w = 0; w < 16; ++w) { tl += s_cl[w]; th += s_ch[w]; }
         A.stats[0] = lo; A.stats[1] = hi; A.stats[2] = (float)tl; A.stats[3] = (float)th;
-        A.stats[4] = 0.f; A.stats[5] = 0.f; A.stats[6] = 0.f;
-        reinterpret_cast<int *>(A.stats)[7] = 0;
     }
+    if (threadIdx.x >= 8 && threadIdx.x <= 24) reinterpret_cast<int *>(A.stats)[threadIdx.x] = 0; // the arrival counters
 }
 
 __device__ __forceinline__ float ssim_x(const SsimArgs &A, float v, float lo, float den)
@@ -124,15 +125,18 @@ __device__ __forceinline__ float ssim_x(const SsimArgs &A, float v, float lo, fl
 
 // One map position per thread, 16 x 16 positions per block, the (16 + win - 1)^2 patches of x and y in LDS.
 // GRAD = false: sum of the SSIM map (-> loss by the last block).  GRAD = true: the three partial derivatives per position.
-template <bool GRAD>
+// WIN: the window size at compile time (11 = piq's and the notebook's default: the taps then sit in SGPRs and the loops
+// unroll), 0 = read it from the arguments (every weight access is then a scalar load from the argument block).
+template <bool GRAD, int WIN>
 __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_map_kernel(SsimArgs A)
 {
+    const int win = WIN ? WIN : A.win;
     __shared__ float px[kSsimPatch][kSsimPatch + 1], py[kSsimPatch][kSsimPatch + 1];
     __shared__ float rows[5][kSsimPatch][kSsimTile + 1]; // the five row sums of every patch row at the tile's 16 columns
     __shared__ float s_part[4];
     const int tx = threadIdx.x % kSsimTile, ty = threadIdx.x / kSsimTile;
     const int r0 = blockIdx.y * kSsimTile, c0 = blockIdx.x * kSsimTile;
-    const int pw = kSsimTile + A.win - 1;
+    const int pw = kSsimTile + win - 1;
     const float lo = A.normalise ? A.stats[0] : 0.f;
     const float den = A.normalise ? __fadd_rn(A.stats[1] - lo, 1e-8f) : 1.f;
     for (int e = threadIdx.x; e < pw * pw; e += kSsimTile * kSsimTile) {
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_map_kernel(SsimArgs
     for (int e = threadIdx.x; e < pw * kSsimTile; e += kSsimTile * kSsimTile) {
         const int r = e / kSsimTile, c = e - r * kSsimTile;
         float rx = 0.f, ry = 0.f, rxx = 0.f, ryy = 0.f, rxy = 0.f;
-        for (int j = 0; j < A.win; ++j) {
+#pragma unroll
+        for (int j = 0; j < win; ++j) {
             const float w = A.w1d[j], x = px[r][c + j], y = py[r][c + j];
             rx = __builtin_fmaf(w, x, rx); ry = __builtin_fmaf(w, y, ry);
             rxx = __builtin_fmaf(w, x * x, rxx); ryy = __builtin_fmaf(w, y * y, ryy); rxy = __builtin_fmaf(w, x * y, rxy);
@@ -159,7 +164,8 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_map_kernel(SsimArgs
     const int r = r0 + ty, c = c0 + tx;
     const bool live = r < A.Hm && c < A.Wm;
     float mx = 0.f, my = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
-    for (int i = 0; i < A.win; ++i) {
+#pragma unroll
+    for (int i = 0; i < win; ++i) {
         const float w = A.w1d[i];
         mx = __builtin_fmaf(w, rows[0][ty + i][tx], mx); my = __builtin_fmaf(w, rows[1][ty + i][tx], my);
         exx = __builtin_fmaf(w, rows[2][ty + i][tx], exx); eyy = __builtin_fmaf(w, rows[3][ty + i][tx], eyy);
@@ -170,21 +176,40 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_map_kernel(SsimArgs
     const float ib = __fdiv_rn(1.f, b1 * b2);
     const float S = a1 * a2 * ib;
     if constexpr (!GRAD) {
+        // Sum of the map, without float atomics (deterministic) and without 2 x 256 returning atomics on ONE address
+        // (they serialise at the L2: ~5 us of this kernel): every block stores its partial; arrival is counted in 16
+        // groups and then once per group; the block that arrives last adds the partials in block order.
+        __shared__ int s_last;
         float v = live ? S : 0.f;
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
         __syncthreads();
+        const int nb = (int)(gridDim.x * gridDim.y), bid = (int)(blockIdx.y * gridDim.x + blockIdx.x);
         if (threadIdx.x == 0) {
-            atomicAdd(&A.stats[4], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
-            __threadfence();
-            const int done = atomicAdd(reinterpret_cast<int *>(A.stats) + 7, 1);
-            if (done == (int)(gridDim.x * gridDim.y) - 1) { // the last block: every partial sum is in
-                const float tot = atomicAdd(&A.stats[4], 0.f);
-                A.loss[0] = 1.f - tot / (float)((long)A.Hm * A.Wm);
+            A.part[bid] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+            __threadfence(); // (3.2 us of this kernel, measured by leaving it out; a finishing launch of its own would cost ~4.8)
+            int *cnt = reinterpret_cast<int *>(A.stats) + 8;
+            const int g = bid & 15, gsize = (nb - g + 15) >> 4, ngroups = nb < 16 ? nb : 16;
+            int last = 0;
+            if (atomicAdd(cnt + g, 1) == gsize - 1) {
+                __threadfence();
+                last = atomicAdd(cnt + 16, 1) == ngroups - 1;
             }
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last) { // block-uniform
+            __threadfence();
+            float t = 0.f;
+            for (int b = threadIdx.x; b < nb; b += kSsimTile * kSsimTile) t += __builtin_nontemporal_load(A.part + b);
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                A.loss[0] = 1.f - ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) / (float)((long)A.Hm * A.Wm);
         }
     } else {
-        if (A.reuse_stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) A.stats[5] = A.stats[6] = 0.f; // ssim_back_kernel adds into them
         if (live) {
             // loss = 1 - mean(S): every position weighs -gloss / N
             const float k = -(A.gloss ? A.gloss[0] : 1.f) / (float)((long)A.Hm * A.Wm);
@@ -201,14 +226,16 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_map_kernel(SsimArgs
 
 // dL/dx(p) = sum over the map positions q whose window covers p of w(p - q) (G_mu(q) + 2 x(p) G_xx(q) + y(p) G_xy(q)),
 // then through the normalisation: dL/dimg = dL/dx / den, and the sums that go to the min / max pixels
+template <int WIN>
 __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_back_kernel(SsimArgs A)
 {
+    const int win = WIN ? WIN : A.win;
     __shared__ float g[3][kSsimPatch][kSsimPatch + 1];
     __shared__ float urow[3][kSsimPatch][kSsimTile + 1]; // row sums, shared like in ssim_map_kernel
     __shared__ float s_a[4], s_b[4];
     const int tx = threadIdx.x % kSsimTile, ty = threadIdx.x / kSsimTile;
     const int r0 = blockIdx.y * kSsimTile, c0 = blockIdx.x * kSsimTile;
-    const int pw = kSsimTile + A.win - 1, off = A.win - 1;
+    const int pw = kSsimTile + win - 1, off = win - 1;
     const long hw = (long)A.Hm * A.Wm;
     for (int e = threadIdx.x; e < pw * pw; e += kSsimTile * kSsimTile) {
         const int r = e / pw, c = e - r * pw, qr = r0 + r - off, qc = c0 + c - off;
@@ -222,7 +249,8 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_back_kernel(SsimArg
     for (int e = threadIdx.x; e < pw * kSsimTile; e += kSsimTile * kSsimTile) { // patch row r, tile column c
         const int r = e / kSsimTile, c = e - r * kSsimTile;
         float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-        for (int j = 0; j < A.win; ++j) { // q = p - (i, j): patch column c + off - j
+#pragma unroll
+        for (int j = 0; j < win; ++j) { // q = p - (i, j): patch column c + off - j
             const float w = A.w1d[j];
             u0 = __builtin_fmaf(w, g[0][r][c + off - j], u0);
             u1 = __builtin_fmaf(w, g[1][r][c + off - j], u1);
@@ -234,7 +262,8 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_back_kernel(SsimArg
     const int r = r0 + ty, c = c0 + tx;
     const bool live = r < A.H && c < A.W;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-    for (int i = 0; i < A.win; ++i) {
+#pragma unroll
+    for (int i = 0; i < win; ++i) {
         const float w = A.w1d[i];
         t0 = __builtin_fmaf(w, urow[0][ty + off - i][tx], t0);
         t1 = __builtin_fmaf(w, urow[1][ty + off - i][tx], t1);
@@ -260,9 +289,10 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_back_kernel(SsimArg
         for (int o = 32; o > 0; o >>= 1) { da += __shfl_xor(da, o); db += __shfl_xor(db, o); }
         if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = da; s_b[threadIdx.x >> 6] = db; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(&A.stats[5], s_a[0] + s_a[1] + s_a[2] + s_a[3]);
-            atomicAdd(&A.stats[6], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+        if (threadIdx.x == 0) { // per-block partials, summed in block order by ssim_ties_kernel: no atomics, deterministic
+            const int bid = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+            A.part[A.nblk + bid] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+            A.part[2 * A.nblk + bid] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
         }
     }
 }
@@ -270,9 +300,17 @@ __global__ __launch_bounds__(kSsimTile *kSsimTile) void ssim_back_kernel(SsimArg
 // the gradient of img.min() / img.max(): shared equally by the pixels that attain them (torch: evenly_distribute_backward)
 __global__ __launch_bounds__(kBlock) void ssim_ties_kernel(SsimArgs A)
 {
+    __shared__ float s_t[2][kWavesPerBlock];
     const long n = (long)A.H * A.W;
     const float lo = A.stats[0], hi = A.stats[1];
-    const float glo = A.stats[5] / A.stats[2], ghi = A.stats[6] / A.stats[3];
+    float ta = 0.f, tb = 0.f; // dL/dlo, dL/dhi: the blocks' partials of ssim_back_kernel in block order (every block, the same sum)
+    for (int b = threadIdx.x; b < A.nblk; b += kBlock) { ta += A.part[A.nblk + b]; tb += A.part[2 * A.nblk + b]; }
+    for (int o = 32; o > 0; o >>= 1) { ta += __shfl_xor(ta, o); tb += __shfl_xor(tb, o); }
+    if ((threadIdx.x & 63) == 0) { s_t[0][threadIdx.x >> 6] = ta; s_t[1][threadIdx.x >> 6] = tb; }
+    __syncthreads();
+    ta = tb = 0.f;
+    for (int w = 0; w < kWavesPerBlock; ++w) { ta += s_t[0][w]; tb += s_t[1][w]; }
+    const float glo = ta / A.stats[2], ghi = tb / A.stats[3];
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
         const float v = A.img[i];
         float add = 0.f;
@@ -289,9 +327,12 @@ int ssim_setup(SsimArgs &A, const float *img, const float *ref, int H, int W, in
     if (H < win || W < win) return DIFFUS_EINVAL;
     A.img = img; A.ref = ref; A.H = H; A.W = W; A.Hm = H - win + 1; A.Wm = W - win + 1; A.win = win;
     A.c1 = k1 * k1; A.c2 = k2 * k2; A.normalise = normalise != 0;
-    if (!workspace || workspace_bytes < align256(8 * sizeof(float)) + sizeof(float) * 3 * (size_t)A.Hm * A.Wm) return DIFFUS_EWORKSPACE;
+    A.nblk = ((W + kSsimTile - 1) / kSsimTile) * ((H + kSsimTile - 1) / kSsimTile);
+    const size_t head = align256(32 * sizeof(float)), parts = align256(sizeof(float) * 3 * (size_t)A.nblk);
+    if (!workspace || workspace_bytes < head + parts + sizeof(float) * 3 * (size_t)A.Hm * A.Wm) return DIFFUS_EWORKSPACE;
     A.stats = (float *)workspace;
-    A.gmap = (float *)((char *)workspace + align256(8 * sizeof(float)));
+    A.part = (float *)((char *)workspace + head);
+    A.gmap = (float *)((char *)workspace + head + parts);
     // normalised 2-D Gaussian exp(-(i^2 + j^2) / (2 sigma^2)) / sum = outer product of the normalised 1-D one
     double w[kSsimMaxWin], tot = 0.0;
     for (int i = 0; i < win; ++i) {
@@ -310,7 +351,8 @@ extern "C" {
 size_t diffus_ssim_workspace_bytes(int H, int W, int win)
 {
     if (H <= 0 || W <= 0 || win < 1 || H < win || W < win) return 0;
-    return align256(8 * sizeof(float)) + align256(sizeof(float) * 3 * (size_t)(H - win + 1) * (W - win + 1));
+    const size_t nblk = (size_t)((W + kSsimTile - 1) / kSsimTile) * ((H + kSsimTile - 1) / kSsimTile);
+    return align256(32 * sizeof(float)) + align256(sizeof(float) * 3 * nblk) + align256(sizeof(float) * 3 * (size_t)(H - win + 1) * (W - win + 1));
 }
 
 int diffus_ssim_loss_fwd(const float *img, const float *ref, int H, int W, int normalise, int win, float sigma, float k1, float k2,
@@ -324,7 +366,10 @@ int diffus_ssim_loss_fwd(const float *img, const float *ref, int H, int W, int n
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(kMmThreads), 0, st, A); // (also clears the accumulators: needed without normalisation too)
     dim3 grid((A.Wm + kSsimTile - 1) / kSsimTile, (A.Hm + kSsimTile - 1) / kSsimTile);
-    hipLaunchKernelGGL(ssim_map_kernel<false>, grid, dim3(kSsimTile * kSsimTile), 0, st, A);
+    if (win == 11)
+        hipLaunchKernelGGL((ssim_map_kernel<false, 11>), grid, dim3(kSsimTile * kSsimTile), 0, st, A);
+    else
+        hipLaunchKernelGGL((ssim_map_kernel<false, 0>), grid, dim3(kSsimTile * kSsimTile), 0, st, A);
     return last_launch();
 }
 
@@ -342,9 +387,15 @@ int diffus_ssim_loss_bwd(const float *img, const float *ref, int H, int W, int n
     // min / max and the tie counts: recomputed, unless the caller vouches that `workspace` still holds the forward's
     if (A.normalise && !A.reuse_stats) hipLaunchKernelGGL(ssim_minmax_kernel, dim3(1), dim3(kMmThreads), 0, st, A);
     dim3 gm((A.Wm + kSsimTile - 1) / kSsimTile, (A.Hm + kSsimTile - 1) / kSsimTile);
-    hipLaunchKernelGGL(ssim_map_kernel<true>, gm, dim3(kSsimTile * kSsimTile), 0, st, A);
+    if (win == 11)
+        hipLaunchKernelGGL((ssim_map_kernel<true, 11>), gm, dim3(kSsimTile * kSsimTile), 0, st, A);
+    else
+        hipLaunchKernelGGL((ssim_map_kernel<true, 0>), gm, dim3(kSsimTile * kSsimTile), 0, st, A);
     dim3 gi((W + kSsimTile - 1) / kSsimTile, (H + kSsimTile - 1) / kSsimTile);
-    hipLaunchKernelGGL(ssim_back_kernel, gi, dim3(kSsimTile * kSsimTile), 0, st, A);
+    if (win == 11)
+        hipLaunchKernelGGL(ssim_back_kernel<11>, gi, dim3(kSsimTile * kSsimTile), 0, st, A);
+    else
+        hipLaunchKernelGGL(ssim_back_kernel<0>, gi, dim3(kSsimTile * kSsimTile), 0, st, A);
     if (A.normalise) {
         unsigned nb = (unsigned)(((long)H * W + kBlock - 1) / kBlock); if (nb > 1024) nb = 1024;
         hipLaunchKernelGGL(ssim_ties_kernel, dim3(nb), dim3(kBlock), 0, st, A);

@@ -66,11 +66,14 @@ class _SplatFn(torch.autograd.Function):
             b = _as(c1, dev, torch.float32)
             v = _as(val, dev, torch.float32)
             out = torch.empty((P, W, H), dtype=torch.float32, device=dev)
+            # the winner raster is kept for the backward when one can follow (three launches there instead of six)
+            keep = torch.empty((P, H * W), dtype=torch.int32, device=dev) if ctx.needs_input_grad[2] else None
             nws = lib.diffus_splat_workspace_bytes(P, H, W)
             ws = _workspace(dev, nws)
-            rc = lib.diffus_splat_fwd(_ptr(a), _ptr(b), _ptr(v), P, n, int(cols), H, W, float(sigma), _ptr(out), _ptr(ws),
-                                      ws.numel(), _stream(dev))
+            rc = lib.diffus_splat_fwd(_ptr(a), _ptr(b), _ptr(v), P, n, int(cols), H, W, float(sigma), _ptr(out), _ptr(keep),
+                                      _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "diffus_splat_fwd")
+        ctx.keep = keep
         ctx.save_for_backward(a, b)
         ctx.meta = (H, W, float(sigma), val.device, val.dtype)
         return out
@@ -86,8 +89,8 @@ class _SplatFn(torch.autograd.Function):
             g = _as(gout, dev, torch.float32)
             gval = torch.empty((P, n), dtype=torch.float32, device=dev)
             ws = _workspace(dev, lib.diffus_splat_workspace_bytes(P, H, W))
-            rc = lib.diffus_splat_bwd(_ptr(a), _ptr(b), P, n, H, W, sigma, _ptr(g), _ptr(gval), _ptr(ws), ws.numel(),
-                                      _stream(dev))
+            rc = lib.diffus_splat_bwd(_ptr(a), _ptr(b), P, n, H, W, sigma, _ptr(g), _ptr(gval), _ptr(ctx.keep), _ptr(ws),
+                                      ws.numel(), _stream(dev))
         _lib.check(rc, "diffus_splat_bwd")
         if gval.device != vdev or gval.dtype != vdt:
             gval = gval.to(device=vdev, dtype=vdt)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DIFFUS_ABI_VERSION 4 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd */
+#define DIFFUS_ABI_VERSION 5 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd; 5: winner raster kept between diffus_splat_fwd / _bwd */
 
 /* error codes */
 #define DIFFUS_OK            0
@@ -354,11 +354,14 @@ int diffus_splat_axes(const void *x, int x_dtype, const void *y, int y_dtype, co
                       float *c0, float *c1, diffus_stream_t stream);
 
 size_t diffus_splat_workspace_bytes(int P, int H, int W);
+/* winner_keep (nullable, P*H*W int32): where the forward builds its winner raster (sample index per pixel, -1 = none) when
+ * the caller wants it kept; handed to diffus_splat_bwd as winner_kept the backward needs no scatter of its own (and, for
+ * kernel half-widths up to 8, three launches instead of six). */
 int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, long n, int cols,
-                     int H, int W, float sigma, float *out,
+                     int H, int W, float sigma, float *out, int *winner_keep,
                      void *workspace, size_t workspace_bytes, diffus_stream_t stream);
 int diffus_splat_bwd(const float *c0, const float *c1, int P, long n,
-                     int H, int W, float sigma, const float *gout, float *gval,
+                     int H, int W, float sigma, const float *gout, float *gval, const int *winner_kept,
                      void *workspace, size_t workspace_bytes, diffus_stream_t stream);
 
 /*
