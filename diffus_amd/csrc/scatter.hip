@@ -19,7 +19,7 @@ namespace {
 __device__ unsigned long long *g_stamps = nullptr;
 #define STAMP(i)                                                                          \
     do {                                                                                  \
-        if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && g_stamps) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define STAMP(i) ((void)0)
@@ -400,8 +400,8 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
         STAMP(5);
 #ifdef DIFFUS_STAMP
         if (threadIdx.x == 0 && g_stamps) {
-            g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)need;
-            g_stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)nsub;
+            g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = (unsigned long long)need;
+            g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = (unsigned long long)nsub;
         }
 #endif
         if (sp + 1 < nsub) __syncthreads();
@@ -410,7 +410,7 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
 }
 
 template <int SAMPLER, int LAYOUT, int PM>
-__global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int step_groups, unsigned npatch)
+__global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int has_finish)
 {
     // General (3-D) tile: 32-bit FIXED POINT with a per-patch power-of-two scale 2^fx chosen so that even all 1024 samples
     // landing on one voxel cannot overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel
@@ -429,9 +429,11 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
 
     // the FIRST blocks of the launch, one per pose: median routing (start > 0) and d/dsource.  They need nothing from the
     // patches, and at the head of the grid their serial reductions run beside the first patches instead of after the last.
-    const unsigned nfin = gridDim.x - npatch;
-    if (blockIdx.x < nfin) {
-        pose_finish_block<SAMPLER, LAYOUT>(A, (int)blockIdx.x, reinterpret_cast<float *>(tile));
+    // Grid: x = (pose, ray group) of one step group, y = step group (+ the finishing row in front): the block reads its
+    // step group off blockIdx.y instead of dividing a linear index (uniform integer divisions are ~20 instructions each,
+    // and every instruction of this kernel costs the same: fact 23).
+    if (has_finish && blockIdx.y == 0) {
+        if (blockIdx.x < (unsigned)A.P) pose_finish_block<SAMPLER, LAYOUT>(A, (int)blockIdx.x, reinterpret_cast<float *>(tile));
         return;
     }
     // patch -> (step group, pose, ray group), step group SLOWEST: the blocks in flight at any time are then the same
@@ -443,10 +445,9 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     bool ray_ok;
     long w, w0;        // this thread's ray, the block's first ray (block-uniform)
     unsigned row_off;  // bytes from zbar[w0][0] to the thread's first sample
-    auto decode = [&](unsigned bid) {
-        const int per_sg = (int)(npatch / (unsigned)step_groups);
-        const int sg = (int)(bid / (unsigned)per_sg);
-        const unsigned Lb = xcd_remap(bid % (unsigned)per_sg, (unsigned)per_sg);
+    auto decode = [&](unsigned bx, unsigned by) {
+        const int sg = (int)by - has_finish;
+        const unsigned Lb = xcd_remap(bx, gridDim.x);
         const int rg = Lb % ray_groups;
         pose = Lb / ray_groups;
         // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..).  (Tried: a wave taking every 4th ray of the
@@ -459,11 +460,11 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         w = w0 + (ray_ok ? rl : 0);
         row_off = (__umul24((unsigned)(ray_ok ? rl : 0), (unsigned)A.N1) + (unsigned)nbase) * 4u; // N1 < 2^24, rl < 2^6
     };
-    unsigned bid = blockIdx.x - nfin;
+    unsigned bx = blockIdx.x, by = blockIdx.y;
 #ifdef DIFFUS_SC_EXIT
     if (DIFFUS_SC_EXIT == 0) return; // launch + dispatch floor
 #endif
-    decode(bid);
+    decode(bx, by);
 
     STAMP(0);
 #ifdef DIFFUS_SC_SALU_PAD // issue-rate probe (tools/): N extra scalar instructions per wave
@@ -501,8 +502,8 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         __syncthreads(); // an oblique patch: every wave has read the records above before the general path rewrites them
         // The general path starts from scratch: laundering the block index keeps the compiler from carrying the patch
         // coordinates and the pose across the planar code above in registers it does not have (60 bytes of spills).
-        asm volatile("" : "+s"(bid));
-        decode(bid);
+        asm volatile("" : "+s"(bx), "+s"(by));
+        decode(bx, by);
         load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     }
     Cell cells[kSPT];
@@ -723,8 +724,8 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     STAMP(5);
 #ifdef DIFFUS_STAMP
     if (threadIdx.x == 0 && g_stamps) {
-        g_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)nt;
-        g_stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)nsub;
+        g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = (unsigned long long)nt;
+        g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = (unsigned long long)nsub;
     }
 #endif
     if (sp + 1 < nsub) __syncthreads(); // the next group adds into the tile this one has just read and cleared
@@ -737,16 +738,16 @@ namespace diffus {
 int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
 {
     const int rgs = (A.R + kScRays - 1) / kScRays, sgs = (A.N1 + kScSteps - 1) / kScSteps;
-    const unsigned np = (unsigned)((long)A.P * rgs * sgs);
-    const unsigned nb = np + (A.finish_in_scatter ? (unsigned)A.P : 0u);
+    const int fin = A.finish_in_scatter ? 1 : 0;
+    const dim3 grid((unsigned)((long)A.P * rgs), (unsigned)(sgs + fin)); // sgs <= 2048 (DIFFUS_MAX_SAMPLES * SEGMENTS / patch steps)
     const bool f32 = !A.src_f64 && !A.dir_f64;
     const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout; // the scatter only sees the gradient
     return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
         constexpr int SM = decltype(S_)::value, LY = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
         if (f32)
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), dim3(nb), dim3(kSB), 0, st, A, rgs, sgs, np);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), grid, dim3(kSB), 0, st, A, rgs, fin);
         else
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), dim3(nb), dim3(kSB), 0, st, A, rgs, sgs, np);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), grid, dim3(kSB), 0, st, A, rgs, fin);
         return last_launch();
     });
 }

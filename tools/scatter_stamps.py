@@ -13,7 +13,7 @@ src, dirs = pose_ring(256, 32, 256)
 hp = HotPath(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), 512, 1e-4, "trilinear", sparse=False)
 hp.fwd(); hp.loss_and_grad(); hp.zero_grad(); hp.bwd(_lib.BWD_SCAN)
 nblk = 32 * 16 * 8
-nfin = 32  # one finishing block per pose, at the head of the grid
+nfin = 32 * 8  # the finishing row in front of the patch rows: P * ray groups blocks, the first P of them work
 st = torch.zeros((nblk + nfin) * 8, dtype=torch.int64, device="cuda")
 lib.diffus_debug_set_stamps.argtypes = [C.c_void_p]
 assert lib.diffus_debug_set_stamps(C.c_void_p(st.data_ptr())) == 0
