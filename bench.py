@@ -705,13 +705,14 @@ class StepRunner:
         return {"dt": dt, "per_rank_ms": per_rank_ms, "host_ms": host_ms, "world_seen": world_seen}
 
 
-def verify_step(args, vol_np, src_all, dirs_all, local_lo, hp, losses_all, frame_poses, loss_poses):
+def verify_step(args, vol_of_pose, src_all, dirs_all, local_lo, hp, losses_all, frame_poses, loss_poses):
     """The timed step checks what it computed, OUTSIDE the timed region: frames of `frame_poses`
     (indices into this rank's shard) and per-pose losses of `loss_poses` (global pose indices, read from the GATHERED
     vector, so a gather that scrambles the pose order fails here) against the CPU oracle (oracle/diffus_oracle.c: the
     restatement of reference src/renderer.py:201-275; echo series in float64).  Frame tolerance: 2e-5 max-norm-relative,
     widened on fans that graze the skull to 16 input roundings' worth (oracle/conditioning.py -- the reference's own
-    float32 LU is 3e-5 .. 1.4e-4 from its float64 result on such rays, golden G17).  loss_p = sum(frame_p^2): 1e-4."""
+    float32 LU is 3e-5 .. 1.4e-4 from its float64 result on such rays, golden G17).  loss_p = sum(frame_p^2): 1e-4.
+    `vol_of_pose(p)` = the volume the OWNER of global pose p rendered (config 5: one phantom variant per rank)."""
     import numpy as np
     from oracle import oracle as orc
     from oracle.conditioning import frame64_and_tolerance
@@ -721,9 +722,9 @@ def verify_step(args, vol_np, src_all, dirs_all, local_lo, hp, losses_all, frame
     def oracle_frame(p):
         if p not in cache:
             if args.start == 0:
-                f64, tol, _ = frame64_and_tolerance(vol_np, src_all[p], dirs_all[p], args.samples, args.alpha, sampler=args.sampler)
+                f64, tol, _ = frame64_and_tolerance(vol_of_pose(p), src_all[p], dirs_all[p], args.samples, args.alpha, sampler=args.sampler)
             else:       # start crop + median: the float32 scalar oracle, fixed tolerance
-                f64 = orc.plot_beam_frame(vol_np, src_all[p], dirs_all[p], args.samples, args.alpha, args.start,
+                f64 = orc.plot_beam_frame(vol_of_pose(p), src_all[p], dirs_all[p], args.samples, args.alpha, args.start,
                                           sampler=args.sampler)[3].astype(np.float64)
                 tol = 1e-4
             cache[p] = (f64, tol)
@@ -823,8 +824,17 @@ def worker(args):
     if rank == 0 and not args.no_verify:
         try:
             loss_poses = sorted({0, P - 1, P_total - 1})
+            vols = {0: vol_np}                        # config 5: pose p was rendered through its owner's phantom variant
+
+            def vol_of_pose(p):
+                v = (p // P) if args.n >= 512 else 0
+                if v not in vols:
+                    for k in [k for k in vols if k != 0]:
+                        del vols[k]                   # 512 MiB each: rank 0's and one other at a time
+                    vols[v] = phantom(args.n, variant=v)
+                return vols[v]
             # (P * 9) // 16: pose 18 of config 3, a fan that grazes the skull -- the hard case is checked too
-            verified = verify_step(args, vol_np, src_all, dirs_all, lo, hp, run.losses_all,
+            verified = verify_step(args, vol_of_pose, src_all, dirs_all, lo, hp, run.losses_all,
                                    sorted({0, (P * 9) // 16, P - 1}), loss_poses)
         except Exception as e:      # the oracle could not be built or run: say so, never claim a check that did not happen
             verified = {"ok": False, "failed": repr(e)}

@@ -16,8 +16,9 @@ from .splat import differentiable_splat, rotate_around_apex, splat_frames  # noq
 from .impedance import ImpedanceEstimator, create_brain_mask, masked_stats, zscore_normalize  # noqa: F401,E402
 from .captured import CapturedStep  # noqa: F401,E402
 from .losses import ssim_loss  # noqa: F401,E402
+from .raster import rasterize_fan  # noqa: F401,E402
 
-__all__ = ["ssim_loss", "prop_single_ray", "propagate_full_rays_batched", "custom_nearest_sampler", "CapturedStep", "ImpedanceEstimator", "create_brain_mask", "zscore_normalize", "masked_stats", "apply_artifacts", "compute_gaussian_pulse", "gaussian_pulse", "FanPose", "compute_us_apex_and_direction", "cone_us_to_mri_world", "voxel_to_world", "world_to_voxel",
+__all__ = ["ssim_loss", "rasterize_fan", "prop_single_ray", "propagate_full_rays_batched", "custom_nearest_sampler", "CapturedStep", "ImpedanceEstimator", "create_brain_mask", "zscore_normalize", "masked_stats", "apply_artifacts", "compute_gaussian_pulse", "gaussian_pulse", "FanPose", "compute_us_apex_and_direction", "cone_us_to_mri_world", "voxel_to_world", "world_to_voxel",
            "differentiable_splat", "rotate_around_apex", "splat_frames", "UltrasoundRenderer", "compute_echo_traces", "render_poses", "trace_rays", "resolve_start",
            "generate_cone_directions", "fan_directions_torch", "DiffusError", "BrickedVolume", "brick_volume",
            "unbrick_volume", "pair_volume"]

@@ -395,7 +395,12 @@ class CapturedStep:
         return g
 
     def replay(self, what: str = "step"):
-        self._graphs[what].replay()
+        """Replay the captured graph of `what`.  A "backward" graph captured with the forward's median baked in
+        (DIFFUS_BWD_KEEP_MEDIAN, start > 0) is only valid for the inputs that median was computed from: after set_poses()
+        or a volume edit without a forward in between it runs eagerly instead (same guard as the autograd path)."""
+        if what not in self._graphs:
+            raise _lib.DiffusError(f"replay({what!r}): nothing captured under that name (capture() first)")
+        self._run(what)
 
     def _run(self, what: str):
         g = self._graphs.get(what)

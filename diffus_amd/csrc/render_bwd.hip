@@ -15,6 +15,14 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
     do {                                                                                                         \
         if (g_bwd_stamps && lane == 0) g_bwd_stamps[((size_t)w * 2 + part) * 12 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#elif defined(DIFFUS_PHASE_MARKS) // static analysis only (tools/issue_model.py): phase boundaries as comments in the assembly
+#define STAMPB(i)                                        \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        asm volatile("; DIFFUS_PHASE " #i);              \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
+#define STAMPRT(i) ((void)0)
 #else
 #define STAMPB(i) ((void)0)
 #define STAMPRT(i) ((void)0)

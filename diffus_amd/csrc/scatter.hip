@@ -447,6 +447,8 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     unsigned row_off;  // bytes from zbar[w0][0] to the thread's first sample
     auto decode = [&](unsigned bx, unsigned by) {
         const int sg = (int)by - has_finish;
+        // gridDim.x is a multiple of 8 (launch_scatter pads it): the hardware's linear block id by * gridDim.x + bx then
+        // has the same residue mod 8 -- the XCD -- as bx in every row, so a pose sits on ONE XCD for all its step groups
         const unsigned Lb = xcd_remap(bx, gridDim.x);
         const int rg = Lb % ray_groups;
         pose = Lb / ray_groups;
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
 #ifdef DIFFUS_SC_EXIT
     if (DIFFUS_SC_EXIT == 0) return; // launch + dispatch floor
 #endif
+    if (xcd_remap(bx, gridDim.x) >= (unsigned)A.P * (unsigned)ray_groups) return; // padding block (block-uniform, before any barrier)
     decode(bx, by);
 
     STAMP(0);
@@ -739,7 +742,8 @@ int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
 {
     const int rgs = (A.R + kScRays - 1) / kScRays, sgs = (A.N1 + kScSteps - 1) / kScSteps;
     const int fin = A.finish_in_scatter ? 1 : 0;
-    const dim3 grid((unsigned)((long)A.P * rgs), (unsigned)(sgs + fin)); // sgs <= 2048 (DIFFUS_MAX_SAMPLES * SEGMENTS / patch steps)
+    // x padded to a multiple of 8 (at most 7 idle blocks per row): see the XCD note in the kernel's decode()
+    const dim3 grid((unsigned)((((long)A.P * rgs + 7) / 8) * 8), (unsigned)(sgs + fin)); // sgs <= 2048 (DIFFUS_MAX_SAMPLES * SEGMENTS / patch steps)
     const bool f32 = !A.src_f64 && !A.dir_f64;
     const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout; // the scatter only sees the gradient
     return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {

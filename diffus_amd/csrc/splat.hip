@@ -696,7 +696,7 @@ int diffus_splat_fwd(const float *c0, const float *c1, const float *val, int P, 
         unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 4096) nb = 4096;
         hipLaunchKernelGGL(splat_winner_kernel, dim3(nb, P), dim3(kBlock), 0, st, c0, c1, n, H, W, winner);
     }
-    if (half <= kSplatFusedMaxHalf) // compose + both blurs + divide in one launch
+    if (half >= 1 && half <= kSplatFusedMaxHalf) // compose + both blurs + divide in one launch (half == 0, sigma < 1/3: the size-1 kernel of the general path)
         return launch_splat_fused<false>(winner, val, n, nullptr, out, H, W, half, sigma, P, st);
     unsigned pb = (unsigned)((hw + kBlock - 1) / kBlock); if (pb > 4096) pb = 4096;
     hipLaunchKernelGGL(splat_compose_kernel, dim3(pb, P), dim3(kBlock), 0, st, winner, val, n, hw, planes);
@@ -721,7 +721,7 @@ int diffus_splat_bwd(const float *c0, const float *c1, int P, long n, int H, int
     float *blurred = (float *)((char *)planes + align256(sizeof(float) * (size_t)P * 2 * hw));
     (void)winner;
     unsigned nb = (unsigned)((n + kBlock - 1) / kBlock); if (nb > 4096) nb = 4096;
-    if (winner_kept && half <= kSplatFusedMaxHalf) {
+    if (winner_kept && half >= 1 && half <= kSplatFusedMaxHalf) {
         // the forward's winner raster says where samples landed: weight plane, its blur and q = gout^T / (bw + eps) in one
         // launch; then blur q and gather per sample
         int rc = launch_splat_fused<true>(winner_kept, nullptr, n, gout, planes, H, W, half, sigma, P, st);

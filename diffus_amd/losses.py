@@ -31,8 +31,10 @@ class _SsimLossFn(torch.autograd.Function):
             rc = lib.diffus_ssim_loss_fwd(_ptr(a), _ptr(b), H, W, int(normalise), win, sigma, k1, k2, _ptr(loss), _ptr(ws),
                                           ws.numel(), _stream(dev))
         _lib.check(rc, "diffus_ssim_loss_fwd")
-        ctx.keep = (a, b, ws)
-        ctx.img_version = a._version       # the workspace keeps min / max / tie counts: valid while `a` is unchanged
+        # save_for_backward (not a plain attribute): torch then raises if `img` / `ref` are edited in place between the
+        # forward and the backward -- the workspace keeps min / max / tie counts of the image as it was
+        ctx.save_for_backward(a, b)
+        ctx.ws = ws
         ctx.meta = (int(normalise), win, sigma, k1, k2, img.device, img.dtype)
         return loss if loss.device == img.device else loss.to(img.device)
 
@@ -40,7 +42,8 @@ class _SsimLossFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gloss):
         lib = _lib.load()
-        a, b, ws = ctx.keep
+        a, b = ctx.saved_tensors
+        ws = ctx.ws
         normalise, win, sigma, k1, k2, idev, idt = ctx.meta
         dev = a.device
         H, W = a.shape
@@ -48,7 +51,7 @@ class _SsimLossFn(torch.autograd.Function):
         with _Scope(dev):
             gimg = torch.empty((H, W), dtype=torch.float32, device=dev)
             rc = lib.diffus_ssim_loss_bwd(_ptr(a), _ptr(b), H, W, normalise, win, sigma, k1, k2, _ptr(g), _ptr(gimg),
-                                          int(a._version == ctx.img_version), _ptr(ws), ws.numel(), _stream(dev))
+                                          1, _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "diffus_ssim_loss_bwd")
         if gimg.device != idev or gimg.dtype != idt:
             gimg = gimg.to(device=idev, dtype=idt)
@@ -58,9 +61,22 @@ class _SsimLossFn(torch.autograd.Function):
 def ssim_loss(img: torch.Tensor, ref: torch.Tensor, normalise: bool = True, win: int = 11, sigma: float = 1.5,
               k1: float = 0.01, k2: float = 0.03) -> torch.Tensor:
     """1 - SSIM(min-max-normalised img, ref) for one (H, W) image pair, differentiable in `img` (scalar tensor).
-    `ref` is used as given (the notebook normalises the real image once, up front)."""
+    `ref` is used as given (the notebook normalises the real image once, up front).
+
+    piq.ssim first average-pools both images by f = max(1, round(min(H, W) / 256)).  Up to 383 pixels that is the
+    identity and the whole loss is the one fused node; for larger images the normalisation and the pooling run as
+    torch ops in front of the kernel (pooling is linear, so it commutes with the min-max of the UNPOOLED image)."""
     if img.dim() != 2 or ref.shape != img.shape:
         raise ValueError(f"img and ref must be (H, W) tensors of the same shape; got {tuple(img.shape)} and {tuple(ref.shape)}")
     if win % 2 == 0 or not (1 <= win <= 15):
         raise ValueError("win must be odd and at most 15")
+    f = max(1, round(min(img.shape) / 256))
+    if f > 1:
+        x = img
+        if normalise:
+            lo, hi = x.min(), x.max()
+            x = (x - lo) / (hi - lo + 1e-8)
+        x = torch.nn.functional.avg_pool2d(x[None, None], f)[0, 0]
+        r = torch.nn.functional.avg_pool2d(ref.to(device=x.device, dtype=x.dtype)[None, None], f)[0, 0]
+        return _SsimLossFn.apply(x, r, False, int(win), float(sigma), float(k1), float(k2))
     return _SsimLossFn.apply(img, ref, bool(normalise), int(win), float(sigma), float(k1), float(k2))

@@ -528,7 +528,8 @@ class _EchoFn(torch.autograd.Function):
             if B:
                 fn, name = (lib.diffus_propagate_rays, "diffus_propagate_rays") if cumulate else (lib.diffus_echo_traces, "diffus_echo_traces")
                 _lib.check(fn(_ptr(r) if N else None, B, N, _ptr(out), _stream(dev)), name)
-        ctx.r, ctx.cumulate = r, bool(cumulate)
+        ctx.save_for_backward(r)           # torch raises if refLR is edited in place before the backward
+        ctx.cumulate = bool(cumulate)
         ctx.meta = (refLR.device, refLR.dtype if refLR.is_floating_point() else torch.float32)
         return out.to(device=ctx.meta[0], dtype=ctx.meta[1])
 
@@ -536,7 +537,7 @@ class _EchoFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
         lib = _lib.load()
-        r = ctx.r
+        r, = ctx.saved_tensors
         dev = r.device
         B, N = r.shape
         g = _as(gout, dev, torch.float32)

@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--big", action="store_true", help="also generate G10 (256 rays x 512 steps, ~150 s)")
+    ap.add_argument("--big", action="store_true", help="also generate G10 (256 rays x 512 steps, ~150 s) and G19 (~15 min)")
     ap.add_argument("--only", default="", help="comma list of cases to (re)generate")
     args = ap.parse_args()
     if not os.path.isdir(os.path.join(REF, "src")):
@@ -470,6 +470,44 @@ def main():
                 out[name] = y.detach().numpy()
                 out["g_" + name] = x.grad.numpy()
         save("g18_echo_autograd", **out)
+
+    # ---- G20: rasterize_fan (src/renderer.py:626-653; host-side SciPy griddata) on a small scattered fan ----------
+    if want("g20"):
+        g = np.random.default_rng(20)
+        ang = g.uniform(-0.5, 0.5, 60)
+        rad = g.uniform(5.0, 40.0, 60)
+        xs, zs = rad * np.sin(ang), rad * np.cos(ang)
+        val = g.uniform(0.0, 1.0, 60)
+        img = ref.rasterize_fan(xs, zs, val)
+        save("g20_rasterize_fan", x=xs, z=zs, v=val, img=img)
+
+    # ---- G19 (--big): EVERY ray of the ill-conditioned poses of config 3 through the reference's dense solves -----
+    # the widened tolerance of the full-size tests (oracle/conditioning.py) is a model; this pins
+    # it on /root/reference/src/renderer.py:407 itself.  Per pose: impedance along all 256 rays (trilinear samples of
+    # the 256^3 phantom from the oracle -- the reference has no trilinear sampler) -> the reference's
+    # compute_reflection_coeff + compute_echo_traces in fp32 AND fp64 (~2.5 + ~5 minutes of dense solves per pose).
+    if args.big and want("g19"):
+        import time
+        from oracle import oracle as orc
+        v = phantom(256)
+        s, d = pose_ring(256, 32, 256)
+        out = {"poses": np.array([18, 6], dtype=np.int64)}
+        for p in (18, 6):
+            Z = orc.sample_trilinear(v, s[p], d[p], 512)
+            Z32 = torch.from_numpy(Z)
+            r32 = ref.UltrasoundRenderer.compute_reflection_coeff(Z32[:, :-1], Z32[:, 1:])
+            t0 = time.time()
+            with quiet():
+                e32, _ = ref.compute_echo_traces(r32)
+            t1 = time.time()
+            with quiet():
+                e64, _ = ref.compute_echo_traces(r32.double())
+            print(f"g19 pose {p}: fp32 {t1 - t0:.0f} s, fp64 {time.time() - t1:.0f} s", flush=True)
+            out[f"Zsum_{p}"] = np.float64(Z.astype(np.float64).sum())
+            out[f"r_{p}"] = r32.numpy()
+            out[f"echo32_{p}"] = e32.numpy()
+            out[f"echo64_{p}"] = e64.numpy()
+        save("g19_ill_conditioned_poses", **out)
 
     # ---- G10 (--big): config-2 shape forward, 256 rays x 512 steps ---------------
     if args.big and want("g10"):

@@ -40,6 +40,42 @@ def test_ssim_loss_value_and_gradient_vs_torch_ops(H, W, normalise):
     assert abs(float(same)) <= 1e-6
 
 
+@pytest.mark.parametrize("H,W", [(512, 512), (400, 640)])
+def test_ssim_loss_large_images_are_average_pooled_like_piq(H, W):
+    """min(H, W) >= 384: piq.ssim average-pools by max(1, round(min(H, W) / 256)) first."""
+    import diffus_amd as da
+    from losses import minmax01, ssim
+    g = torch.Generator().manual_seed(H + W)
+    ref = torch.rand(H, W, generator=g).cuda()
+    img = (torch.rand(H, W, generator=g) * 2.0).cuda()
+    a = img.clone().requires_grad_(True)
+    b = img.clone().requires_grad_(True)
+    la = da.ssim_loss(a, ref)
+    lb = 1.0 - ssim(minmax01(b)[None, None], ref[None, None], data_range=1.0)
+    assert abs(float(la) - float(lb)) <= 2e-6
+    la.backward(); lb.backward()
+    den = float(b.grad.abs().max())
+    assert float((a.grad - b.grad).abs().max()) <= 2e-4 * den
+
+
+def test_ssim_loss_and_echo_series_detect_in_place_edits():
+    """an input edited in place between forward and backward raises (torch's saved-tensor version check), ADVICE r3"""
+    import diffus_amd as da
+    img = torch.rand(64, 64).cuda().requires_grad_(True)
+    ref = torch.rand(64, 64).cuda()
+    work = img * 1.0
+    l = da.ssim_loss(work, ref)
+    work.add_(1.0)
+    with pytest.raises(RuntimeError):
+        l.backward()
+    r = (torch.rand(3, 20).cuda() - 0.5).requires_grad_(True)
+    rw = r * 1.0
+    e, _ = da.compute_echo_traces(rw)
+    rw.mul_(0.5)
+    with pytest.raises(RuntimeError):
+        e.sum().backward()
+
+
 def test_ssim_loss_is_capturable_and_validates():
     import diffus_amd as da
     img = torch.rand(64, 64).cuda().requires_grad_(True)

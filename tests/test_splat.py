@@ -47,6 +47,26 @@ def test_hip_splat_matches_reference_and_oracle():
 
 
 @pytest.mark.gpu
+def test_hip_splat_tiny_sigma_size_one_kernel():
+    """0 < sigma < 1/3: int(6 sigma) | 1 = 1, the reference's size-1 Gaussian kernel (src/renderer.py:722-727) -- the
+    generic blur path, not the fused half >= 1 kernels (this raised DIFFUS_EUNSUPPORTED)."""
+    import diffus_amd
+    from oracle import splat as osp
+    g, tags = _cases()
+    t = tags[0]
+    H, W = int(g[f"{t}_H"]), int(g[f"{t}_W"])
+    for sigma in (0.3, 0.1):
+        x, y, z = (torch.from_numpy(g[f"{t}_{c}"]).cuda() for c in "xyz")
+        f = torch.from_numpy(g[f"{t}_f"]).cuda().requires_grad_(True)
+        out = diffus_amd.differentiable_splat(x, y, z, f, H=H, W=W, sigma=sigma)
+        o2, _ = osp.splat(g[f"{t}_x"], g[f"{t}_y"], g[f"{t}_z"], g[f"{t}_f"], H, W, sigma)
+        assert maxnorm_rel(out.detach().cpu().numpy(), o2) < 2e-6, sigma
+        (out * torch.from_numpy(g[f"{t}_up"]).cuda()).sum().backward()
+        gr = osp.splat_grad(g[f"{t}_x"], g[f"{t}_y"], g[f"{t}_z"], g[f"{t}_f"], g[f"{t}_up"], H, W, sigma)
+        assert maxnorm_rel(f.grad.cpu().numpy(), gr) < 2e-5, sigma
+
+
+@pytest.mark.gpu
 def test_hip_rotate_around_apex_matches_reference():
     import diffus_amd
     g, _ = _cases()
