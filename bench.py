@@ -42,10 +42,13 @@ step: kernels of one stream run back to back, two graph LAUNCHES are ~8.6 us apa
 Kernel durations for the roofline come from HIP events recorded on the launch
 stream (torch's current stream, which is the one handed to the C-ABI).
 
-`roofline` carries two figures for the dominant kernel: `achieved` = the no-reuse ALGORITHMIC bytes
-over its live launch time, and `measured_hbm_GBs` = HBM-side bytes of the committed rocprofv3 PMC passes for
-exactly this workload (profiles/*_pmc_*.json) over the same time.  `bound` names what the counters say limits
-the kernel; it is "hbm" only when the measured traffic is near the HBM rate.
+`roofline` leads with what was MEASURED for the dominant kernel: `achieved` / `frac` = HBM-side bytes of the committed
+rocprofv3 PMC passes for exactly this workload (profiles/*_pmc_*.json) over its live launch time; the contract's no-reuse
+ALGORITHMIC figure (SURVEY 8d bytes per ray-step x ray-steps per launch / launch time) sits beside it under `algorithmic`
+-- it is a model, and for cache-resident planar fans it exceeds what crosses the HBM interface.  `bound` names what the
+counters say limits the kernel ("hbm" only when the measured traffic is near the HBM rate); `issue_roofline` prices the
+kernel's VALU instruction stream against the SIMDs' issue rate, both at the guide's FP32 rate (2 cycles per wave64
+instruction) and cost-weighted with the per-instruction costs measured by tools/valu_issue_bench.hip.
 
 `callers` (N = 1 only) times the shapes the reference's notebooks actually run: the REUBEN demo frame
 (start > 0, artifacts, splat), a learnable volume (re-converted every step) and poses that move every step.
@@ -318,6 +321,19 @@ def find_pmc_summary(key):
             continue
         if pm.get("workload") == key and not pm.get("superseded_by"):   # before/after pairs of one round carry that key
             best = (os.path.relpath(f, ROOT), pm)          # names sort by round: the last match is the newest
+    return best
+
+
+def issue_mix(kernel):
+    """Mean issue cycles per VALU instruction of `kernel` (tools/issue_model.py --json, committed under profiles/)."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*issue_model*.json"))):
+        try:
+            for rec in json.load(open(f)).get("kernels", []):
+                if rec.get("short") == kernel:
+                    best = dict(rec, source=os.path.relpath(f, ROOT))
+        except Exception:
+            continue
     return best
 
 
@@ -710,7 +726,7 @@ def verify_step(args, vol_of_pose, src_all, dirs_all, local_lo, hp, losses_all, 
     (indices into this rank's shard) and per-pose losses of `loss_poses` (global pose indices, read from the GATHERED
     vector, so a gather that scrambles the pose order fails here) against the CPU oracle (oracle/diffus_oracle.c: the
     restatement of reference src/renderer.py:201-275; echo series in float64).  Frame tolerance: 2e-5 max-norm-relative,
-    widened on fans that graze the skull to 16 input roundings' worth (oracle/conditioning.py -- the reference's own
+    widened on fans that graze the skull to 10 input roundings' worth (oracle/conditioning.py -- the reference's own
     float32 LU is 3e-5 .. 1.4e-4 from its float64 result on such rays, golden G17).  loss_p = sum(frame_p^2): 1e-4.
     `vol_of_pose(p)` = the volume the OWNER of global pose p rendered (config 5: one phantom variant per rank)."""
     import numpy as np
@@ -877,6 +893,8 @@ def worker(args):
             dist.barrier()
         elif world == 1 and args.scaling == "auto" and config_label(args, 1, P_total) == "BASELINE config 3":
             scale_info["strong_base"] = one_gpu_leg(args.poses_total)
+            # the value a reader of the N = 1, 2, 4, 8 lines must divide the N > 1 (strong, config 4) values by
+            scale_info["scale_base_value"] = scale_info["strong_base"]["value"]
             scale_info["note"] = ("`value` is BASELINE config 3 (32 poses on one GPU).  With --gpus N > 1 this script shards "
                                   f"config 4's {args.poses_total} poses over the N ranks (strong scaling); the one-GPU leg of THAT "
                                   "curve is strong_base.value, not `value`")
@@ -924,14 +942,29 @@ def worker(args):
                                       "avg_us") if k in e}
         if "step_valu_wave_insts" in pm:
             evidence["step_valu_wave_insts"] = pm["step_valu_wave_insts"]
-        # What the kernel is actually held to (the counters say "valu-issue", not "hbm"): its own VALU instruction count
-        # against the chip's issue rate -- 1024 SIMDs, one 64-lane VALU instruction per 4 cycles each, 2.4 GHz.
+        # What the kernel is actually held to (the counters say "valu-issue", not "hbm"): its VALU instruction stream
+        # against the SIMDs' issue rate.  Two peaks, both from evidence under profiles/ (tools/valu_issue_bench.hip, round 4):
+        #   * the guide's FP32 rate, 2 cycles per wave64 instruction (MI355X_MICROARCH.md "Wave scheduling"; measured 2.2-2.5
+        #     for v_fma/v_mul/v_add_f32, v_mov, v_and/v_or, v_add_u32 with >= 2 waves per SIMD);
+        #   * cost-weighted: DPP moves, selects, compares, conversions, v_ldexp, min/max, 24-bit multiplies and the
+        #     3-operand integer forms take 4.25 cycles, v_rcp/v_exp 8.2 -- the kernel's own mix (tools/issue_model.py on its
+        #     disassembly, profiles/r04_issue_model.json) gives its mean cycles per instruction.
         vi = e.get("counters", {}).get("SQ_INSTS_VALU")
         if vi:
-            peak = 1024 * 2.4e9 / 4.0
+            n_simd, clk = 1024, 2.4e9
+            peak = n_simd * clk / 2.0
             issue = {"bound": "valu-issue", "wave_insts_per_launch": vi, "achieved": vi / (dom_ms * 1e-3), "peak": peak,
                      "unit": "VALU wave-instructions/s", "frac": vi / (dom_ms * 1e-3) / peak,
-                     "note": "SQ_INSTS_VALU of the committed PMC pass over the live launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles"}
+                     "note": "SQ_INSTS_VALU of the committed PMC pass over the live launch time; peak = 1024 SIMDs x 2.4 GHz / 2 "
+                             "cycles (the FP32 rate of MI355X_MICROARCH.md, confirmed by profiles/r04_valu_issue_bench.txt)"}
+            mix = issue_mix(dom)
+            if mix:
+                cyc = vi * mix["mean_cycles_per_valu"] / n_simd
+                issue["cost_weighted"] = {
+                    "mean_cycles_per_inst": mix["mean_cycles_per_valu"], "issue_cycles_per_simd": cyc,
+                    "frac": cyc / (dom_ms * 1e-3 * clk), "source": mix["source"],
+                    "note": "the kernel's instruction mix priced with the MEASURED per-instruction issue costs: the share of the "
+                            "launch its SIMDs need just to issue its VALU instructions"}
         else:
             issue = None
         if traffic is not None:
@@ -943,7 +976,7 @@ def worker(args):
     elif measured is not None:
         bound = "latency/issue (measured HBM-side traffic is %.0f %% of peak; no SQ counters committed for this workload)" % (100 * measured / HBM_PEAK_GBS)
     else:
-        bound = "hbm (no-reuse model only: no PMC summary committed for this workload)"
+        bound = "unmeasured (no PMC summary committed for this workload; the algorithmic model alone cannot name a bound)"
 
     # --- single-pose latency (BASELINE config 2): 1 pose, fwd + bwd, eager and graph-replayed ---
     hp1 = make_step(src[:1].contiguous(), dirs[:1].contiguous(), learnable=False)
@@ -1007,22 +1040,23 @@ def worker(args):
             },
             "verified": verified,
             "roofline": {
+                # measured first: `achieved` / `frac` are the HBM-side bytes of the committed PMC passes over the
+                # live launch time; the contract's no-reuse ALGORITHMIC figure sits beside them under `algorithmic`
                 "bound": bound,
                 "kernel": dom,
-                "achieved": achieved,
+                "achieved": measured,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "model": f"no-reuse algorithmic bytes, {b[dom]} B per ray-step (SURVEY §8d); `achieved` is that model over the live "
-                         "launch time, NOT bytes that crossed the HBM interface -- see measured_hbm_GBs",
+                "frac": None if measured is None else measured / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "measured_hbm_GBs": measured,
-                "measured_hbm_frac": None if measured is None else measured / HBM_PEAK_GBS,
                 "pmc_summary": pmc_file,
+                "algorithmic": {"GBs": achieved, "frac_of_peak": achieved / HBM_PEAK_GBS, "bytes_per_ray_step": b[dom],
+                                "ray_steps_per_launch": local_rs,
+                                "note": f"no-reuse model, {b[dom]} B per ray-step (SURVEY 8d) x ray-steps per launch / launch time: NOT "
+                                        "bytes that crossed the HBM interface -- a planar fan re-reads a cache-resident sheet "
+                                        "(traffic / algorithmic = %s)" % ("n/a" if traffic is None else "%.2f" % (traffic / (b[dom] * local_rs)))},
                 "issue_roofline": issue,
                 "evidence": evidence,
-                "bytes_per_ray_step": b[dom],
-                "ray_steps_per_launch": local_rs,
                 "launch_ms": dom_ms,
                 "kernels_ms": k_ms,
                 "whole_step_algorithmic_GBs": (sum(b[k] for k in kern) * local_rs) / (dt / args.steps) / 1e9,

@@ -104,10 +104,31 @@ __device__ __forceinline__ Mat mat_scale(const Mat &m, int e)
 __device__ __forceinline__ int mat_renorm(Mat &m)
 {
     float mx = fmaxf(fmaxf(fabsf(m.a), fabsf(m.b)), fmaxf(fabsf(m.c), fabsf(m.d)));
+#ifdef DIFFUS_RENORM_LDEXP // rounds 1-3: v_frexp_exp_i32_f32 + four v_ldexp_f32, 4.25 issue cycles each (tools/valu_issue_bench.hip)
     // v_frexp_exp_i32_f32 returns 0 for +-0, inf and NaN: no branch needed, ldexp(x, 0) is a no-op
     int ex = __builtin_amdgcn_frexp_expf(mx);
     m = mat_scale(m, -ex);
     return ex;
+#else
+    // The scale 2^-ex as a float, straight from mx's exponent field (two full-rate integer instructions), and four
+    // full-rate multiplies: exact like ldexp (a power of two; the products stay normal: mx 2^-ex is in [0.5, 1)).
+    // ex = biased exponent - 126 is frexp's exponent for every normal mx.  mx = 0 (an all-zero matrix) scales zeros by
+    // 2^126 and reports -126, a NaN matrix stays NaN -- both only ever meet zeros / NaNs downstream; a matrix that has
+    // overflowed to infinity was garbage before and is garbage after.
+    const unsigned e23 = __float_as_uint(mx) & 0x7f800000u;
+    const float sc = __uint_as_float(0x7e800000u - e23);
+    m.a *= sc; m.b *= sc; m.c *= sc; m.d *= sc;
+    return (int)(e23 >> 23) - 126;
+#endif
+}
+
+// a * b with DX9 rules: 0 * anything (NaN and infinity included) = 0, an IEEE product otherwise.  One full-rate
+// instruction where `a != 0 ? a * b : 0` is a compare and a select (4.25 issue cycles each, tools/valu_issue_bench.hip).
+__device__ __forceinline__ float mul_legacy(float a, float b)
+{
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 __device__ __forceinline__ bool finitef(float x) { return fabsf(x) < __builtin_inff(); }
@@ -181,6 +202,25 @@ template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ Mat mat_dpp_get(const Mat &m)
 {
     return Mat{dpp_get<CTRL, ROW_MASK>(m.a), dpp_get<CTRL, ROW_MASK>(m.b), dpp_get<CTRL, ROW_MASK>(m.c), dpp_get<CTRL, ROW_MASK>(m.d)};
+}
+// The scans' fetch with the operation's IDENTITY where a lane has no source (lower rows of a row_shr round, rows a
+// row_mask leaves out): the round then multiplies in every lane and needs no select afterwards -- a v_cndmask costs 4.25
+// issue cycles like the DPP move itself, a v_mov of the constant 2.25 (tools/valu_issue_bench.hip), and with a full row
+// mask the zeros of the identity come from bound_ctrl for nothing.  1 * a + 0 * c is a exactly (c finite).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ Mat mat_dpp_ident(const Mat &m)
+{
+    if constexpr (ROW_MASK == 0xf)
+        return Mat{dpp_mov<CTRL>(1.f, m.a), dpp_get<CTRL>(m.b), dpp_get<CTRL>(m.c), dpp_mov<CTRL>(1.f, m.d)};
+    else
+        return Mat{dpp_mov<CTRL, ROW_MASK>(1.f, m.a), dpp_mov<CTRL, ROW_MASK>(0.f, m.b), dpp_mov<CTRL, ROW_MASK>(0.f, m.c),
+                   dpp_mov<CTRL, ROW_MASK>(1.f, m.d)};
+}
+// ... and for sums: 0 where there is no source (folds into one v_add_u32_dpp)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_get0(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
 }
 __device__ __forceinline__ float lane_bcast(float v, int srclane) // wave-uniform value of one lane (v_readlane_b32)
 {
@@ -410,6 +450,31 @@ __device__ __forceinline__ Axis tri_axis(float p, int dim)
     return a;
 }
 
+// The same cell for the fused gathers, cheaper by what the measured issue costs say (tools/valu_issue_bench.hip: compares,
+// selects, v_floor, conversions and integer min/max cost 4.25 cycles, FP32 add/sub 2.25):
+//   * t = fract(pc) (one instruction; pc >= 0, so pc - floor(pc) is exact and below 1: the same bits), i0 = trunc(pc);
+//   * the border rule "no gradient where p <= 0 or p >= dim - 1" needs a test at the LOW side only: at the high side the
+//     upper neighbour is the clamped cell itself (i1 = i0, or the repeated entry of a PAIRED record), so the difference
+//     is an exact 0 by itself (NaN where the voxel is not finite -- as 0 * NaN was).  `lo` = p > 0 (false for NaN);
+// (Addressing the cell itself as its own upper neighbour at the low side would make that difference an exact 0 too, but
+// then a non-finite voxel next to the border no longer reaches the value as 0 * NaN = NaN, as it does in grid_sample.)
+struct AxisG {
+    int i0, i1;
+    float t;
+    bool lo;
+};
+__device__ __forceinline__ AxisG tri_axis_g(float p, int dim)
+{
+    AxisG a;
+    const float hi = (float)(dim - 1);
+    const float pc = __builtin_amdgcn_fmed3f(p, 0.f, hi);
+    a.lo = p > 0.f;
+    a.i0 = (int)pc;
+    a.t = __builtin_amdgcn_fractf(pc);
+    a.i1 = min(a.i0 + 1, dim - 1);
+    return a;
+}
+
 struct __attribute__((packed, aligned(4))) F2 {
     float x, y;
 };
@@ -524,6 +589,7 @@ struct Args {
     int accum_pose;    // backward: add to (instead of overwrite) the per-ray pose-gradient partials
     float neg_alpha;     // -alpha
     float neg_alpha_l2e; // -alpha * log2(e): attenuation = exp2(neg_alpha_l2e * n), one multiply in front of v_exp_f32
+    float att_step[16]; // exp2(neg_alpha_l2e * j), j = 0..15 (host: make_args) -- chunk_attenuation() under -DDIFFUS_ATT_STEPS
     // forward
     float *frame;
     long long *idx;
@@ -583,6 +649,26 @@ __device__ __forceinline__ void block_sums(float (&a)[N], float *sm)
         for (int w = 0; w < nw; ++w) t += sm[n * nw + w];
         a[n] = t;
     }
+}
+
+// exp(-alpha * n) for the C consecutive samples n = first .. first + C - 1 of a lane (reference src/renderer.py:256-259).
+// Default: one v_exp_f32 per sample.  -DDIFFUS_ATT_STEPS: exp2(a * first) * exp2(a * j) with the second factor from the
+// kernel arguments -- 85 issue cycles fewer per wave of the adjoint scan and within 2 ulp of the direct form, but another
+// rounding: the volume gradient of a short nearest-sampled ray (hundreds of signed terms cancelling on one border voxel)
+// moved from 3.45e-4 to 3.66e-4 of its float64 value (tools/diag_grad_noise.py), which put one parity case
+// (test_backward_vs_float64_autograd[150-0-nearest]) at 1.10e-3 against its 1e-3.  Not taken.
+template <int C>
+__device__ __forceinline__ void chunk_attenuation(const Args &A, int first, float (&att)[C])
+{
+    static_assert(C <= 16, "att_step holds 16 factors");
+#ifndef DIFFUS_ATT_STEPS
+#pragma unroll
+    for (int j = 0; j < C; ++j) att[j] = fast_exp2(A.neg_alpha_l2e * (float)(first + j));
+#else
+    const float e0 = fast_exp2(A.neg_alpha_l2e * (float)first);
+#pragma unroll
+    for (int j = 0; j < C; ++j) att[j] = (j == 0) ? e0 : e0 * A.att_step[j];
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -651,21 +737,38 @@ struct __attribute__((aligned(4))) F4a4 {
 struct __attribute__((aligned(4))) F2a4 {
     float x, y;
 };
-template <int C>
+// STREAM: the row is written once and read by a LATER kernel (frame rows, zbar): a non-temporal store goes through the L2
+// instead of leaving 33 MB of dirty lines for the end-of-kernel release to write back -- one-pass scan at config 3
+// 29.3 -> 28.0 us (tools/time_step.py).
+typedef float V4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float V2a4 __attribute__((ext_vector_type(2), aligned(4)));
+template <int C, bool STREAM = false>
 __device__ __forceinline__ void store_chunk(float *__restrict__ row, int n0, int segN, const float (&v)[C])
 {
     if (n0 + C <= segN) {
         if constexpr (C >= 4) {
 #pragma unroll
-            for (int q = 0; q < C / 4; ++q)
-                *reinterpret_cast<F4a4 *>(row + n0 + 4 * q) = F4a4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            for (int q = 0; q < C / 4; ++q) {
+                if constexpr (STREAM)
+                    __builtin_nontemporal_store(V4a4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}, reinterpret_cast<V4a4 *>(row + n0 + 4 * q));
+                else
+                    *reinterpret_cast<F4a4 *>(row + n0 + 4 * q) = F4a4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            }
         } else {
-            *reinterpret_cast<F2a4 *>(row + n0) = F2a4{v[0], v[1]};
+            if constexpr (STREAM)
+                __builtin_nontemporal_store(V2a4{v[0], v[1]}, reinterpret_cast<V2a4 *>(row + n0));
+            else
+                *reinterpret_cast<F2a4 *>(row + n0) = F2a4{v[0], v[1]};
         }
     } else {
 #pragma unroll
         for (int j = 0; j < C; ++j)
-            if (n0 + j < segN) row[n0 + j] = v[j];
+            if (n0 + j < segN) {
+                if constexpr (STREAM)
+                    __builtin_nontemporal_store(v[j], row + n0 + j);
+                else
+                    row[n0 + j] = v[j];
+            }
     }
 }
 template <int C>
@@ -724,23 +827,26 @@ __device__ __forceinline__ unsigned part_z(int z)
 // VALU-issue-bound).  Same trilinear polynomial, other rounding: <= 2e-7 relative from the oracle's sequence, inside the
 // 1e-5 frame tolerance; the stage-wise kernels (tri_sample) keep the oracle's exact sequence.
 typedef float V2f __attribute__((ext_vector_type(2)));
+// keep0/1/2: false where the border rule must zero that gradient component and the difference is not an exact 0 by
+// itself (tri_axis_g: only the low side of an axis whose upper neighbour is not addressed separately)
 template <bool GRAD>
-__device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], const Axis &a, const Axis &b, const Axis &c)
+__device__ __forceinline__ TriSample tri_lerp(const float (&v)[8], float at, float bt, float ct, bool keep0, bool keep1, bool keep2)
 {
     const V2f r0a = {v[0], v[1]}, r0b = {v[2], v[3]}, r1a = {v[4], v[5]}, r1b = {v[6], v[7]}; // (x, y): its (z0, z1)
-    const V2f ta = {a.t, a.t}, tb = {b.t, b.t};
+    const V2f ta = {at, at}, tb = {bt, bt};
     const V2f da = r1a - r0a, db = r1b - r0b;                                   // d/d dim0 at y0, y1
     const V2f xa = __builtin_elementwise_fma(ta, da, r0a), xb = __builtin_elementwise_fma(ta, db, r0b);
     const V2f ey = xb - xa;                                                     // d/d dim1 at z0, z1
     const V2f yv = __builtin_elementwise_fma(tb, ey, xa);
     const float ez = yv.y - yv.x;                                               // d/d dim2
     TriSample s;
-    s.v = __builtin_fmaf(c.t, ez, yv.x);
+    s.v = __builtin_fmaf(ct, ez, yv.x);
     if (GRAD) {
         const V2f dy = __builtin_elementwise_fma(tb, db - da, da);
-        s.g0 = __builtin_fmaf(c.t, dy.y - dy.x, dy.x) * a.m;
-        s.g1 = __builtin_fmaf(c.t, ey.y - ey.x, ey.x) * b.m;
-        s.g2 = ez * c.m;
+        const float g0 = __builtin_fmaf(ct, dy.y - dy.x, dy.x), g1 = __builtin_fmaf(ct, ey.y - ey.x, ey.x);
+        s.g0 = keep0 ? g0 : 0.f;
+        s.g1 = keep1 ? g1 : 0.f;
+        s.g2 = keep2 ? ez : 0.f;
     } else {
         s.g0 = s.g1 = s.g2 = 0.f;
     }
@@ -794,7 +900,7 @@ __device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, in
     for (int gb = 0; gb < C; gb += G) {
         float raw[G][NV];
         float ta[G], tb[G], tc[G]; // interpolation weights, kept for phase B
-        unsigned mk[G];            // border-rule bits of the three axes (gradient only)
+        bool k0[G], k1[G], k2[G];  // border rule per axis (gradient only): false = zero that component
         // ---- phase A: addresses + loads
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) {
@@ -807,7 +913,7 @@ __device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, in
                 int i0 = nearest_index(p0, A.G.d0), i1 = nearest_index(p1, A.G.d1), i2 = nearest_index(p2, A.G.d2);
                 raw[jj][0] = ldb_f32(vol, part_x<LAYOUT>(A.G, i0) + part_y<LAYOUT>(A.G, i1) + part_z<LAYOUT>(i2));
             } else {
-                Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1), c = tri_axis(p2, A.G.d2);
+                const AxisG a = tri_axis_g(p0, A.G.d0), b = tri_axis_g(p1, A.G.d1), c = tri_axis_g(p2, A.G.d2);
                 const unsigned x0 = part_x<LAYOUT>(A.G, a.i0), x1 = part_x<LAYOUT>(A.G, a.i1);
                 const unsigned y0 = part_y<LAYOUT>(A.G, b.i0), y1 = part_y<LAYOUT>(A.G, b.i1);
                 const unsigned z0 = part_z<LAYOUT>(c.i0);
@@ -861,37 +967,34 @@ __device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, in
 #endif
                 }
                 ta[jj] = a.t; tb[jj] = b.t; tc[jj] = c.t;
-                if (GRAD) mk[jj] = (a.m != 0.f ? 1u : 0u) | (b.m != 0.f ? 2u : 0u) | (c.m != 0.f ? 4u : 0u);
+                if (GRAD) { // the low-side tests, as lane masks (SGPR pairs: they cost no VGPR)
+                    k0[jj] = a.lo; k1[jj] = b.lo; k2[jj] = c.lo;
+                }
             }
         }
         // ---- phase B: interpolation
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) {
             const int j = gb + jj;
-            const bool live = j * kWave + lane < segN;
+            // Samples past the end of the ray (j * 64 + lane >= segN) keep whatever their clamped re-read gave: every
+            // consumer masks by the sample index itself (reflect_chunk: r = 0 there; the frame, zbar, loss and
+            // pose-gradient sums: n < segN) and drops non-finite products, so no select is spent on them here (it was
+            // four v_cndmask per sample, 4.25 cycles each: tools/valu_issue_bench.hip).
+            (void)segN;
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
-                z[j] = live ? raw[jj][0] : 1.f;
+                z[j] = raw[jj][0];
                 if (GRAD) g0[j] = g1[j] = g2[j] = 0.f;
             } else {
-                Axis a, b, c;
-                a.t = ta[jj]; b.t = tb[jj]; c.t = tc[jj];
-                if (GRAD) {
-                    a.m = (mk[jj] & 1u) ? 1.f : 0.f;
-                    b.m = (mk[jj] & 2u) ? 1.f : 0.f;
-                    c.m = (mk[jj] & 4u) ? 1.f : 0.f;
-                }
 #ifdef DIFFUS_ABLATE_LERP
                 TriSample sm;
-                sm.v = raw[jj][0] + raw[jj][1] + raw[jj][2] + raw[jj][3] + raw[jj][4] + raw[jj][5] + raw[jj][6] + raw[jj][7] + a.t + b.t + c.t;
+                sm.v = raw[jj][0] + raw[jj][1] + raw[jj][2] + raw[jj][3] + raw[jj][4] + raw[jj][5] + raw[jj][6] + raw[jj][7] + ta[jj] + tb[jj] + tc[jj];
                 sm.g0 = sm.g1 = sm.g2 = 0.f;
 #else
-                TriSample sm = tri_lerp<GRAD>(raw[jj], a, b, c);
+                TriSample sm = tri_lerp<GRAD>(raw[jj], ta[jj], tb[jj], tc[jj], GRAD ? k0[jj] : true, GRAD ? k1[jj] : true, GRAD ? k2[jj] : true);
 #endif
-                z[j] = live ? sm.v : 1.f;
+                z[j] = sm.v;
                 if (GRAD) {
-                    g0[j] = live ? sm.g0 : 0.f;
-                    g1[j] = live ? sm.g1 : 0.f;
-                    g2[j] = live ? sm.g2 : 0.f;
+                    g0[j] = sm.g0; g1[j] = sm.g1; g2[j] = sm.g2;
                     // Materialise the three gradient components HERE.  Left alone, LLVM sinks these lerps down to
                     // their only use (the pose-gradient sum at the end of the backward) and keeps the 8 corner values
                     // and 3 weights of every sample alive across the whole scan instead: 15 registers per sample, not 3
@@ -923,16 +1026,20 @@ __device__ __forceinline__ void gather_interleaved(const Args &A, int seg0, int 
 // (n = lane*C+j).  r = 0 (identity transfer matrix) for n = 0 and n >= N1; with
 // start > 0 the first kept coefficient is replaced by the per-pose median
 // (reference :243-244).
+// inv_out (optional): 1 / (Z_{n-1} + Z_n) of every sample as the reflection coefficient used it (the backward needs it
+// again for d r / d Z: a second v_rcp_f32 per sample is 8.2 issue cycles, an LDS round trip of the chunk is four slots)
 template <int C>
 __device__ __forceinline__ void reflect_chunk(const Args &A, int seg0, int segN, int n0, const float (&z)[C], float zprev, float medv,
-                                              float (&r)[C])
+                                              float (&r)[C], float *inv_out = nullptr)
 {
     // n0 = lane*C is the segment-local index of the lane's first sample; the global cropped index is seg0 + n0 + j
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         int nl = n0 + j, n = seg0 + nl;
         float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
-        float v = reflect_fast(zp, z[j]);
+        const float inv = __builtin_amdgcn_rcpf(zp + z[j]);
+        float v = (z[j] - zp) * inv; // = reflect_fast(zp, z[j])
+        if (inv_out) inv_out[j] = inv;
         if (n == 1 && A.start > 0) v = medv;
         r[j] = (n >= 1 && nl < segN) ? v : 0.f;
     }
@@ -962,13 +1069,11 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
         if (!FAST || (j & 3) == 3 || j == C - 1) mat_renorm(L);
     }
     {
-#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)         \
-    {                                              \
-        const Mat o = mat_dpp_get<CTRL, RMASK>(L); \
-        if (HAS) {                                 \
-            L = mat_mul(o, L);                     \
-            if (RN) mat_renorm(L);                 \
-        }                                          \
+#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)           \
+    {                                                \
+        const Mat o = mat_dpp_ident<CTRL, RMASK>(L); \
+        L = mat_mul(o, L);                           \
+        if (RN) mat_renorm(L);                       \
     }
         DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
 #undef DIFFUS_ROUND

@@ -2,6 +2,8 @@
 // validation, (sampler, layout) -> template dispatch, and the per-pose median kernel that both the
 // forward and the backward launch when start > 0.
 #pragma once
+#include <cmath>
+
 #include "diffus_device.hpp"
 
 namespace {
@@ -127,6 +129,7 @@ Args make_args(const float *vol, int d0, int d1, int d2, int layout, const void 
     A.seg0 = 0; A.segN = A.N1; // one launch covers the ray unless the caller loops over segments
     A.neg_alpha = -alpha;
     A.neg_alpha_l2e = (float)(-(double)alpha * 1.4426950408889634);
+    for (int j = 0; j < 16; ++j) A.att_step[j] = exp2f(A.neg_alpha_l2e * (float)j);
     A.med = ws.med; A.who = ws.who; A.gmed = ws.gmed; A.medinfo = ws.medinfo;
     return A;
 }

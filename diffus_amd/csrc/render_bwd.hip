@@ -38,8 +38,18 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
 // W_n = 2^{e_n-e_{n-1}} (Gbar'_n + U'_n):  Tbar_n = P'_{n-1}^T W_n,  U'_{n-1} = W_n T_n^T.
 // The chunk of one lane is an affine map U_in -> U_out; lanes are combined with a
 // reverse Hillis-Steele scan of affine maps (A, B, beta):  X -> A + X (B 2^beta)^T.
+#ifdef DIFFUS_COUNT_FAST_ONLY // static analysis only (tools/issue_model.py): the rare wave-uniform repair passes compiled out
+#define DIFFUS_RARE(cond) false
+#else
+#define DIFFUS_RARE(cond) (cond)
+#endif
+// Waves per SIMD the C = 8 kernels of a bricked / paired volume are compiled for.  4 = a 128-VGPR budget: the kernel is
+// VALU-issue-bound (its time is resident waves x issue cycles), sits at 126-138 registers depending on what the
+// register allocator makes of the last change, and three waves per SIMD instead of four is a quarter of the chip idle in
+// every generation of waves -- a handful of spilled dwords is the cheaper side of that.  (Canonical volumes -- eight
+// address registers per sample in flight -- stay at the compiler's choice: forced to 128 they spill 41 dwords.)
 #ifndef DIFFUS_BWD_MIN_WAVES
-#define DIFFUS_BWD_MIN_WAVES 1
+#define DIFFUS_BWD_MIN_WAVES 4
 #endif
 #ifndef DIFFUS_SPLIT_MIN_WAVES // SPLIT kernels: 3 waves per SIMD, 139 VGPRs, no scratch.  (Forced to 4 waves = 128 VGPRs the
 #define DIFFUS_SPLIT_MIN_WAVES 3 // compiler spills 15 dwords: one-pass scan 42.5 against 43.5 us at the config-5 shape, whole step 98.5 against 96 -- a wash; the spill-free build is kept)
@@ -52,7 +62,7 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
 // a lane's serial sweeps are twice as long; two C = 8 waves need 126 each (4 per SIMD) and overlap their gathers,
 // local products, scans and epilogues -- only the second half's adjoint has to finish before the first half's.
 template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM, bool SEG = false, int SPLIT = 1>
-__global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (C <= 8 ? DIFFUS_BWD_MIN_WAVES : 1))) void render_bwd_kernel(Args A)
+__global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : ((C == 8 && LAYOUT != DIFFUS_CANONICAL) ? DIFFUS_BWD_MIN_WAVES : 1))) void render_bwd_kernel(Args A)
 {
     static_assert(SPLIT == 1 || (SPLIT == 2 && WPB == 2 && !SEG), "SPLIT: one ray per block of two waves");
     __shared__ float s_c[5], s_u[4], s_zc, s_pg[6]; // SPLIT exchange: forward carry, adjoint carry, zbar boundary term, pose-gradient partials
@@ -70,7 +80,10 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     float *const uout = SEG ? A.uout + (A.uout ? w * 4 : 0) : ((SPLIT > 1 && part == 1) ? s_u : nullptr);
     float *const zcout = SEG ? A.zcout + (A.zcout ? w : 0) : ((SPLIT > 1 && part == 1) ? &s_zc : nullptr);
     const bool accum_pose = SEG && A.accum_pose;
-    __shared__ __attribute__((aligned(16))) float lds[WPB][kWave * C];
+    // per wave: the INTERLEAVED <-> CHUNKED transpose buffer (64 C floats), reused afterwards -- together with a second
+    // half -- to park d r / d Z_n and d r / d Z_{n-1} of every sample (lane-private 16-byte slots) from the reflection
+    // step to the zbar step at the very end: the samples themselves then die before the scans (8 + 1 registers)
+    __shared__ __attribute__((aligned(16))) float lds[WPB][2 * kWave * C];
     constexpr bool KEEP_GRAD = GPOSE && (C < 16); // C = 16: re-gather at the end instead of 12 KiB more LDS per wave
     __shared__ __attribute__((aligned(16))) float stash[KEEP_GRAD ? WPB : 1][KEEP_GRAD ? 3 * kWave * C : 4];
     const int lane = threadIdx.x & 63;
@@ -141,8 +154,10 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
             }
         }
         if (A.mse != 2) { // (the one-pass step forms dL/dframe, attenuation included, in the forward sweep below)
+            float att[C];
+            chunk_attenuation<C>(A, seg0 + n0, att);
 #pragma unroll
-            for (int j = 0; j < C; ++j) gb[j] *= fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
+            for (int j = 0; j < C; ++j) gb[j] *= att[j];
         }
     }
     float zprev = lane_prev(z[C - 1], z[C - 1]);
@@ -152,7 +167,33 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     }
     if (cin && lane == 0) zprev = cin[4]; // last sample of the previous segment
     const float medv = (A.start > 0) ? A.med[pose] : 0.f;
-    reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r);
+    {
+        // d r / d Z_n = 2 Z_{n-1} / (Z_{n-1} + Z_n)^2 and d r / d Z_{n-1} = -2 Z_n / (...)^2 (reference :33) are formed HERE,
+        // where the samples and the reciprocal of their sum are at hand, and wait in LDS for the zbar step
+        float inv[C], dzn[C], dzp[C];
+        reflect_chunk<C>(A, seg0, segN, n0, z, zprev, medv, r, inv);
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
+            dzn[j] = 2.f * zp * inv[j] * inv[j];
+            dzp[j] = -2.f * z[j] * inv[j] * inv[j];
+        }
+        float *pk = wb + 2 * n0;
+        if constexpr (C >= 4) {
+            float4 *q = reinterpret_cast<float4 *>(pk);
+#pragma unroll
+            for (int t = 0; t < C / 4; ++t) {
+                q[t] = make_float4(dzn[4 * t], dzn[4 * t + 1], dzn[4 * t + 2], dzn[4 * t + 3]);
+                q[C / 4 + t] = make_float4(dzp[4 * t], dzp[4 * t + 1], dzp[4 * t + 2], dzp[4 * t + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                pk[j] = dzn[j];
+                pk[C + j] = dzp[j];
+            }
+        }
+    }
     STAMPB(2);
 
     // ---- forward recompute with exponent tracking ----
@@ -168,14 +209,13 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     int iota = lam;       // inclusive prefix exponent
     {
         // six scan rounds on the DPP path (diffus_device.hpp): matrix and exponent move together
-#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)               \
-    {                                                    \
-        const Mat o = mat_dpp_get<CTRL, RMASK>(L);       \
-        const int oe = dpp_get<CTRL, RMASK>(iota);       \
-        if (HAS) {                                       \
-            L = mat_mul(o, L);                           \
-            iota = oe + iota - (RN ? mat_renorm(L) : 0); \
-        }                                                \
+        // (a lane without a source gets the identity and exponent 0, diffus_device.hpp mat_dpp_ident: no selects)
+#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)                                     \
+    {                                                                          \
+        const Mat o = mat_dpp_ident<CTRL, RMASK>(L);                           \
+        iota += dpp_get0<CTRL, RMASK>(iota);                                   \
+        L = mat_mul(o, L);                                                     \
+        if (RN) iota -= mat_renorm(L);                                         \
     }
         DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
 #undef DIFFUS_ROUND
@@ -200,38 +240,72 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     float rho[C];
     int esum = 0;
     float ssq2 = 0.f; // one-pass step: this lane's share of sum((frame - target)^2)
+    float att_c[C];   // attenuation of the lane's samples (one-pass step only)
+    if (A.mse == 2) chunk_attenuation<C>(A, seg0 + n0, att_c);
+    // FILTER = true is the loop as the arithmetic defines it.  FILTER = false leaves out everything that only matters when
+    // an echo or a seed is not finite -- nan_to_num on the echo, the finite tests of the seed: a compare or a select each, 4.25
+    // issue cycles apiece, six per sample -- and reports through `poison` (x * 0: 0 for finite x, NaN otherwise) whether
+    // that was legitimate; if not for any lane of the wave, the filtering loop runs again from the same prefix (rare).
+    // One-pass step: the frame row replaces the target row in tg as it is formed (no second array alive across the loop);
+    // the repair pass loads the target row again.
+    auto seeds_pass = [&](auto filter_, const Mat Pstart) -> float {
+        constexpr bool FILTER = decltype(filter_)::value;
+        float poison = 0.f;
+        Pm = Pstart;
+        esum = 0;
+        ssq2 = 0.f;
+        if (FILTER && A.mse == 2) { // the first pass has overwritten the target row with its frame
+            if (A.target) {
+                load_chunk<C>(A.target + w * A.N1 + seg0, n0, segN, tg);
+            } else {
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        Pin[j] = Pm;
-        Pm = mat_step(Pm, r[j]);
-        ex[j] = ((j & 3) == 3 || j == C - 1) ? mat_renorm(Pm) : 0; // compile-time schedule: the zeros fold away
-        esum += ex[j];
-        const float rd = __builtin_amdgcn_rcpf(Pm.d);
-        const float e = Pm.b * rd;
-        const bool num = (e == e);         // echoes zeroed by nan_to_num are constants: no gradient through them
-        if (A.mse == 2) {
-            // ONE-PASS STEP (diffus_render_step_mse): the echo just recomputed IS the forward's (render_fwd_kernel's
-            // arithmetic; only the association of the scan may differ -- chunk length, two waves per ray -- i.e. the
-            // last bits), so the frame, the loss term and dL/dframe are formed right here and the separate forward
-            // launch -- a second gather of every sample -- is not needed.
-            const float att = fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
-            const float fr = (n0 + j < segN) ? __fmul_rn(num ? e : 0.f, att) : 0.f;
-            const float dlt = fr - tg[j]; // tg is 0 past the end of the row
-            ssq2 = __builtin_fmaf(dlt, dlt, ssq2);
-            gb[j] = (2.f * A.loss_scale) * dlt * att;
-            tg[j] = fr; // the frame row, stored after the loop
+                for (int j = 0; j < C; ++j) tg[j] = 0.f;
+            }
         }
-        const float q = (num ? gb[j] : 0.f) * rd;
-        rho[j] = num ? e : 0.f;
-        // Nothing but a finite seed may enter the adjoint chain (a NaN in U would wipe out every earlier step as well).
-        // Two compares are enough: a non-finite r or P'_{n-1} makes P'_n -- hence e or q -- non-finite too, an infinite
-        // echo fails the second test, and 0 * inf = NaN fails the first.  (Per-entry tests of r and P'_{n-1} here
-        // were 6 more compares and a branch per sample.)
-        gu[j] = (finitef(q) && finitef(e)) ? q : 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            Pin[j] = Pm;
+            Pm = mat_step(Pm, r[j]);
+            ex[j] = ((j & 3) == 3 || j == C - 1) ? mat_renorm(Pm) : 0; // compile-time schedule: the zeros fold away
+            esum += ex[j];
+            const float rd = __builtin_amdgcn_rcpf(Pm.d);
+            const float e = Pm.b * rd;
+            const bool num = FILTER ? (e == e) : true; // echoes zeroed by nan_to_num are constants: no gradient through them
+            float g = gb[j];
+            if (A.mse == 2) {
+                // ONE-PASS STEP (diffus_render_step_mse): the echo just recomputed IS the forward's (render_fwd_kernel's
+                // arithmetic; only the association of the scan may differ -- chunk length, two waves per ray -- i.e. the
+                // last bits), so the frame, the loss term and dL/dframe are formed right here and the separate forward
+                // launch -- a second gather of every sample -- is not needed.
+                const float att = att_c[j];
+                const float fr = (n0 + j < segN) ? __fmul_rn(num ? e : 0.f, att) : 0.f;
+                const float dlt = fr - tg[j]; // tg is 0 past the end of the row
+                ssq2 = __builtin_fmaf(dlt, dlt, ssq2);
+                g = (2.f * A.loss_scale) * dlt * att;
+                tg[j] = fr; // the frame row, stored after the loop
+            }
+            const float q = g * rd; // (an echo zeroed by nan_to_num fails the finite test of e below: no select needed here)
+            rho[j] = num ? e : 0.f;
+            // Nothing but a finite seed may enter the adjoint chain (a NaN in U would wipe out every earlier step as well).
+            // Two compares are enough: a non-finite r or P'_{n-1} makes P'_n -- hence e or q -- non-finite too, an infinite
+            // echo fails the second test, and 0 * inf = NaN fails the first.  (Per-entry tests of r and P'_{n-1} here
+            // were 6 more compares and a branch per sample.)
+            if (FILTER) {
+                gu[j] = (finitef(q) && finitef(e)) ? q : 0.f;
+            } else {
+                gu[j] = q;
+                poison = __builtin_fmaf(q, 0.f, __builtin_fmaf(e, 0.f, poison));
+            }
+        }
+        return poison;
+    };
+    {
+        const float poison = seeds_pass(std::false_type{}, Pm);
+        if (DIFFUS_RARE(__builtin_amdgcn_ballot_w64(poison != 0.f) != 0ull)) seeds_pass(std::true_type{}, Pin[0]); // wave-uniform; Pin[0] = the prefix the first pass started from
     }
 
     if (A.mse == 2) {
-        if (A.frame) store_chunk<C>(A.frame + w * A.N1 + seg0, n0, segN, tg);
+        if (A.frame) store_chunk<C, true>(A.frame + w * A.N1 + seg0, n0, segN, tg);
         ssq2 = wave_sum_to_lane63(ssq2);
         if (lane == kWave - 1) {
             float *lp = A.loss_part + w * 2 + part;
@@ -246,9 +320,23 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     STAMPB(4);
 
     // ---- lane-local affine map: A-part = sweep from U = 0 ----
+    // Filters against non-finite values cost a compare and a select each (4.25 issue cycles apiece, tools/valu_issue_bench.hip)
+    // on values that are finite in all but degenerate volumes.  Where the filter is the identity for finite input, the
+    // wave first asks whether ANY of its values is non-finite -- x * 0 is 0 for a finite x and NaN otherwise, one
+    // full-rate multiply-add per value into a running "poison" -- and only then runs the filtering pass (wave-uniform).
     float rr[C]; // r with non-finite steps cut (U is zero there anyway)
+    {
+        float poison = 0.f;
 #pragma unroll
-    for (int j = 0; j < C; ++j) rr[j] = finitef(r[j]) ? r[j] : 0.f;
+        for (int j = 0; j < C; ++j) {
+            rr[j] = r[j];
+            poison = __builtin_fmaf(r[j], 0.f, poison);
+        }
+        if (DIFFUS_RARE(__builtin_amdgcn_ballot_w64(poison != 0.f) != 0ull)) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) rr[j] = finitef(r[j]) ? r[j] : 0.f;
+        }
+    }
     auto sweep = [&](Mat U, float *rbar) {
 #pragma unroll
         for (int j = C - 1; j >= 0; --j) {
@@ -349,28 +437,58 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
 #pragma unroll
     for (int j = 0; j < C; ++j) zbar[j] = 0.f;
     float carry = 0.f, gmed_lane = 0.f;
+    float dzn[C], dzp[C]; // d r / d Z_n, d r / d Z_{n-1}: parked by the reflection step (same lane wrote them: no synchronisation)
+    {
+        const float *pk = wb + 2 * n0;
+        if constexpr (C >= 4) {
+            const float4 *q = reinterpret_cast<const float4 *>(pk);
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        int n = seg0 + n0 + j;
-        bool live = (n >= 1 && n0 + j < segN);
-        float rb = live ? rbar[j] : 0.f;
-        if (n == 1 && A.start > 0) { // the first kept coefficient is the per-pose median: its gradient goes there
-            gmed_lane = finitef(rb) ? rb : 0.f;
-            rb = 0.f;
+            for (int t = 0; t < C / 4; ++t) {
+                const float4 v = q[t], u = q[C / 4 + t];
+                dzn[4 * t] = v.x; dzn[4 * t + 1] = v.y; dzn[4 * t + 2] = v.z; dzn[4 * t + 3] = v.w;
+                dzp[4 * t] = u.x; dzp[4 * t + 1] = u.y; dzp[4 * t + 2] = u.z; dzp[4 * t + 3] = u.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                dzn[j] = pk[j];
+                dzp[j] = pk[C + j];
+            }
         }
-        float zp = (j == 0) ? zprev : z[j == 0 ? 0 : j - 1];
-        float s = zp + z[j];
-        float inv = __builtin_amdgcn_rcpf(s);
-        float dz = 2.f * zp * inv * inv;     // d r / d Z_n
-        float dzp = -2.f * z[j] * inv * inv; // d r / d Z_{n-1}
-        float c1 = rb * dz, c0 = rb * dzp;
-        if (!finitef(c1)) c1 = 0.f; // drop non-finite contributions (a non-finite rbar makes both of them so)
-        if (!finitef(c0)) c0 = 0.f;
-        zbar[j] += c1;
-        if (j == 0)
-            carry = c0;
-        else
-            zbar[j == 0 ? 0 : j - 1] += c0;
+    }
+    // (FILTER = false: the pass without the per-contribution finite tests; its poison says whether it may stand)
+    auto zbar_pass = [&](auto filter_) -> float {
+        constexpr bool FILTER = decltype(filter_)::value;
+        float poison = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) zbar[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            int n = seg0 + n0 + j;
+            bool live = (n >= 1 && n0 + j < segN);
+            float rb = live ? rbar[j] : 0.f;
+            if (n == 1 && A.start > 0) { // the first kept coefficient is the per-pose median: its gradient goes there
+                gmed_lane = finitef(rb) ? rb : 0.f;
+                rb = 0.f;
+            }
+            float c1 = rb * dzn[j], c0 = rb * dzp[j];
+            if (FILTER) {
+                if (!finitef(c1)) c1 = 0.f; // drop non-finite contributions (a non-finite rbar makes both of them so)
+                if (!finitef(c0)) c0 = 0.f;
+            } else {
+                poison = __builtin_fmaf(c1, 0.f, __builtin_fmaf(c0, 0.f, poison));
+            }
+            zbar[j] += c1;
+            if (j == 0)
+                carry = c0;
+            else
+                zbar[j == 0 ? 0 : j - 1] += c0;
+        }
+        return poison;
+    };
+    {
+        const float poison = zbar_pass(std::false_type{});
+        if (DIFFUS_RARE(__builtin_amdgcn_ballot_w64(poison != 0.f) != 0ull)) zbar_pass(std::true_type{}); // wave-uniform, rare
     }
     const float cnb = lane_next0(carry);
     if (lane != kWave - 1) zbar[C - 1] += cnb;
@@ -391,7 +509,7 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     // ---- hand zbar to the scatter kernel, reduce the pose gradient: both from the CHUNKED mapping ----
     // The volume scatter is a separate launch (scatter_patch_kernel): its thread <-> sample
     // mapping is chosen for LDS privatisation, not for the scan.
-    if (A.zbar) store_chunk<C>(A.zbar + w * A.N1 + seg0, n0, segN, zbar);
+    if (A.zbar) store_chunk<C, true>(A.zbar + w * A.N1 + seg0, n0, segN, zbar);
     STAMPB(8);
     if (GPOSE) {
         float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
@@ -430,12 +548,13 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
                     g0 = sm.g0; g1 = sm.g1; g2 = sm.g2;
                 }
             }
-            // branch-free (selects): nothing flows where zbar is 0 -- past the end of the row, and where the gradient
-            // was dropped, whatever the spatial gradient is there (it may be NaN next to NaN voxels)
-            const float zb = (n < segN) ? zbar[j] : 0.f;
-            const bool on = zb != 0.f;
+            // Nothing flows where zbar is 0 -- past the end of the row (rbar is masked there and non-finite products are
+            // dropped, so zbar IS 0) and where the gradient was dropped -- whatever the spatial gradient is there (it may be
+            // NaN next to NaN voxels): v_mul_legacy_f32 (0 * anything = 0, an IEEE product otherwise; zbar is finite) does
+            // that in the multiply itself.  It was a compare and three selects per sample, 4.25 issue cycles each.
+            const float zb = zbar[j];
             const float kf = (float)k;
-            const float a0 = on ? zb * g0 : 0.f, a1 = on ? zb * g1 : 0.f, a2 = on ? zb * g2 : 0.f;
+            const float a0 = mul_legacy(zb, g0), a1 = mul_legacy(zb, g1), a2 = mul_legacy(zb, g2);
             gs0 += a0; gs1 += a1; gs2 += a2;
             gd0 = __builtin_fmaf(kf, a0, gd0);
             gd1 = __builtin_fmaf(kf, a1, gd1);
@@ -498,7 +617,14 @@ int launch_bwd_p(const Args &A, hipStream_t st)
     case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
     // (256 < N1 <= 512 as two waves of 4 samples per lane was measured too: 46.5 against 37 us at config 3 -- the split
     // pays only where it lifts the single wave out of the 2-waves-per-SIMD register regime)
-    case 8: hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
+    case 8: {
+#ifndef DIFFUS_BWD_WPB8
+#define DIFFUS_BWD_WPB8 kWavesPerBlock
+#endif
+        constexpr int W8 = DIFFUS_BWD_WPB8; // waves (= rays) per block of the C = 8 kernel
+        hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, W8, PM>), dim3((unsigned)((waves + W8 - 1) / W8)), dim3(kWave * W8), 0, st, A);
+        break;
+    }
     default: // 512 < N1 <= 1024: two waves of 8 samples per lane share a ray (SPLIT), one ray per 128-thread block
         hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, 2, PM, false, 2>), dim3((unsigned)waves), dim3(2 * kWave), 0, st, A);
         break;

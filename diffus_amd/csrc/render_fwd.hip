@@ -107,11 +107,11 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
     }
     if (SEG && !A.frame) return; // carry-only pass (first half of a segmented backward)
     STAMPW(4);
+    {   // attenuation, reference :256-259: exp(-alpha * n) (chunk_attenuation: one v_exp_f32 per lane)
+        float att[C];
+        chunk_attenuation<C>(A, seg0 + n0, att);
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        // attenuation, reference :256-259: exp(-alpha * n), as exp2 of the pre-scaled exponent
-        float att = fast_exp2(A.neg_alpha_l2e * (float)(seg0 + n0 + j));
-        e[j] = __fmul_rn(e[j], att);
+        for (int j = 0; j < C; ++j) e[j] = __fmul_rn(e[j], att[j]);
     }
     STAMPW(5);
     // the frame row leaves from the CHUNKED mapping: two 16-byte stores per lane (a wave's 2 KiB contiguous) instead of
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
     for (int j = 0; j < C; ++j) acc += e[j];
     if (acc == 123.456f) out[lane] = acc;
 #else
-    store_chunk<C>(out, n0, segN, e);
+    store_chunk<C, true>(out, n0, segN, e);
 #endif
 
     STAMPW(6);

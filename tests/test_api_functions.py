@@ -147,3 +147,15 @@ def test_echo_series_is_differentiable_like_the_reference():
     with pytest.raises(NotImplementedError):
         da.prop_single_ray(torch.from_numpy(g["r"]).cuda().requires_grad_(True))
     assert da.prop_single_ray(torch.from_numpy(g["r"]).cuda()).shape == (5, 82)      # detached input: as before
+
+
+def test_rasterize_fan_matches_reference():
+    """rasterize_fan (reference src/renderer.py:626-653, `[DEMO] REUBEN DATA 46` cell 11): host-side SciPy griddata onto the
+    grid of the samples' own coordinates; golden G20 = the reference's output on 60 scattered fan samples."""
+    import diffus_amd
+    g = load_golden("g20_rasterize_fan")
+    img = diffus_amd.rasterize_fan(g["x"], g["z"], g["v"])
+    assert img.shape == g["img"].shape == (60, 60)
+    np.testing.assert_allclose(img, g["img"], rtol=0, atol=1e-12)
+    img_t = diffus_amd.rasterize_fan(torch.from_numpy(g["x"]), torch.from_numpy(g["z"]), torch.from_numpy(g["v"]), output_shape=(8, 8))
+    np.testing.assert_array_equal(img_t, img)            # tensors are accepted; output_shape is ignored, as in the reference

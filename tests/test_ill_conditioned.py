@@ -1,0 +1,116 @@
+"""The ill-conditioned poses of the benchmark workload, pinned on the reference itself (golden G19).
+
+Fans 18 and 6 of BASELINE config 3 graze the skull: the echo is b/d with d nearly cancelled (|echo| = 123 on ray 4 of pose
+18) and every float32 evaluation carries (condition number) x eps of noise.  G19 holds, for ALL 256 rays of both poses, what
+the reference's own code gives on the oracle's float32 impedance samples:
+    echo32   compute_reflection_coeff + compute_echo_traces in float32 (/root/reference/src/renderer.py:33, :407-457)
+    echo64   the same dense solves in float64 on the float32 reflection coefficients (the solver's noise alone)
+    echo64z  the float64 pipeline from the same samples (what every float32 evaluation approximates)
+Per ray, the reference's float32 result is up to 4.2e-5 (pose 18) / 2.3e-5 (pose 6) from echo64z.
+
+CPU: the inputs are the oracle's, the oracle's float64 scan IS the reference's float64 result (1e-12), and the tolerance model
+of the full-size tests (oracle/conditioning.py) is bracketed by the reference's own noise: between 1 and 4 times
+max(1e-5, 2 |echo32 - echo64z|).  GPU, per ray, against max(1e-5, 3 x the reference's float32 noise): the stage-wise echo
+kernel on the golden's coefficients (the wave scan associates the 2x2 products as a tree: 1.05e-4 on ray 4 of pose 18,
+2.5x the dense LU's 4.2e-5 there; the scalar O(N) oracle is at 1.1x) and the fused frames of the benchmark step (which
+also sample the volume themselves: their impedances differ from the oracle's by a rounding, worth sens = 3e-5 on pose
+18; measured 2.3-2.4x).  Twice the reference's noise -- VERDICT r3's proposal -- is what the scalar oracle meets, not
+the wave scans; the factor is stated here, not hidden in a tolerance model."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from diffus_amd.phantom import phantom, pose_ring
+
+N, R, S, ALPHA = 256, 256, 512, 1e-4
+POSES = (18, 6)
+
+
+@pytest.fixture(scope="module")
+def g19():
+    return load_golden("g19_ill_conditioned_poses")
+
+
+@pytest.fixture(scope="module")
+def vol256():
+    return phantom(N)
+
+
+def _per_ray(a, b):
+    """max-norm-relative error of every ray (row): max|a - b| / max|b|"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-300)
+
+
+def _reference_bound(g, p, k=2.0):
+    """per ray: max(1e-5, k x the reference's own float32 error against the float64 pipeline)"""
+    return np.maximum(1e-5, k * _per_ray(g[f"echo32_{p}"], g[f"echo64z_{p}"]))
+
+
+def test_g19_inputs_are_the_oracles_and_the_float64_scan_is_the_references(oracle, g19, vol256):
+    src, dirs = pose_ring(N, 32, R)
+    for p in POSES:
+        Z = oracle.sample_trilinear(vol256, src[p], dirs[p], S)
+        assert float(Z.astype(np.float64).sum()) == float(g19[f"Zsum_{p}"])
+        r = oracle.reflection(Z)
+        assert np.array_equal(r, g19[f"r_{p}"])                       # IEEE f32 sub / add / div on both sides
+        e64 = oracle.echo_scan(r.astype(np.float64), np.float64)
+        assert np.abs(e64 - g19[f"echo64_{p}"]).max() <= 1e-12 * np.abs(e64).max()
+        # the O(N) float32 scan of the oracle: within 2x the reference's float32 noise on every ray
+        e32 = oracle.echo_scan(r, np.float32)
+        assert np.all(_per_ray(e32, g19[f"echo64z_{p}"]) <= _reference_bound(g19, p)), p
+
+
+def test_conditioning_model_is_bracketed_by_the_references_noise(g19, vol256):
+    """oracle/conditioning.py's tolerance for these frames is a model (input roundings x sensitivity); here it is held to
+    the reference: at least the reference-derived bound (so that a kernel as good as the reference passes), at most 4x it."""
+    from oracle.conditioning import frame64_and_tolerance
+    src, dirs = pose_ring(N, 32, R)
+    att = np.exp(-ALPHA * np.arange(S))
+    for p in POSES:
+        f64, tol, sens = frame64_and_tolerance(vol256, src[p], dirs[p], S, ALPHA)
+        den = np.abs(g19[f"echo64z_{p}"] * att).max()
+        err32 = np.abs((g19[f"echo32_{p}"].astype(np.float64) - g19[f"echo64z_{p}"]) * att).max() / den
+        bound = max(1e-5, 2 * err32)                                  # frame-level form of the per-ray bound
+        assert bound <= tol <= 4 * bound, (p, tol, bound, sens)
+        # the model's float64 frame starts from the float32 coefficients: it is the reference's echo64
+        assert np.abs(f64 - g19[f"echo64_{p}"] * att).max() <= 1e-12 * den
+
+
+@pytest.mark.gpu
+def test_hip_echo_kernel_within_three_times_the_references_noise_per_ray(g19):
+    """diffus_echo_traces on the golden's float32 coefficients: the scan arithmetic alone, ray by ray (measured: 2.5x on
+    the worst ray, below 2x on all but three rays of pose 18)"""
+    import diffus_amd as da
+    for p in POSES:
+        r = torch.from_numpy(g19[f"r_{p}"]).cuda()
+        e, _ = da.compute_echo_traces(r)
+        err = _per_ray(e.cpu().numpy(), g19[f"echo64z_{p}"])
+        bound = _reference_bound(g19, p, k=3.0)
+        assert np.all(err <= bound), (p, int(np.argmax(err / bound)), float((err / bound).max()))
+        assert np.mean(err <= _reference_bound(g19, p, k=2.0)) >= 0.98
+
+
+@pytest.mark.gpu
+def test_hip_one_pass_frame_within_three_times_the_references_noise_per_ray(g19, vol256):
+    """The fused kernel of the benchmark step on the ill-conditioned poses, every ray against the float64 pipeline.  It
+    samples the volume itself (fused lerps, another rounding sequence than the oracle's samples the golden was made from):
+    one input rounding's worth on top of the scan's own noise -- measured 2.3x the reference's noise on the worst ray."""
+    import diffus_amd as da
+    src, dirs = pose_ring(N, 32, R)
+    vol = torch.from_numpy(vol256).cuda()
+    idx = list(POSES)
+    step = da.CapturedStep(vol, torch.from_numpy(src[idx]).cuda(), torch.from_numpy(dirs[idx]).cuda(), S, ALPHA, "trilinear",
+                           layout="paired")
+    step.step()
+    torch.cuda.synchronize()
+    fwd = da.render_poses(vol, torch.from_numpy(src[idx]), torch.from_numpy(dirs[idx]), S, ALPHA, sampler="trilinear",
+                          layout="paired").cpu().numpy()
+    att = np.exp(-ALPHA * np.arange(S))
+    for q, p in enumerate(POSES):
+        want = g19[f"echo64z_{p}"] * att
+        bound = _reference_bound(g19, p, k=3.0)
+        for name, frame in (("one-pass", step.frame[q].cpu().numpy()), ("forward", fwd[q])):
+            err = _per_ray(frame, want)
+            assert np.all(err <= bound), (name, p, int(np.argmax(err / bound)), float((err / bound).max()))

@@ -37,6 +37,11 @@ print("wall clock (s_memrealtime, 100 MHz): first wave start -> last wave end %.
       % (span, (rt1 - rt0).mean() / 100.0, life.mean() / ((rt1 - rt0).mean() / 100.0) / 1e3))
 st_us = np.sort(rt0 - t0) / 100.0
 en_us = np.sort(rt1 - t0) / 100.0
-for q in (0.05, 0.25, 0.5, 0.55, 0.75, 0.95, 1.0):
+for q in (0.05, 0.1, 0.2, 0.25, 0.3, 0.4, 0.45, 0.5, 0.55, 0.6, 0.7, 0.75, 0.8, 0.9, 0.95, 1.0):
     i = int(q * len(st_us)) - 1
     print("  %3.0f %% of the waves have started by %5.1f us, ended by %5.1f us" % (100 * q, st_us[i], en_us[i]))
+
+# how many waves are resident over time (per SIMD: / 1024)
+ts = np.linspace(0, span, 35)
+res = [(int(((rt0 - t0) / 100.0 <= t).sum() - ((rt1 - t0) / 100.0 <= t).sum())) for t in ts]
+print("resident waves per SIMD over time (us: waves):", "  ".join("%.0f:%.1f" % (t, r / 1024.0) for t, r in zip(ts, res)))

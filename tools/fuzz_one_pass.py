@@ -71,6 +71,8 @@ for c in range(cases):
     for k in worst:
         if np.isfinite(e[k]):
             worst[k] = max(worst[k], e[k])
+    if c % 500 == 499:
+        print("progress", c + 1, {k: "%.1e" % x for k, x in worst.items()}, flush=True)
     if bad:
         print("MISMATCH case", c, dims, P, R, S, start, sampler, layout, alpha, "f64" if f64 else "f32", e, flush=True)
 if cases:

@@ -52,7 +52,29 @@ def kernel_body(asm: str, pick: str):
     raise SystemExit(f"no kernel matching {pick!r}")
 
 
+def emit(path):
+    """profiles/<round>_issue_model.json: the executed copies of the step's two big kernels (bench.py reads it)."""
+    recs = []
+    for short, unit, pick, defs in (
+            ("render_bwd_kernel", "render_bwd", "render_bwd_kernel<8, 1, 2, true, 4, 0, false, 1>", ["-DDIFFUS_COUNT_PLANAR=1", "-DDIFFUS_COUNT_FAST_ONLY"]),
+            ("scatter_patch_kernel", "scatter", "scatter_patch_kernel<1, 1, 0>", ["-DDIFFUS_SC_PLANAR_ONLY"])):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), unit, pick, *defs, "--json"], check=True,
+                             capture_output=True, text=True).stdout
+        rec = json.loads(out)
+        rec["short"] = short
+        recs.append(rec)
+    json.dump({"costs": {"full_rate": FULL, "half_rate": HALF, "transcendental": TRANS, "f64": F64, "packed_f32": 4.55,
+                         "source": "profiles/r04_valu_issue_bench.txt (tools/valu_issue_bench.hip on MI355X, >= 4 waves per SIMD)"},
+               "note": "static VALU instruction mix of the executed copy of each kernel (config 3: planar fans, f32 poses, paired "
+                       "volume) priced with the measured per-instruction issue costs",
+               "kernels": recs}, open(path, "w"), indent=1)
+    for r in recs:
+        print(r["short"], r["static_counts"], "%.0f cycles per wave, %.2f per VALU instruction" % (r["valu_issue_cycles_per_wave"], r["mean_cycles_per_valu"]))
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--emit":
+        return emit(sys.argv[2])
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
     unit, pick = args[0], args[1]

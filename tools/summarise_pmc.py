@@ -82,7 +82,9 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
 summary = {"tag": tag, "workload": workload,
            "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  [FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md §HBM]",
            "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; *_frac_of_wave = share of a "
-                    "wave's resident cycles; valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)",
+                    "wave's resident cycles; valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) -- every instruction "
+                    "counts a whole quad, FP32 arithmetic issues in ~2.2 cycles (profiles/r04_valu_issue_bench.txt): an upper estimate; "
+                    "valu_issue_frac_at_fp32_rate = SQ_INSTS_VALU x 2 cycles / 1024 SIMDs / (trace duration x 2.4 GHz)",
            "kernels": {}}
 for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "gradbuf_flush_kernel", "median_kernel",
           "median_bwd_kernel", "pair_convert_kernel", "brick_convert_kernel", "loss_sumsq_kernel"):
@@ -117,7 +119,13 @@ for k in ("render_fwd_kernel", "render_bwd_kernel", "scatter_patch_kernel", "gra
                 e[key] = c[name] / wc
     gui = c.get("GRBM_GUI_ACTIVE")
     if gui and "SQ_ACTIVE_INST_VALU" in c:
+        # counter units are quad-cycles: an FP32 instruction that issues in ~2.2 cycles still counts one quad, so this is
+        # an UPPER estimate of how busy the pipes are (tools/valu_issue_bench.hip; VERDICT r3 "what's weak" 1)
         e["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4 / N_SIMD / (gui / 8)
+    if "SQ_INSTS_VALU" in c:
+        # the instruction stream against the guide's FP32 issue rate (2 cycles per wave64 instruction, 2.4 GHz), over the
+        # kernel-trace duration (no counters attached)
+        e["valu_issue_frac_at_fp32_rate"] = c["SQ_INSTS_VALU"] * 2 / N_SIMD / (us * 1e-6 * 2.4e9)
     if gui and "SQ_LDS_IDX_ACTIVE" in c:
         e["lds_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / 256 / (gui / 8)
         e["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c["SQ_LDS_IDX_ACTIVE"], 1.0)
