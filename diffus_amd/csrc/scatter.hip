@@ -340,7 +340,6 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
         // half-wave derive its own column from a flat index: a float division, two quarter-rate v_mul_lo_u32 and two
         // v_mad_u64_u32 per column per lane -- 24 VALU instructions per wave-atomic, a third of the kernel's VALU count.)
         {
-            const int npr = (b1 + 1) >> 1, npairs = b0 * npr; // column pairs per brick row, in the box
             const int lane = tid & 63, o = lane & 31, h = lane >> 5;
             const int zz = (o & 1) ? iz1 : iz0;
             const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
@@ -352,48 +351,49 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
             unsigned lc_tile_o = lc_tile;
             asm volatile("" : "+v"(lc_tile_o)); // opaque: or else (4 ci + x) * BY is re-associated into a per-column v_mul_lo_u32
             const char *tile_b = reinterpret_cast<const char *>(tile);
-            constexpr int FU2 = 4; // tile reads in flight per thread
-            // pair p = ci * npr + cp; this wave's pairs are wv, wv + kSW, ...: advanced by carry, no division
+            // The four waves split the box 2 x 2: wave wv takes the brick rows ci = wv >> 1, + 2, ... and of each the column
+            // pairs cp = wv & 1, + 2, ... -- two plain nested scalar loops.  (Round 3 dealt the flattened pairs p = ci * npr +
+            // cp out round-robin and advanced (ci, cp) by a carry loop, four pairs in flight: ~28 scalar instructions per
+            // pair -- two 64-bit multiplies for the brick address among them -- in a kernel whose scalar pipe is as busy as
+            // its vector pipe: 408 of them per wave, tools/pmc_step.sh.)  Everything that depends on (ci, cp) is scalar: the
+            // tile address is a scalar + a lane constant, the brick a scalar 32-bit index, the memory operands a scalar
+            // 64-bit base + a 32-bit lane offset.
             const int wv = __builtin_amdgcn_readfirstlane(wib);
-            int ci = 0, cp = wv;
-            auto carry = [&]() {
-                while (cp >= npr) { cp -= npr; ++ci; } // at most kSW trips (wave-uniform)
+            const unsigned nb2u = (unsigned)A.G.nb2;
+            char *const gvol_b = reinterpret_cast<char *>(A.gvol);
+            char *const gt_b = reinterpret_cast<char *>(A.gtouched);
+            auto flush_pair = [&](unsigned trow, unsigned grow, int cp, double &v, unsigned &ta) { // issue the tile read
+                const bool second = 2 * cp + 1 < b1; // wave-uniform: the pair's second column exists
+                ta = trow + 64u * (unsigned)cp + lc_tile_o;
+                v = (h0 || second) ? *reinterpret_cast<const double *>(tile_b + ta) : 0.0;
+                (void)grow;
             };
-            carry();
-            for (int p0 = wv; p0 < npairs; p0 += kSW * FU2) {
-                double v[FU2];
-                unsigned ta[FU2];
-                int sci[FU2], scp[FU2];
-#pragma unroll
-                for (int u = 0; u < FU2; ++u) {
-                    sci[u] = ci; scp[u] = cp;
-                    const bool in = p0 + u * kSW < npairs;            // wave-uniform
-                    const bool second = 2 * cp + 1 < b1;              // wave-uniform: the pair's second column exists
-                    ta[u] = (unsigned)((4 * ci) * BY + 8 * cp) * 8u + lc_tile_o;
-                    v[u] = (in && (h0 || second)) ? *reinterpret_cast<const double *>(tile_b + ta[u]) : 0.0;
-                    cp += kSW;
-                    carry();
-                }
-                if (nsub > 1) { // leave the tile clean for the next group (after both lanes of a pair have read their entry)
-#pragma unroll
-                    for (int u = 0; u < FU2; ++u)
-                        if (v[u] != 0.0 && !(o & 1)) *reinterpret_cast<double *>(const_cast<char *>(tile_b) + ta[u]) = 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < FU2; ++u) {
-                    const bool nz = v[u] != 0.0 && adds;
-                    if (__builtin_amdgcn_ballot_w64(nz) == 0ull) continue; // wave-uniform
-                    const size_t g0 = ((size_t)((unsigned)(l0 + sci[u]) * (unsigned)A.G.nb1 + (unsigned)(l1 + 2 * scp[u]))) * (size_t)A.G.nb2;
+            auto emit_pair = [&](unsigned grow, int cp, double v, unsigned ta) {
+                if (nsub > 1 && v != 0.0 && !(o & 1)) *reinterpret_cast<double *>(const_cast<char *>(tile_b) + ta) = 0.0; // leave the tile clean for the next group
+                const bool nz = v != 0.0 && adds;
 #ifdef DIFFUS_ABLATE_SC_FLUSH
-                    asm volatile("" :: "s"(g0), "v"((float)v[u] * wz));
+                asm volatile("" :: "s"(grow), "v"((float)v * wz), "v"(nz));
 #else
-                    if (nz) {
-                        // every adding lane marks its brick (lanes of a brick store the same word: one write)
-                        if (A.gtouched) *reinterpret_cast<int *>(reinterpret_cast<char *>(A.gtouched + g0) + (size_t)lc_t) = 1;
-                        atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(A.gvol + g0 * kBrickFloats) + (size_t)lc_g),
-                                  (float)v[u] * wz);
-                    }
+                if (nz) {
+                    const unsigned gb = grow + 2u * (unsigned)cp * nb2u; // brick index of the pair's first column at depth brick 0
+                    // every adding lane marks its brick (lanes of a brick store the same word: one write)
+                    if (A.gtouched) *reinterpret_cast<int *>(gt_b + (size_t)gb * 4u + (size_t)lc_t) = 1;
+                    atomicAdd(reinterpret_cast<float *>(gvol_b + (size_t)gb * (kBrickFloats * 4u) + (size_t)lc_g), (float)v * wz);
+                }
 #endif
+            };
+            const int npr = (b1 + 1) >> 1; // column pairs per brick row, in the box
+            for (int ci = wv >> 1; ci < b0; ci += 2) {
+                const unsigned trow = (unsigned)(4 * ci * BY) * 8u;                                                // bytes, tile
+                const unsigned grow = ((unsigned)(l0 + ci) * (unsigned)A.G.nb1 + (unsigned)l1) * nb2u;              // bricks
+                for (int cp = wv & 1; cp < npr; cp += 4) { // two pairs per trip: two tile reads in flight
+                    double v0, v1 = 0.0;
+                    unsigned t0, t1 = 0;
+                    const bool two = cp + 2 < npr; // wave-uniform
+                    flush_pair(trow, grow, cp, v0, t0);
+                    if (two) flush_pair(trow, grow, cp + 2, v1, t1);
+                    emit_pair(grow, cp, v0, t0);
+                    if (two) emit_pair(grow, cp + 2, v1, t1);
                 }
             }
         }

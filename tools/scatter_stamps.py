@@ -39,3 +39,17 @@ print("kernel span (cycles, min start..max end): %.0f" % (span.max() - span.min(
 te = s[done][:, 6]
 for c in (1024, 2048, 3072, 4096, 6144, 8192, 12288):
     print("tile entries <= %5d: %5.1f %%" % (c, 100.0 * (te <= c).mean()))
+# blocks by tile size: how much of the kernel's block time do the small (rays clamped outside the volume) patches take?
+life = (s[:, 5] - s[:, 0]).astype(np.float64)
+ok = (s[:, 5] > 0) & (s[:, 0] > 0)
+te_all = s[:, 6].astype(np.float64)
+for lo, hi in ((0, 1), (1, 64), (64, 256), (256, 1024), (1024, 2048), (2048, 4096)):
+    m = ok & (te_all >= lo) & (te_all < hi)
+    if m.any():
+        print("tile entries [%4d, %4d): %5d blocks  mean life %7.0f cycles  share of block time %5.1f %%" % (lo, hi, m.sum(), life[m].mean(), 100 * life[m].sum() / life[ok].sum()))
+print("blocks without stamps at the end (returned early):", int((~ok).sum()))
+dd = np.diff(s[:, :6].astype(np.int64), axis=1)
+for lo, hi in ((1, 64), (64, 256), (256, 1024), (1024, 4096)):
+    m = ok & (te_all >= lo) & (te_all < hi)
+    if m.any():
+        print("tile [%4d, %4d): " % (lo, hi) + "  ".join("%s %6.0f" % (n, dd[m][:, i].mean()) for i, n in enumerate(names)))
