@@ -969,6 +969,26 @@ def worker(args):
             issue = None
         if traffic is not None:
             measured = traffic / (dom_ms * 1e-3) / 1e9
+    # the same figures for every timed kernel of the step (scan and scatter are within a few per cent of each other: which
+    # of them is "dominant" changes from run to run)
+    per_kernel = {}
+    for k, t in kern.items():
+        rec = {"launch_ms": t["mean"], "algorithmic_GBs": b[k] * local_rs / (t["mean"] * 1e-3) / 1e9}
+        if found is not None:
+            ek = found[1].get("kernels", {}).get(k, {})
+            if ek.get("hbm_bytes_per_launch") is not None:
+                rec["traffic"] = ek["hbm_bytes_per_launch"]
+                rec["measured_hbm_GBs"] = ek["hbm_bytes_per_launch"] / (t["mean"] * 1e-3) / 1e9
+                rec["measured_hbm_frac"] = rec["measured_hbm_GBs"] / HBM_PEAK_GBS
+            vk = ek.get("counters", {}).get("SQ_INSTS_VALU")
+            mk = issue_mix(k)
+            if vk:
+                rec["valu_issue_frac_at_fp32_rate"] = vk * 2.0 / 1024 / (t["mean"] * 1e-3 * 2.4e9)
+                if mk:
+                    rec["valu_issue_frac_cost_weighted"] = vk * mk["mean_cycles_per_valu"] / 1024 / (t["mean"] * 1e-3 * 2.4e9)
+            if ek.get("limiter"):
+                rec["bound"] = ek["limiter"]
+        per_kernel[k] = rec
     if measured is not None and measured / HBM_PEAK_GBS >= 0.4:
         bound = "hbm"
     elif limiter:
@@ -1056,6 +1076,7 @@ def worker(args):
                                         "bytes that crossed the HBM interface -- a planar fan re-reads a cache-resident sheet "
                                         "(traffic / algorithmic = %s)" % ("n/a" if traffic is None else "%.2f" % (traffic / (b[dom] * local_rs)))},
                 "issue_roofline": issue,
+                "per_kernel": per_kernel,
                 "evidence": evidence,
                 "launch_ms": dom_ms,
                 "kernels_ms": k_ms,
