@@ -114,3 +114,37 @@ def test_hip_one_pass_frame_within_three_times_the_references_noise_per_ray(g19,
         for name, frame in (("one-pass", step.frame[q].cpu().numpy()), ("forward", fwd[q])):
             err = _per_ray(frame, want)
             assert np.all(err <= bound), (name, p, int(np.argmax(err / bound)), float((err / bound).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,index,pose,peak", [(21, 10458, 0, 3.5e3), (21, 13253, 2, 141.0), (21, 57848, 0, 917.0)])
+def test_fuzz_outliers_are_single_ill_conditioned_echoes(seed, index, pose, peak):
+    """Fixed regression cases out of tools/fuzz_one_pass.py (100 000 random cases, seed 21, round 4: seven cases where the
+    one-pass step and the two-call path differ by 5e-5 .. 1.1e-3, all of them rays through a flat WHITE-NOISE slab, the
+    same seven with the same digits on the round-3 library).  Each is one echo with a nearly cancelled denominator --
+    |frame| = 3510, 141, 917 where the other poses of the case peak at 0.2 .. 2 -- and BOTH kernels sit within 20 x the
+    frame's own one-rounding sensitivity of the float64 result (measured 4.7 / 5.4 / 17 x: white noise is harsher than the
+    anatomical volumes oracle/conditioning.py's 10 x is pinned on), while every other pose of the case is within 2e-5."""
+    import diffus_amd as da
+    from oracle.conditioning import frame64_and_tolerance
+    from tools.fuzz_one_pass import gen_case
+    rng = np.random.default_rng(seed)
+    for _ in range(index + 1):
+        k = gen_case(rng)
+    assert k["start"] == 0 and k["sampler"] == "trilinear"
+    v = torch.from_numpy(k["vol"]).cuda()
+    s, d = torch.from_numpy(k["src"]).cuda(), torch.from_numpy(k["dirs"]).cuda()
+    one = da.CapturedStep(v, s, d, k["S"], k["alpha"], k["sampler"], layout=k["layout"], target=torch.from_numpy(k["tgt"]).cuda(),
+                          loss_scale=k["scale"])
+    one.step()
+    two = da.render_poses(v, s, d, k["S"], k["alpha"], sampler=k["sampler"], layout=k["layout"])
+    torch.cuda.synchronize()
+    for p in range(k["P"]):
+        f64, tol, sens = frame64_and_tolerance(k["vol"], k["src"][p], k["dirs"][p], k["S"], k["alpha"])
+        den = np.abs(f64).max()
+        for frame in (one.frame[p], two[p]):
+            err = np.abs(frame.cpu().numpy() - f64).max() / den
+            if p == pose:
+                assert den > 0.5 * peak and err <= 20 * sens, (p, den, err, sens)
+            else:
+                assert err <= 2e-5, (p, err)
