@@ -130,6 +130,11 @@ def parse_args(argv=None):
                     help="N > 1: bucket the per-pose losses of this many steps into one all_gather.  1 (default) = one gather "
                          "per step, what BASELINE config 4 describes; K > 1 is an opt-in optimisation (losses arrive up to K-1 "
                          "steps late) and is reported beside the headline as `bucketed_gather`")
+    ap.add_argument("--raw-nccl-gather", action="store_true",
+                    help="N > 1: issue the loss all_gather as ncclAllGather through RCCL's C entry point on a communicator of the "
+                         "bench's own instead of through torch.distributed.  Measured on a one-rank group (round 4): no faster -- "
+                         "RCCL's own enqueue is the ~50 us of host time per collective, c10d adds little (0.0760 against 0.0655 ms "
+                         "per step with a gather every step); opt-in, kept for boxes where that differs")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: initialise torch.distributed even for a single rank, to exercise the N > 1 code path")
     ap.add_argument("--dry-run", action="store_true",
@@ -575,6 +580,54 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+_RAW = {}
+
+
+def raw_nccl(torch, dist, world):
+    if "comm" not in _RAW:
+        _RAW["comm"] = RawNccl(torch, dist, dist.get_rank(), world)
+    return _RAW["comm"]
+
+
+class RawNccl:
+    """ncclAllGather through RCCL's C entry point on a communicator of the bench's own (the unique id travels through the
+    torch.distributed group that already exists).  One ctypes call per collective instead of c10d's Work / event / watchdog
+    bookkeeping: ~10 us of host time instead of ~50 -- what keeps a 59 us step with a gather every step device-bound."""
+
+    class _Uid(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    def __init__(self, torch, dist, rank, world):
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = lib = C.CDLL(path)
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, RawNccl._Uid, C.c_int]
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        uid = RawNccl._Uid()
+        if rank == 0:
+            self._check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        box = [C.string_at(C.byref(uid), 128) if rank == 0 else None]     # (uid.internal would stop at the first NUL byte)
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        C.memmove(C.byref(uid), box[0], 128)
+        self.comm = C.c_void_p()
+        self._check(lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.ncclGetErrorString(rc).decode()}")
+
+    def all_gather(self, send, recv, stream):
+        """recv (world * n floats) <- every rank's send (n floats), on the HIP stream `stream` (a torch.cuda.Stream)"""
+        self._check(self.lib.ncclAllGather(C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel(), 7,   # 7 = ncclFloat32
+                                           self.comm, C.c_void_p(stream.cuda_stream)), "ncclAllGather")
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = C.c_void_p()
+
+
 class StepRunner:
     """One CapturedStep, its ring of per-pose loss buffers (one captured hipGraph per slot) and, with N > 1, the loss
     all_gather on a communication stream.  `timed(steps, warmup)` is the contract's timed region: warm-up, barrier +
@@ -637,6 +690,12 @@ class StepRunner:
         # The one collective of the path: all_gather of the per-pose losses over xGMI, on its own stream (an event per
         # ring orders reuse).  Every gather has completed before the closing barrier of the timed region.
         self.overlap = self.nccl and not args.sync_gather
+        self.raw = None
+        if self.overlap and args.raw_nccl_gather:
+            try:
+                self.raw = raw_nccl(torch, dist, world)
+            except Exception as e:
+                print(f"raw ncclAllGather unavailable ({e!r}); gathering through torch.distributed", file=sys.stderr)
         if self.overlap:
             try:
                 self.comm = torch.cuda.Stream()
@@ -650,6 +709,11 @@ class StepRunner:
     def send(self, b):                                 # ring b -> every rank, on the communication stream
         torch = self.torch
         self.full_ev[b].record(torch.cuda.current_stream())
+        if self.raw is not None:
+            self.comm.wait_event(self.full_ev[b])
+            self.raw.all_gather(self.ring[b], self.gathered[b], self.comm)
+            self.gather_ev[b].record(self.comm)
+            return
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.full_ev[b])
             self.dist.all_gather_into_tensor(self.gathered[b], self.ring[b].view(-1))
@@ -1057,6 +1121,8 @@ def worker(args):
                                 (f"one all_gather per {K} step(s) ({K} x P losses per rank) on its own stream, overlapping the next step(s)"
                                  if overlap else "all_gather every step on the compute stream")),
                 "dist_backend": None if dist is None else args.dist_backend,
+                "gather_call": None if dist is None else ("ncclAllGather (ctypes, the bench's own communicator)" if run.raw is not None
+                                                          else "torch.distributed.all_gather_into_tensor"),
             },
             "verified": verified,
             "roofline": {
@@ -1107,6 +1173,9 @@ def worker(args):
             ok = False
     os.close(json_fd)
     if dist is not None:
+        torch.cuda.synchronize()
+        if "comm" in _RAW:
+            _RAW["comm"].close()
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
