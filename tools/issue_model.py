@@ -56,7 +56,7 @@ def emit(path):
     """profiles/<round>_issue_model.json: the executed copies of the step's two big kernels (bench.py reads it)."""
     recs = []
     for short, unit, pick, defs in (
-            ("render_bwd_kernel", "render_bwd", "render_bwd_kernel<8, 1, 2, true, 4, 0, false, 1>", ["-DDIFFUS_COUNT_PLANAR=1", "-DDIFFUS_COUNT_FAST_ONLY"]),
+            ("render_bwd_kernel", "render_bwd", "render_bwd_kernel<8, 1, 2, true, 4, 0, false, 1, true>", ["-DDIFFUS_COUNT_PLANAR=1", "-DDIFFUS_COUNT_FAST_ONLY"]),
             ("scatter_patch_kernel", "scatter", "scatter_patch_kernel<1, 1, 0>", ["-DDIFFUS_SC_PLANAR_ONLY"])):
         out = subprocess.run([sys.executable, os.path.abspath(__file__), unit, pick, *defs, "--json"], check=True,
                              capture_output=True, text=True).stdout
