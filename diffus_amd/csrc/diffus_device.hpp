@@ -131,6 +131,21 @@ __device__ __forceinline__ float mul_legacy(float a, float b)
     return r;
 }
 
+// a * b + c on the low 24 bits of a and b (v_mad_u32_u24): ONE half-rate instruction where hipcc turns
+// __umul24(a, b) + c + d into a multiply and a three-operand add (two).  b: a wave-uniform value (SGPR) / the constant 40.
+__device__ __forceinline__ unsigned mad_u24_s(unsigned a, unsigned b_uniform, unsigned c)
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned mad_u24_40(unsigned a, unsigned c)
+{
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, 40, %2" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ bool finitef(float x) { return fabsf(x) < __builtin_inff(); }
 __device__ __forceinline__ bool mat_finite(const Mat &m) { return finitef(m.a) && finitef(m.b) && finitef(m.c) && finitef(m.d); }
 
@@ -925,9 +940,15 @@ __device__ __forceinline__ void gather_interleaved_z(const Args &A, int seg0, in
                     // behind wave-uniform branches, and fetching the second column by an exec-masked extra load
                     // instead of storing it twice: hipcc then waits for the loads at every branch merge, 19.9 -> 24.1
                     // and 13.6 -> 21.2 us.  The loads stay unconditional.)
-                    const F4a8 q0 = ldb_f32x4(vol, x0 + y0 + z0);
-                    const F4a8 q1 = ldb_f32x4(vol, x1 + y0 + z0);
-                    (void)y1;
+                    // (x + (y + z) offsets: the dim-0 part as two chained v_mad_u32_u24 on top of the shared (y + z) part --
+                    // part_x() + a three-operand add was two multiplies and a v_add3 per row, each a half-rate instruction)
+                    const unsigned syB_u = (unsigned)__builtin_amdgcn_readfirstlane((int)A.G.syB);
+                    const unsigned yz = mad_u24_s((unsigned)b.i0 >> 2, syB_u, (((unsigned)b.i0 & 3u) << 3) + z0);
+                    (void)y0;
+                    const unsigned sxB_u = (unsigned)__builtin_amdgcn_readfirstlane((int)A.G.sxB);
+                    const F4a8 q0 = ldb_f32x4(vol, mad_u24_s((unsigned)a.i0 >> 2, sxB_u, mad_u24_40((unsigned)a.i0 & 3u, yz)));
+                    const F4a8 q1 = ldb_f32x4(vol, mad_u24_s((unsigned)a.i1 >> 2, sxB_u, mad_u24_40((unsigned)a.i1 & 3u, yz)));
+                    (void)y1; (void)x0; (void)x1;
 #endif
                     raw[jj][0] = q0.x; raw[jj][1] = q0.y; raw[jj][2] = q0.z; raw[jj][3] = q0.w;
                     raw[jj][4] = q1.x; raw[jj][5] = q1.y; raw[jj][6] = q1.z; raw[jj][7] = q1.w;
