@@ -47,9 +47,13 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
 // VALU-issue-bound (its time is resident waves x issue cycles), sits at 126-138 registers depending on what the
 // register allocator makes of the last change, and three waves per SIMD instead of four is a quarter of the chip idle in
 // every generation of waves -- a handful of spilled dwords is the cheaper side of that.  (Canonical volumes -- eight
-// address registers per sample in flight -- stay at the compiler's choice: forced to 128 they spill 41 dwords.)
+// address registers per sample in flight -- get THREE waves per SIMD, 164-168 registers: 48.8 -> 44.6 us at config 3;
+// forced to 128 they spill 41 dwords: 63 us.)
 #ifndef DIFFUS_BWD_MIN_WAVES
 #define DIFFUS_BWD_MIN_WAVES 4
+#endif
+#ifndef DIFFUS_BWD_MIN_WAVES_CANONICAL
+#define DIFFUS_BWD_MIN_WAVES_CANONICAL 3
 #endif
 #ifndef DIFFUS_SPLIT_MIN_WAVES // SPLIT kernels: 3 waves per SIMD, 139 VGPRs, no scratch.  (Forced to 4 waves = 128 VGPRs the
 #define DIFFUS_SPLIT_MIN_WAVES 3 // compiler spills 15 dwords: one-pass scan 42.5 against 43.5 us at the config-5 shape, whole step 98.5 against 96 -- a wash; the spill-free build is kept)
@@ -65,7 +69,7 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
 // compile-time constant and every "sample index < segN" test (three per sample: reflection, frame, zbar; a compare and a
 // select each, 4.25 issue cycles apiece) folds away.
 template <int C, int SAMPLER, int LAYOUT, bool GPOSE, int WPB, int PM, bool SEG = false, int SPLIT = 1, bool FULL = false>
-__global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : ((C == 8 && LAYOUT != DIFFUS_CANONICAL) ? DIFFUS_BWD_MIN_WAVES : 1))) void render_bwd_kernel(Args A)
+__global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : ((C == 8 && LAYOUT != DIFFUS_CANONICAL) ? DIFFUS_BWD_MIN_WAVES : ((C == 8) ? DIFFUS_BWD_MIN_WAVES_CANONICAL : 1)))) void render_bwd_kernel(Args A)
 {
     static_assert(SPLIT == 1 || (SPLIT == 2 && WPB == 2 && !SEG), "SPLIT: one ray per block of two waves");
     __shared__ float s_c[5], s_u[4], s_zc, s_pg[6]; // SPLIT exchange: forward carry, adjoint carry, zbar boundary term, pose-gradient partials
