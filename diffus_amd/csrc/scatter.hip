@@ -410,7 +410,7 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
 }
 
 template <int SAMPLER, int LAYOUT, int PM>
-__global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int has_finish)
+__global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int has_finish, int step_groups, int sg_mul)
 {
     // General (3-D) tile: 32-bit FIXED POINT with a per-patch power-of-two scale 2^fx chosen so that even all 1024 samples
     // landing on one voxel cannot overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel
@@ -436,22 +436,28 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         if (blockIdx.x < (unsigned)A.P) pose_finish_block<SAMPLER, LAYOUT>(A, (int)blockIdx.x, reinterpret_cast<float *>(tile));
         return;
     }
-    // patch -> (step group, pose, ray group), step group SLOWEST: the blocks in flight at any time are then the same
-    // depth range of all poses and ray groups -- patches of similar cost (the box grows with the distance from the
-    // apex) spread over the whole volume -- instead of all depths of a few neighbouring fans (58 -> 52 us).  Within a
-    // step group the XCD remap keeps a pose on one XCD.
+    // block -> (row, pose, ray group) with the row SLOWEST, and the row -> step group mapping of decode() below: the blocks
+    // in flight at any time are then spread over all poses and ray groups (round 1: all depths of a few neighbouring fans
+    // at a time was 58 against 52 us) AND over all depths (round 4).  Within a row the XCD remap keeps a pose on one XCD.
     const int tid = threadIdx.x;
     int pose, nbase;
     bool ray_ok;
     long w, w0;        // this thread's ray, the block's first ray (block-uniform)
     unsigned row_off;  // bytes from zbar[w0][0] to the thread's first sample
     auto decode = [&](unsigned bx, unsigned by) {
-        const int sg = (int)by - has_finish;
         // gridDim.x is a multiple of 8 (launch_scatter pads it): the hardware's linear block id by * gridDim.x + bx then
         // has the same residue mod 8 -- the XCD -- as bx in every row, so a pose sits on ONE XCD for all its step groups
         const unsigned Lb = xcd_remap(bx, gridDim.x);
         const int rg = Lb % ray_groups;
         pose = Lb / ray_groups;
+        // Which step group a block takes: NOT simply its row.  Patches of one depth are alike -- near the apex small boxes
+        // full of duplicate addresses (LDS-bound), at mid depth full tiles (bound by the L2's atomic rate in their flush),
+        // beyond the volume a few border voxels -- and the dispatcher fills the chip row after row, so with sg = row every
+        // generation of resident blocks queued for the same unit while the others idled.  sg = (row * m + 3 * pose) mod
+        // groups, m coprime to the group count and about 7/16 of it (a bijection row -> sg for every pose), deals every
+        // window of rows AND every row a mix of depths: 28.4 -> 25.5 us at 32 poses, 178.6 -> 145.2 us at 256 (round 4).
+        const int row = (int)by - has_finish;
+        const int sg = (int)(((unsigned)row * (unsigned)sg_mul + 3u * (unsigned)pose) % (unsigned)step_groups);
         // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..).  (Tried: a wave taking every 4th ray of the
         // patch instead of 8 adjacent ones, so that near the apex -- adjacent rays less than a voxel apart -- fewer lanes of
         // one LDS atomic share an address: 29.9 -> 30.5 us.)
@@ -741,6 +747,13 @@ namespace diffus {
 int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
 {
     const int rgs = (A.R + kScRays - 1) / kScRays, sgs = (A.N1 + kScSteps - 1) / kScSteps;
+    int sg_mul = 1; // row -> step group multiplier: odd, about 7/16 of the group count, coprime to it (see the kernel's decode())
+    if (sgs >= 3) {
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        sg_mul = ((sgs * 7) / 16) | 1;
+        while (sg_mul < sgs && gcd(sg_mul, sgs) != 1) sg_mul += 2;
+        if (sg_mul >= sgs) sg_mul = 1;
+    }
     const int fin = A.finish_in_scatter ? 1 : 0;
     // x padded to a multiple of 8 (at most 7 idle blocks per row): see the XCD note in the kernel's decode()
     const dim3 grid((unsigned)((((long)A.P * rgs + 7) / 8) * 8), (unsigned)(sgs + fin)); // sgs <= 2048 (DIFFUS_MAX_SAMPLES * SEGMENTS / patch steps)
@@ -749,9 +762,9 @@ int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
     return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
         constexpr int SM = decltype(S_)::value, LY = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
         if (f32)
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), grid, dim3(kSB), 0, st, A, rgs, fin);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), grid, dim3(kSB), 0, st, A, rgs, fin, sgs, sg_mul);
         else
-            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), grid, dim3(kSB), 0, st, A, rgs, fin);
+            hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1>), grid, dim3(kSB), 0, st, A, rgs, fin, sgs, sg_mul);
         return last_launch();
     });
 }
