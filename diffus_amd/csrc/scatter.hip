@@ -817,23 +817,18 @@ __global__ __launch_bounds__(kBlock) void brick_convert_kernel(const float *__re
     }
 }
 
-// Sparse bricked gradient -> canonical: one wave per 64 bricks reads their "touched" flags; every
-// touched brick is added into (or stored to) the canonical tensor, ZEROED in the bricked buffer and
-// its flag cleared, so the bricked buffer and the flags are all-zero again afterwards.  A fan touches
-// a few thousand of the 524 288 bricks of a 256^3 volume: this replaces a 64 MiB memset plus a
-// 128 MiB dense conversion per step.
+// Bricked gradient scratch -> canonical tensor.  Every touched brick (flag != 0) is added into (or stored to) the
+// canonical tensor, ZEROED in the bricked buffer and its flag cleared, so the bricked buffer and the flags are all-zero
+// again afterwards.  A fan touches a few thousand of the 524 288 bricks of a 256^3 volume: this replaces a 64 MiB memset
+// plus a 128 MiB dense conversion per step.
 // mode DIFFUS_FLUSH_PERSISTENT: `out` is a gradient tensor the caller keeps across steps and only this call writes.
 // A brick stored this step gets flag 2 ("out holds last step's values, scratch is zero"); if the next step does not
 // touch it again (the scatter overwrites the flag with 1) its voxels are zeroed in `out` and the flag cleared.  `out`
 // therefore always equals the dense gradient of the latest step without ever being memset.
-// (Tried in round 3: 256 bricks per wave, one 16-byte flag load per lane, 512 blocks instead of 2048 -- 11.2 -> 12.7 us at
-// 32 poses (each wave's serial loop over its touched bricks gets four times longer), 15.0 -> 13.3 us at 256 poses: the
-// 64-brick waves stay.)
-__global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict__ bricked, int *__restrict__ touched,
-                                                               float *__restrict__ out, Geom G, long nbricks,
-                                                               int mode)
+// mode DIFFUS_FLUSH_DENSE (this kernel): every voxel of `out` is written, one lane per brick.
+__global__ __launch_bounds__(kBlock) void gradbuf_flush_dense_kernel(float *__restrict__ bricked, int *__restrict__ touched,
+                                                                     float *__restrict__ out, Geom G, long nbricks)
 {
-    __shared__ int s_list[kWavesPerBlock][kWave];
     const int wib = threadIdx.x >> 6;
     const long w = (long)blockIdx.x * kWavesPerBlock + wib;
     const int lane = threadIdx.x & 63;
@@ -841,7 +836,7 @@ __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict
     if (b0 >= nbricks) return;
     const long mine = b0 + lane;
     int f = (mine < nbricks) ? touched[mine] : 0;
-    if (mode == DIFFUS_FLUSH_DENSE) {
+    {
         // EVERY voxel of `out` is written: a lane takes one brick, the wave 64 consecutive ones -- consecutive along dim 2,
         // so that each of a brick's 16 (x, y) rows is a 512-byte run of the canonical tensor across the wave.
         if (mine >= nbricks) return;
@@ -871,34 +866,78 @@ __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict
         }
         return;
     }
-    unsigned long long m = __ballot(f != 0);
-    if (m == 0) return; // wave-uniform: nothing touched in these 64 bricks
-    if (f) {
-        touched[mine] = (mode == DIFFUS_FLUSH_PERSISTENT && f == 1) ? 2 : 0;
-        // compact the touched ids; bit 6 marks a stale brick (nothing new, clear what the last step left)
-        s_list[wib][__builtin_popcountll(m & ((1ull << lane) - 1))] = lane | (f == 2 ? 64 : 0);
+}
+
+// The sparse modes.  A wave reads the flags of 256 consecutive bricks (four coalesced loads), compacts the ids of the
+// touched ones into LDS and walks them EIGHT per trip: 8 lanes per brick, a lane moving four floats = the z pairs of two
+// neighbouring (x, y) rows.  (Rounds 2-3: 64 bricks per wave, two per trip -- 2048 blocks whose launch and flag reads were
+// most of the kernel at 32 poses; 256 bricks per wave at two per trip was slower there, the serial walk four times longer.)
+constexpr int kFlushBricks = 256;
+template <bool VEC2> // VEC2: d2 even and `out` 8-byte aligned -- a z pair is one aligned 8-byte word of the canonical tensor
+__global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict__ bricked, int *__restrict__ touched,
+                                                               float *__restrict__ out, Geom G, long nbricks, int mode)
+{
+    __shared__ short s_list[kWavesPerBlock][kFlushBricks];
+    const int wib = threadIdx.x >> 6;
+    const long w = (long)blockIdx.x * kWavesPerBlock + wib;
+    const int lane = threadIdx.x & 63;
+    const long b0 = w * kFlushBricks;
+    if (b0 >= nbricks) return;
+    int f[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const long mine = b0 + c * kWave + lane;
+        f[c] = (mine < nbricks) ? touched[mine] : 0;
+    }
+    if (__ballot((f[0] | f[1] | f[2] | f[3]) != 0) == 0ull) return; // wave-uniform: nothing touched in these 256 bricks
+    int cnt = 0;
+    const unsigned long long below = (1ull << lane) - 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned long long m = __ballot(f[c] != 0);
+        if (f[c]) {
+            touched[b0 + c * kWave + lane] = (mode == DIFFUS_FLUSH_PERSISTENT && f[c] == 1) ? 2 : 0;
+            // bit 8 marks a stale brick (nothing new this step: clear what the last step left in `out`)
+            s_list[wib][cnt + __builtin_popcountll(m & below)] = (short)((c * kWave + lane) | (f[c] == 2 ? 256 : 0));
+        }
+        cnt += __builtin_popcountll(m);
     }
     wave_lds_sync();
-    const int cnt = __builtin_popcountll(m);
-    const int o = lane & 31, half = lane >> 5;
-    // two bricks per step (one per half-wave); iterations are independent so their loads overlap
-#pragma unroll 4
-    for (int i = half; i < cnt; i += 2) {
+    const int sub = lane & 7, grp = lane >> 3;
+    // the lane's two rows inside a brick: x = sub / 2, y = 2 (sub % 2) and the next one; floats 4 sub .. 4 sub + 3
+    const int xl = sub >> 1, yl = (sub & 1) * 2;
+#pragma unroll 2
+    for (int i = grp; i < cnt; i += 8) { // trips are independent: their loads overlap
         const int e = s_list[wib][i];
-        const long brick = b0 + (e & 63);
-        float v = 0.f;
-        if (!(e & 64)) { // wave-half-uniform
-            v = bricked[brick * kBrickFloats + o];
-            bricked[brick * kBrickFloats + o] = 0.f;
+        const long brick = b0 + (e & 255);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(e & 256)) { // uniform over the brick's 8 lanes
+            float4 *src = reinterpret_cast<float4 *>(bricked + brick * kBrickFloats + sub * 4);
+            v = *src;
+            *src = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // 32-bit index arithmetic (a volume has fewer than 2^25 bricks): the 64-bit divisions that stood here were ~200 of the
-        // kernel's 287 VALU instructions per wave, on the dependent chain of every touched brick
+        // 32-bit index arithmetic (a volume has fewer than 2^25 bricks)
         const unsigned ub = (unsigned)brick, t = ub / (unsigned)G.nb2, bz = ub - t * (unsigned)G.nb2;
         const unsigned bx = t / (unsigned)G.nb1, by = t - bx * (unsigned)G.nb1;
-        int x = (int)bx * 4 + (o >> 3), y = (int)by * 4 + ((o >> 1) & 3), z = (int)bz * 2 + (o & 1);
-        if (x < G.d0 && y < G.d1 && z < G.d2) {
-            long a = ((long)x * G.d1 + y) * G.d2 + z;
-            out[a] = (mode == DIFFUS_FLUSH_ACCUMULATE) ? out[a] + v : v;
+        const int x = (int)bx * 4 + xl, y = (int)by * 4 + yl, z = (int)bz * 2;
+        if (x >= G.d0) continue;
+        float *o = out + ((long)x * G.d1 + y) * G.d2 + z;
+#pragma unroll
+        for (int r = 0; r < 2; ++r, o += G.d2) {
+            if (y + r >= G.d1) break;
+            const float v0 = r ? v.z : v.x, v1 = r ? v.w : v.y;
+            if (VEC2) { // z + 1 < d2 always: d2 is even
+                float2 *o2 = reinterpret_cast<float2 *>(o);
+                if (mode == DIFFUS_FLUSH_ACCUMULATE) {
+                    const float2 q = *o2;
+                    *o2 = make_float2(q.x + v0, q.y + v1);
+                } else {
+                    *o2 = make_float2(v0, v1);
+                }
+            } else {
+                o[0] = (mode == DIFFUS_FLUSH_ACCUMULATE) ? o[0] + v0 : v0;
+                if (z + 1 < G.d2) o[1] = (mode == DIFFUS_FLUSH_ACCUMULATE) ? o[1] + v1 : v1;
+            }
         }
     }
 }
@@ -964,10 +1003,19 @@ int diffus_gradbuf_flush(float *bricked, int *touched, int d0, int d1, int d2, f
     if (accumulate < DIFFUS_FLUSH_STORE || accumulate > DIFFUS_FLUSH_DENSE) return DIFFUS_EINVAL;
     Geom G = make_geom(d0, d1, d2);
     const long nbricks = (long)(bricked_floats(d0, d1, d2) / kBrickFloats);
-    const long waves = (nbricks + kWave - 1) / kWave;
+    if (reinterpret_cast<uintptr_t>(bricked) & 15) return DIFFUS_EINVAL; // a brick is read as 16-byte words
+    const long per_wave = accumulate == DIFFUS_FLUSH_DENSE ? kWave : kFlushBricks;
+    const long waves = (nbricks + per_wave - 1) / per_wave;
     const unsigned nblk = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(gradbuf_flush_kernel, dim3(nblk), dim3(kBlock), 0, (hipStream_t)stream, bricked, touched, vol, G,
-                       nbricks, accumulate);
+    if (accumulate == DIFFUS_FLUSH_DENSE)
+        hipLaunchKernelGGL(gradbuf_flush_dense_kernel, dim3(nblk), dim3(kBlock), 0, (hipStream_t)stream, bricked, touched, vol,
+                           G, nbricks);
+    else if (!(d2 & 1) && !(reinterpret_cast<uintptr_t>(vol) & 7))
+        hipLaunchKernelGGL(gradbuf_flush_kernel<true>, dim3(nblk), dim3(kBlock), 0, (hipStream_t)stream, bricked, touched, vol,
+                           G, nbricks, accumulate);
+    else
+        hipLaunchKernelGGL(gradbuf_flush_kernel<false>, dim3(nblk), dim3(kBlock), 0, (hipStream_t)stream, bricked, touched, vol,
+                           G, nbricks, accumulate);
     return last_launch();
 }
 

@@ -117,6 +117,8 @@ size_t diffus_workspace_zbar_offset(int P, int R, int S, int start);
  * step and is never memset.  (`touched` then holds 2 for the bricks `vol` currently has values in.)
  * Mode DENSE writes EVERY voxel of `vol`: the touched bricks' values and zeros everywhere else -- a fresh dense
  * gradient in one launch (the drop-in autograd path: no torch.zeros + flush, i.e. one launch and one dispatch fewer).
+ * `bricked` must be 16-byte aligned (DIFFUS_EINVAL otherwise; any hipMalloc / torch allocation is); `vol` may sit at
+ * any float offset (8-byte aligned and d2 even: a z pair moves as one word).
  */
 #define DIFFUS_FLUSH_STORE      0
 #define DIFFUS_FLUSH_ACCUMULATE 1

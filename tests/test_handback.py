@@ -115,6 +115,52 @@ def test_flush_mode_dense_writes_every_voxel(d):
     assert torch.all(bricked == 0) and torch.all(touched == 0)
 
 
+@pytest.mark.parametrize("mode", ["store", "accumulate", "persistent"])
+@pytest.mark.parametrize("d,shift", [((9, 10, 7), 0), ((8, 8, 8), 0), ((5, 3, 1), 0), ((64, 64, 64), 0), ((33, 70, 130), 0),
+                                     ((33, 70, 130), 1), ((40, 36, 129), 0)])
+def test_flush_sparse_modes_all_shapes(d, shift, mode):
+    """The sparse modes of diffus_gradbuf_flush (a wave per 256 bricks, eight bricks per trip, 16-byte reads of the scratch,
+    8-byte words of the canonical tensor when dim 2 is even and the tensor 8-byte aligned): edge bricks, odd dim 2, a brick
+    count that is no multiple of 256, a canonical tensor at an odd float offset (`shift`), stale bricks (flag 2)."""
+    from diffus_amd import _lib
+    lib = _lib.load()
+    nb = lib.diffus_brick_count(*d)
+    nf = lib.diffus_bricked_floats(*d)
+    g = torch.Generator().manual_seed(sum(d) + shift)
+    dense = torch.randn(d, generator=g).cuda()
+    bricked = torch.zeros(nf, device="cuda")
+    assert lib.diffus_brick_volume(vp(dense), *d, vp(bricked), None) == 0
+    pick = (torch.rand(nb, generator=g) < 0.3).cuda()
+    stale = (~pick) & (torch.rand(nb, generator=g) < 0.2).cuda()
+    touched = pick.to(torch.int32) + 2 * stale.to(torch.int32)
+    bricked.copy_((bricked.view(nb, 32) * pick[:, None]).reshape(-1))
+    # what the picked / the stale bricks cover, as canonical masks and values
+    def canon(per_brick):
+        b = per_brick.reshape(-1).contiguous()
+        out = torch.empty(d, device="cuda")
+        assert lib.diffus_unbrick_volume(vp(b), *d, vp(out), 0, None) == 0
+        torch.cuda.synchronize()
+        return out
+    ones = torch.ones(nb, 32, device="cuda")
+    in_pick, in_stale = canon(ones * pick[:, None]) != 0, canon(ones * stale[:, None]) != 0
+    vals = canon(bricked.view(nb, 32).clone())
+    store = torch.empty(int(torch.tensor(d).prod()) + shift, device="cuda")
+    out = store[shift:].view(d)
+    out.copy_(torch.full(d, 5.0))
+    code = {"store": _lib.FLUSH_STORE, "accumulate": _lib.FLUSH_ACCUMULATE, "persistent": _lib.FLUSH_PERSISTENT}[mode]
+    assert lib.diffus_gradbuf_flush(vp(bricked), vp(touched), *d, vp(out), code, None) == 0
+    torch.cuda.synchronize()
+    want = torch.full(d, 5.0, device="cuda")
+    if mode == "accumulate":
+        want[in_pick] += vals[in_pick]
+    else:
+        want[in_pick] = vals[in_pick]
+        want[in_stale] = 0.0                                             # a stale brick: cleared in `out`
+    assert torch.equal(out, want)
+    assert torch.all(bricked == 0)
+    assert torch.equal(touched, (2 * pick.to(torch.int32)) if mode == "persistent" else torch.zeros_like(touched))
+
+
 @pytest.mark.parametrize("P,n", [(1, 4), (3, 1000), (32, 256 * 512), (5, 131073)])
 def test_loss_sumsq_single_launch(P, n):
     from diffus_amd import _lib
