@@ -16,13 +16,16 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle.so")
+# DIFFUS_ORACLE_SO: another build of the same source (oracle/Makefile `sanitize`, tools/oracle_sanitize.sh)
+_SO = os.environ.get("DIFFUS_ORACLE_SO") or os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (seconds).  Idempotent."""
     src = os.path.join(_HERE, "diffus_oracle.c")
+    if os.environ.get("DIFFUS_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
     return _SO
