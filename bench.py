@@ -455,8 +455,16 @@ def callers_legs(args, vol, dev):
         st.capture()
         leg[f"{layout}_ms_per_step"] = time_events(st.replay, 30)["median"]
         del st
+    # ... or ONE slice of it (the reference's MLP training loop rewrites the slice the fan lies in): only that slice's records
+    for layout in ("paired", "bricked"):
+        st = CapturedStep(vol, sa, da, args.samples, args.alpha, args.sampler, layout=layout, learnable_volume=True)
+        st.dirty_box = ((0, n), (0, n), (n // 2, n // 2 + 1))
+        st.capture()
+        leg[f"{layout}_one_slice_ms_per_step"] = time_events(st.replay, 30)["median"]
+        del st
     leg["note"] = ("headline workload with the volume re-converted inside every step (paired: diffus_pair_volume, bricked: "
-                   "diffus_brick_volume, canonical: no conversion, kernels read the caller's tensor)")
+                   "diffus_brick_volume, canonical: no conversion, kernels read the caller's tensor); *_one_slice: the caller "
+                   "rewrites one dim-2 slice per step and sets CapturedStep.dirty_box (diffus_convert_volume_box)")
     out["learnable_volume"] = leg
     # (c) poses that move: a different ring of poses every step, copied in place into the captured step's buffers
     pool = [pose_ring(n, args.poses, args.rays, phase=0.013 * i) for i in range(16)]

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DIFFUS_LIB") or os.path.join(_HERE, "libdiffus_hip.so
 
 EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "diffus_workspace_zbar_offset",
            "diffus_bricked_floats", "diffus_brick_volume", "diffus_unbrick_volume", "diffus_paired_floats",
-           "diffus_pair_volume", "diffus_brick_count", "diffus_gradbuf_flush",
+           "diffus_pair_volume", "diffus_convert_volume_box", "diffus_brick_count", "diffus_gradbuf_flush",
            "diffus_render_fwd", "diffus_render_bwd", "diffus_render_bwd_mse", "diffus_render_step_mse", "diffus_trace_rays", "diffus_echo_traces",
            "diffus_loss_sumsq", "diffus_splat_workspace_bytes", "diffus_splat_fwd", "diffus_splat_bwd",
            "diffus_artifacts_workspace_bytes", "diffus_artifacts",
@@ -23,7 +23,7 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
            "diffus_echo_bwd_workspace_bytes", "diffus_echo_traces_bwd", "diffus_splat_axes", "diffus_rotate_around_apex",
            "diffus_ssim_workspace_bytes", "diffus_ssim_loss_fwd", "diffus_ssim_loss_bwd")
 
-ABI_VERSION = 5          # include/diffus_hip.h DIFFUS_ABI_VERSION
+ABI_VERSION = 6          # include/diffus_hip.h DIFFUS_ABI_VERSION
 DIFFUS_F32, DIFFUS_F64, DIFFUS_I64 = 0, 1, 2
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
@@ -82,6 +82,8 @@ def load():
     lib.diffus_paired_floats.argtypes = [i, i, i]
     lib.diffus_pair_volume.restype = i
     lib.diffus_pair_volume.argtypes = [vp, i, i, i, vp, vp]
+    lib.diffus_convert_volume_box.restype = i
+    lib.diffus_convert_volume_box.argtypes = [vp, i, i, i, i, vp, i, i, i, i, i, i, vp]
     lib.diffus_brick_volume.restype = i
     lib.diffus_brick_volume.argtypes = [vp, i, i, i, vp, vp]
     lib.diffus_unbrick_volume.restype = i

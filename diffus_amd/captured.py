@@ -169,6 +169,9 @@ class CapturedStep:
         self.S, self.start, self.alpha = int(num_samples), int(start), float(attenuation_coeff)
         self.N1 = self.S - self.start
         self.learnable_volume = bool(learnable_volume)
+        # learnable_volume: step() re-converts the volume first; all of it, or -- when the caller sets this to
+        # ((x0, x1), (y0, y1), (z0, z1)) -- only the part it rewrites between steps (refresh_volume)
+        self.dirty_box = None
         # render(): hand autograd the step's own gradient buffers instead of clones of them.  Fine for the usual loop
         # (optimizer.zero_grad(set_to_none=True), one backward per forward); a .grad that autograd adopted is then
         # overwritten in place by the next step.
@@ -260,10 +263,20 @@ class CapturedStep:
             self.dirs.copy_(directions.reshape(self.dirs.shape))
         self._stamp += 1            # a frame rendered before this call can no longer be back-propagated
 
-    def refresh_volume(self):
-        """Rebuild the converted copy from `self.vol` (after the caller changed the volume in place)."""
+    def refresh_volume(self, box=None):
+        """Rebuild the converted copy from `self.vol` (after the caller changed the volume in place).
+        box = ((x0, x1), (y0, y1), (z0, z1)), half-open, or `self.dirty_box` when set: only that part of the canonical
+        volume changed since the last conversion -- the reference's training loop rewrites one slice per step -- and only
+        the records / bricks that hold it are rebuilt (diffus_convert_volume_box)."""
         self._conv_stamp += 1
         self._stamp += 1
+        box = box if box is not None else self.dirty_box
+        if box is not None and self.layout != _lib.CANONICAL:
+            (x0, x1), (y0, y1), (z0, z1) = box
+            _lib.check(self.lib.diffus_convert_volume_box(_vp(self.vol), *self.dims, self.layout, _vp(self.vol_k), int(x0), int(x1),
+                                                          int(y0), int(y1), int(z0), int(z1), self.stream()),
+                       "diffus_convert_volume_box")
+            return
         if self.layout == _lib.BRICKED:
             _lib.check(self.lib.diffus_brick_volume(_vp(self.vol), *self.dims, _vp(self.vol_k), self.stream()), "diffus_brick_volume")
         elif self.layout == _lib.PAIRED:

@@ -776,35 +776,36 @@ namespace {
 // canonical <-> bricked conversion.  A block moves 4 x 4 x 64 voxels (32 bricks,
 // 4 KiB): 16 canonical rows of 256 B on one side, 4 KiB contiguous on the other,
 // through an LDS transpose so that both sides are coalesced.
-constexpr int kConvZ = 64;
-template <bool TO_BRICKED, bool ACCUMULATE>
+constexpr int kConvZ = 64, kConvZThin = 8; // depths per block: whole volumes / thin sub-boxes (diffus_convert_volume_box)
+template <bool TO_BRICKED, bool ACCUMULATE, int CZ = kConvZ>
 __global__ __launch_bounds__(kBlock) void brick_convert_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                               Geom G)
+                                                               Geom G, int zblk0 = 0, int by_0 = 0, int bx_0 = 0)
 {
-    __shared__ float t[16][kConvZ + 1];
-    const int bz0 = blockIdx.x * (kConvZ / 2); // first brick along dim 2
-    const int by = blockIdx.y, bx = blockIdx.z;
+    __shared__ float t[16][CZ + 1];
+    // (zblk0, by_0, bx_0): the first block of a sub-box conversion (diffus_convert_volume_box); 0 for a whole volume
+    const int bz0 = ((int)blockIdx.x + zblk0) * (CZ / 2); // first brick along dim 2
+    const int by = blockIdx.y + by_0, bx = blockIdx.z + bx_0;
     const int tid = threadIdx.x;
     const long brick0 = ((long)bx * G.nb1 + by) * G.nb2 + bz0;
     if (TO_BRICKED) {
-        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
-            int row = e / kConvZ, zz = e - row * kConvZ;
+        for (int e = tid; e < 16 * CZ; e += kBlock) {
+            int row = e / CZ, zz = e - row * CZ;
             int x = bx * 4 + (row >> 2), y = by * 4 + (row & 3), z = bz0 * 2 + zz;
             t[row][zz] = (x < G.d0 && y < G.d1 && z < G.d2) ? in[((long)x * G.d1 + y) * G.d2 + z] : 0.f;
         }
         __syncthreads();
-        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+        for (int e = tid; e < 16 * CZ; e += kBlock) {
             int brick = e >> 5, off = e & 31;
             if (bz0 + brick < G.nb2) out[(brick0 + brick) * kBrickFloats + off] = t[off >> 1][brick * 2 + (off & 1)];
         }
     } else {
-        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
+        for (int e = tid; e < 16 * CZ; e += kBlock) {
             int brick = e >> 5, off = e & 31;
             if (bz0 + brick < G.nb2) t[off >> 1][brick * 2 + (off & 1)] = in[(brick0 + brick) * kBrickFloats + off];
         }
         __syncthreads();
-        for (int e = tid; e < 16 * kConvZ; e += kBlock) {
-            int row = e / kConvZ, zz = e - row * kConvZ;
+        for (int e = tid; e < 16 * CZ; e += kBlock) {
+            int row = e / CZ, zz = e - row * CZ;
             int x = bx * 4 + (row >> 2), y = by * 4 + (row & 3), z = bz0 * 2 + zz;
             if (x < G.d0 && y < G.d1 && z < G.d2) {
                 long o = ((long)x * G.d1 + y) * G.d2 + z;
@@ -951,23 +952,26 @@ __global__ __launch_bounds__(kBlock) void gradbuf_flush_kernel(float *__restrict
 #ifndef DIFFUS_PC_Z
 #define DIFFUS_PC_Z 128
 #endif
-constexpr int kPcZ = DIFFUS_PC_Z, kPcCols = 9, kPcRows = 4 * kPcCols;
-__global__ __launch_bounds__(kBlock) void pair_convert_kernel(const float *__restrict__ in, float *__restrict__ out, Geom G)
+constexpr int kPcZ = DIFFUS_PC_Z, kPcZThin = 8, kPcCols = 9, kPcRows = 4 * kPcCols; // kPcZThin: thin sub-boxes (diffus_convert_volume_box)
+template <int PZ = kPcZ>
+__global__ __launch_bounds__(kBlock) void pair_convert_kernel(const float *__restrict__ in, float *__restrict__ out, Geom G,
+                                                              int zblk0 = 0, int byp0 = 0, int bx_0 = 0)
 {
-    __shared__ float t[kPcRows][kPcZ + 2];
-    const int z0 = blockIdx.x * kPcZ;
-    const int by0 = blockIdx.y * 2, bx = blockIdx.z;
+    __shared__ float t[kPcRows][PZ + 2];
+    // (zblk0, byp0, bx_0): the first block of a sub-box conversion (diffus_convert_volume_box); 0 for a whole volume
+    const int z0 = ((int)blockIdx.x + zblk0) * PZ;
+    const int by0 = ((int)blockIdx.y + byp0) * 2, bx = blockIdx.z + bx_0;
     const int tid = threadIdx.x;
-    for (int e = tid; e < kPcRows * (kPcZ + 1); e += kBlock) {
-        int row = e / (kPcZ + 1), zz = e - row * (kPcZ + 1); // row = (x & 3) * 9 + column 0..8
+    for (int e = tid; e < kPcRows * (PZ + 1); e += kBlock) {
+        int row = e / (PZ + 1), zz = e - row * (PZ + 1); // row = (x & 3) * 9 + column 0..8
         int x = min(bx * 4 + row / kPcCols, G.d0 - 1), y = min(by0 * 4 + row % kPcCols, G.d1 - 1), z = min(z0 + zz, G.d2 - 1);
         t[row][zz] = in[((long)x * G.d1 + y) * G.d2 + z];
     }
     __syncthreads();
     // float4 = the (z, z + 1) pairs of two neighbouring columns of one x-row: 10 per record
     constexpr int V4 = kPairFloats / 4;
-    for (int e = tid; e < 2 * kPcZ * V4; e += kBlock) {
-        const int half = e / (kPcZ * V4), r = e - half * (kPcZ * V4);
+    for (int e = tid; e < 2 * PZ * V4; e += kBlock) {
+        const int half = e / (PZ * V4), r = e - half * (PZ * V4);
         const int zz = r / V4, q = r - zz * V4;       // q-th float4 of the record: pairs 2q and 2q + 1
         const int by = by0 + half;
         if (by < G.nb1 && z0 + zz < G.d2) {
@@ -1031,8 +1035,44 @@ int diffus_pair_volume(const float *vol, int d0, int d1, int d2, float *paired, 
     Geom G = make_geom(d0, d1, d2);
     dim3 grid((d2 + kPcZ - 1) / kPcZ, (G.nb1 + 1) / 2, (d0 + 3) / 4);
     if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
-    hipLaunchKernelGGL(pair_convert_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, vol, paired, G);
+    hipLaunchKernelGGL(pair_convert_kernel<kPcZ>, grid, dim3(kBlock), 0, (hipStream_t)stream, vol, paired, G, 0, 0, 0);
     return last_launch();
+}
+
+int diffus_convert_volume_box(const float *vol, int d0, int d1, int d2, int layout, float *converted, int x0, int x1,
+                              int y0, int y1, int z0, int z1, diffus_stream_t stream)
+{
+    if (!vol || !converted || d0 <= 0 || d1 <= 0 || d2 <= 0) return DIFFUS_EINVAL;
+    if (layout != DIFFUS_BRICKED && layout != DIFFUS_PAIRED) return DIFFUS_EINVAL;
+    if (x0 < 0 || y0 < 0 || z0 < 0 || x1 > d0 || y1 > d1 || z1 > d2) return DIFFUS_EINVAL;
+    if (x0 >= x1 || y0 >= y1 || z0 >= z1) return DIFFUS_OK; // an empty box
+    Geom G = make_geom(d0, d1, d2);
+    const int bx_lo = x0 >> 2, bx_hi = (x1 - 1) >> 2; // brick rows (4 voxels of dim 0): no layout repeats a dim-0 neighbour
+    // depths per block: the whole-volume kernels' (128 / 64: long coalesced rows) for a deep box, 8 for a thin one -- a
+    // slice of constant dim 2, the plane every fan of the reference lies in, is two depths of records
+    auto launch = [&](auto kernel_for, int per_block, int zlo, int zhi, int by_lo, int by_hi) { // depths zlo..zhi; by_lo..by_hi in blocks
+        const dim3 grid(zhi / per_block - zlo / per_block + 1, by_hi - by_lo + 1, bx_hi - bx_lo + 1);
+        if (grid.y > 65535 || grid.z > 65535) return (int)DIFFUS_EUNSUPPORTED;
+        kernel_for(grid, zlo / per_block, by_lo);
+        return last_launch();
+    };
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == DIFFUS_PAIRED) {
+        // A record (brick column by, depth z) repeats the first column of brick column by + 1 and the depth z + 1: the
+        // records that hold a voxel of [y0, y1) x [z0, z1) are brick columns (y0 - 1) / 4 .. (y1 - 1) / 4, depths z0 - 1 .. z1 - 1
+        const int by_lo = max(y0 - 1, 0) >> 2, by_hi = (y1 - 1) >> 2, zr_lo = max(z0 - 1, 0), zr_hi = z1 - 1;
+        if (zr_hi - zr_lo < 2 * kPcZThin)
+            return launch([&](dim3 g, int zb, int byp) { hipLaunchKernelGGL(pair_convert_kernel<kPcZThin>, g, dim3(kBlock), 0, st, vol, converted, G, zb, byp, bx_lo); },
+                          kPcZThin, zr_lo, zr_hi, by_lo >> 1, by_hi >> 1);
+        return launch([&](dim3 g, int zb, int byp) { hipLaunchKernelGGL(pair_convert_kernel<kPcZ>, g, dim3(kBlock), 0, st, vol, converted, G, zb, byp, bx_lo); },
+                      kPcZ, zr_lo, zr_hi, by_lo >> 1, by_hi >> 1);
+    }
+    const int by_lo = y0 >> 2, by_hi = (y1 - 1) >> 2;
+    if (z1 - z0 <= 2 * kConvZThin)
+        return launch([&](dim3 g, int zb, int by) { hipLaunchKernelGGL((brick_convert_kernel<true, false, kConvZThin>), g, dim3(kBlock), 0, st, vol, converted, G, zb, by, bx_lo); },
+                      kConvZThin, z0, z1 - 1, by_lo, by_hi);
+    return launch([&](dim3 g, int zb, int by) { hipLaunchKernelGGL((brick_convert_kernel<true, false, kConvZ>), g, dim3(kBlock), 0, st, vol, converted, G, zb, by, bx_lo); },
+                  kConvZ, z0, z1 - 1, by_lo, by_hi);
 }
 
 int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked, diffus_stream_t stream)
@@ -1041,7 +1081,7 @@ int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked
     Geom G = make_geom(d0, d1, d2);
     dim3 grid((G.nb2 + kConvZ / 2 - 1) / (kConvZ / 2), G.nb1, (d0 + 3) / 4);
     if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
-    hipLaunchKernelGGL((brick_convert_kernel<true, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, vol, bricked, G);
+    hipLaunchKernelGGL((brick_convert_kernel<true, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, vol, bricked, G, 0, 0, 0);
     return last_launch();
 }
 
@@ -1053,9 +1093,9 @@ int diffus_unbrick_volume(const float *bricked, int d0, int d1, int d2, float *v
     dim3 grid((G.nb2 + kConvZ / 2 - 1) / (kConvZ / 2), G.nb1, (d0 + 3) / 4);
     if (grid.y > 65535 || grid.z > 65535) return DIFFUS_EUNSUPPORTED;
     if (accumulate)
-        hipLaunchKernelGGL((brick_convert_kernel<false, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G);
+        hipLaunchKernelGGL((brick_convert_kernel<false, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G, 0, 0, 0);
     else
-        hipLaunchKernelGGL((brick_convert_kernel<false, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G);
+        hipLaunchKernelGGL((brick_convert_kernel<false, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, bricked, vol, G, 0, 0, 0);
     return last_launch();
 }
 

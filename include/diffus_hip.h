@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DIFFUS_ABI_VERSION 5 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd; 5: winner raster kept between diffus_splat_fwd / _bwd */
+#define DIFFUS_ABI_VERSION 6 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd; 5: winner raster kept between diffus_splat_fwd / _bwd; 6: diffus_convert_volume_box */
 
 /* error codes */
 #define DIFFUS_OK            0
@@ -104,6 +104,12 @@ size_t diffus_workspace_zbar_offset(int P, int R, int S, int start);
  *   diffus_unbrick_volume  bricked -> canonical; accumulate != 0 adds instead of
  *                          storing (used to fold a bricked gradient into a
  *                          canonical one)
+ *   diffus_convert_volume_box   canonical -> `layout` (DIFFUS_BRICKED or DIFFUS_PAIRED) for every record / brick that
+ *                          holds a voxel of the box [x0,x1) x [y0,y1) x [z0,z1) -- what a caller runs after it
+ *                          changed only that part of the canonical volume (the reference's training loop rewrites ONE
+ *                          slice per step: notebooks/[DEMO] Train MRI to Impedance MLP - GPU.ipynb cell 16), instead of
+ *                          a pass over the whole volume.  Whole blocks of the conversion kernels are re-converted, i.e.
+ *                          somewhat more than the box; an empty box is a no-op.
  */
 /*
  * Sparse gradient hand-back.  diffus_gradbuf_flush visits only the bricks whose flag is set:
@@ -136,6 +142,8 @@ int diffus_brick_volume(const float *vol, int d0, int d1, int d2, float *bricked
                         diffus_stream_t stream);
 int diffus_unbrick_volume(const float *bricked, int d0, int d1, int d2, float *vol,
                           int accumulate, diffus_stream_t stream);
+int diffus_convert_volume_box(const float *vol, int d0, int d1, int d2, int layout, float *converted,
+                              int x0, int x1, int y0, int y1, int z0, int z1, diffus_stream_t stream);
 
 /*
  * Forward: replaces UltrasoundRenderer.plot_beam_frame with artifacts=False

@@ -31,7 +31,7 @@ def test_header_and_exports_agree(lib):
     assert sorted(_lib.EXPORTS) == names
     for n in names:
         assert getattr(lib, n) is not None          # dlsym succeeds
-    assert lib.diffus_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.diffus_abi_version() == _lib.ABI_VERSION == 6
     assert lib.diffus_strerror(0) == b"ok"
     assert b"workspace" in lib.diffus_strerror(-4)
 
@@ -83,6 +83,10 @@ def test_argument_validation_without_a_gpu(lib):
     assert lib.diffus_gradbuf_flush(None, p, 2, 2, 2, p, 1, None) == -1
     assert lib.diffus_echo_traces(None, 1, 4, p, None) == -1
     assert lib.diffus_brick_volume(None, 2, 2, 2, p, None) == -1
+    assert lib.diffus_convert_volume_box(None, 2, 2, 2, 1, p, 0, 1, 0, 1, 0, 1, None) == -1      # null volume
+    assert lib.diffus_convert_volume_box(p, 2, 2, 2, 0, p, 0, 1, 0, 1, 0, 1, None) == -1         # canonical is no converted layout
+    assert lib.diffus_convert_volume_box(p, 2, 2, 2, 2, p, 0, 3, 0, 1, 0, 1, None) == -1         # box outside the volume
+    assert lib.diffus_convert_volume_box(p, 2, 2, 2, 2, p, 1, 1, 0, 2, 0, 2, None) == 0          # empty box: nothing launched
     assert lib.diffus_loss_sumsq(p, 0, 4, p, None, p, 1024, None) == -1
     assert lib.diffus_loss_sumsq(p, 1, 4, p, None, None, 0, None) == -4
 

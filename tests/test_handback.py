@@ -161,6 +161,69 @@ def test_flush_sparse_modes_all_shapes(d, shift, mode):
     assert torch.equal(touched, (2 * pick.to(torch.int32)) if mode == "persistent" else torch.zeros_like(touched))
 
 
+@pytest.mark.parametrize("layout", ["bricked", "paired"])
+@pytest.mark.parametrize("d", [(9, 10, 7), (8, 8, 8), (5, 3, 1), (64, 64, 64), (33, 70, 300), (12, 9, 130)])
+def test_convert_volume_box_equals_a_full_conversion(d, layout):
+    """diffus_convert_volume_box after a change confined to a box == converting the whole changed volume: slices along
+    every axis (the reference's training loop rewrites one slice per step), corners, random boxes, the whole volume, an
+    empty box; the paired records' repeated neighbours (next column, next depth) included."""
+    from diffus_amd import _lib
+    lib = _lib.load()
+    code = {"bricked": _lib.BRICKED, "paired": _lib.PAIRED}[layout]
+    nf = lib.diffus_bricked_floats(*d) if layout == "bricked" else lib.diffus_paired_floats(*d)
+    full = lib.diffus_brick_volume if layout == "bricked" else lib.diffus_pair_volume
+    g = torch.Generator().manual_seed(sum(d))
+    rng = np.random.default_rng(sum(d))
+    vol = torch.randn(d, generator=g).cuda()
+    conv = torch.zeros(nf, device="cuda")
+    assert full(vp(vol), *d, vp(conv), None) == 0
+    boxes = [((0, d[0]), (0, d[1]), (0, d[2])), ((0, 0), (0, d[1]), (0, d[2]))]
+    for ax in range(3):                                                  # one slice along each axis: first, last, a middle one
+        for k in {0, d[ax] - 1, d[ax] // 2}:
+            b = [(0, d[0]), (0, d[1]), (0, d[2])]
+            b[ax] = (k, k + 1)
+            boxes.append(tuple(b))
+    for _ in range(6):
+        lo = [int(rng.integers(0, n)) for n in d]
+        boxes.append(tuple((l, int(rng.integers(l + 1, n + 1))) for l, n in zip(lo, d)))
+    for (x0, x1), (y0, y1), (z0, z1) in boxes:
+        vol[x0:x1, y0:y1, z0:z1] = torch.randn((x1 - x0, y1 - y0, z1 - z0), generator=g).cuda()
+        assert lib.diffus_convert_volume_box(vp(vol), *d, code, vp(conv), x0, x1, y0, y1, z0, z1, None) == 0
+        want = torch.zeros(nf, device="cuda")
+        assert full(vp(vol), *d, vp(want), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(conv, want), ((x0, x1), (y0, y1), (z0, z1))
+
+
+@pytest.mark.parametrize("layout", ["bricked", "paired"])
+def test_learnable_volume_step_with_a_dirty_box(Step, layout):
+    """A volume of which the caller rewrites ONE slice between steps: step() with `dirty_box` set (only that slice's
+    records re-converted) gives what a step with the full conversion gives."""
+    n, P, R, S = 48, 2, 16, 64
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, P, R)
+    s, dd = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+    part = Step(vol.clone(), s, dd, S, 1e-4, "trilinear", layout=layout, learnable_volume=True)
+    whole = Step(vol.clone(), s, dd, S, 1e-4, "trilinear", layout=layout, learnable_volume=True)
+    g = torch.Generator().manual_seed(3)
+    for it in range(4):
+        ax, k = it % 3, 20 + it
+        sl = [slice(None)] * 3
+        sl[ax] = slice(k, k + 1)
+        new = (1.5e6 + 1e5 * torch.randn(vol[tuple(sl)].shape, generator=g)).cuda()
+        box = [(0, n)] * 3
+        box[ax] = (k, k + 1)
+        for st in (part, whole):
+            st.vol[tuple(sl)] = new
+        part.dirty_box = tuple(box)
+        part.step()
+        whole.step()
+        torch.cuda.synchronize()
+        assert torch.equal(part.vol_k, whole.vol_k)
+        assert torch.equal(part.frame, whole.frame) and torch.equal(part.loss, whole.loss)
+        assert float((part.gvol - whole.gvol).abs().max()) <= 1e-5 * float(whole.gvol.abs().max())
+
+
 @pytest.mark.parametrize("P,n", [(1, 4), (3, 1000), (32, 256 * 512), (5, 131073)])
 def test_loss_sumsq_single_launch(P, n):
     from diffus_amd import _lib
