@@ -97,6 +97,7 @@ class _CapturedMSE(torch.autograd.Function):
             if not (slice_values.data_ptr() == sl.data_ptr() and slice_values.shape == sl.shape
                     and slice_values.stride() == sl.stride() and slice_values.dtype == sl.dtype):
                 sl.copy_(slice_values)  # (values written straight into slice_view(dim, index) are already in place)
+            step._mark_slice(dim, index)
         step._run("step")
         ctx.step = step
         ctx.where = None if slice_values is None else (dim, index)
@@ -132,6 +133,7 @@ class _SliceIntoVolume(torch.autograd.Function):
         if not (values.data_ptr() == sl.data_ptr() and values.shape == sl.shape and values.stride() == sl.stride()
                 and values.dtype == sl.dtype):
             sl.copy_(values)            # (values written straight into slice_view(dim, index) are already in place)
+        step._mark_slice(dim, index)
         ctx.where = (dim, index)
         return step.vol.detach()
 
@@ -148,7 +150,7 @@ class CapturedStep:
     def __init__(self, volume: torch.Tensor, sources: torch.Tensor, directions: torch.Tensor, num_samples: int,
                  attenuation_coeff: float, sampler: str = "trilinear", start: int = 0, want_gvol: bool = True,
                  layout: str = "paired", sparse: bool = True, persistent: bool = True,
-                 learnable_volume: bool = False, alias_grads: bool = False, fused_loss: bool = True,
+                 learnable_volume=False, alias_grads: bool = False, fused_loss: bool = True,
                  target: Optional[torch.Tensor] = None, loss_scale: float = 1.0, one_pass: bool = True,
                  bricked_grad: Optional[bool] = None):
         if not volume.is_cuda:
@@ -170,8 +172,15 @@ class CapturedStep:
         self.N1 = self.S - self.start
         self.learnable_volume = bool(learnable_volume)
         # learnable_volume: step() re-converts the volume first; all of it, or -- when the caller sets this to
-        # ((x0, x1), (y0, y1), (z0, z1)) -- only the part it rewrites between steps (refresh_volume)
+        # ((x0, x1), (y0, y1), (z0, z1)) -- only the part it rewrites between steps (refresh_volume).
+        # learnable_volume="slice": the volume changes ONLY through volume_with_slice() / mse_loss(slice_values=...) (the
+        # reference's training loop: one slice of predicted impedance per iteration); those calls then set the box themselves.
         self.dirty_box = None
+        self.slice_only = isinstance(learnable_volume, str) and learnable_volume == "slice"
+        if isinstance(learnable_volume, str) and not self.slice_only:
+            raise ValueError("learnable_volume: False, True or 'slice'")
+        self._full_once = False      # a volume copied in by _adopt(): the next conversion covers all of it
+        self._graph_box: dict = {}   # the box a captured "step" / "forward" graph has baked into its conversion launch
         # render(): hand autograd the step's own gradient buffers instead of clones of them.  Fine for the usual loop
         # (optimizer.zero_grad(set_to_none=True), one backward per forward); a .grad that autograd adopted is then
         # overwritten in place by the next step.
@@ -214,6 +223,8 @@ class CapturedStep:
             nk = nb if self.layout == _lib.BRICKED else self.lib.diffus_paired_floats(d0, d1, d2)
             self.vol_k = torch.empty(nk, dtype=torch.float32, device=dev)
             self.refresh_volume()
+            if self.slice_only:
+                self.dirty_box = ((0, 0), (0, 0), (0, 0))     # nothing changes until a slice is written
         else:
             self.vol_k = volume
         if self.grad_bricked:
@@ -271,6 +282,8 @@ class CapturedStep:
         self._conv_stamp += 1
         self._stamp += 1
         box = box if box is not None else self.dirty_box
+        if self._full_once:
+            box, self._full_once = None, False
         if box is not None and self.layout != _lib.CANONICAL:
             (x0, x1), (y0, y1), (z0, z1) = box
             _lib.check(self.lib.diffus_convert_volume_box(_vp(self.vol), *self.dims, self.layout, _vp(self.vol_k), int(x0), int(x1),
@@ -403,6 +416,7 @@ class CapturedStep:
         with torch.cuda.graph(g, stream=self._side):
             fn()
         self._graphs[what] = g
+        self._graph_box[what] = self.dirty_box
         self._graph_keeps_median = getattr(self, "_graph_keeps_median", {})
         self._graph_keeps_median[what] = keeps
         return g
@@ -420,6 +434,9 @@ class CapturedStep:
         if g is not None and what == "backward" and getattr(self, "_graph_keeps_median", {}).get(what) \
                 and not self._median_valid():
             g = None            # the captured launch would reuse a median of other inputs: recompute it eagerly instead
+        if g is not None and what in ("forward", "step") and self.learnable_volume and self.layout != _lib.CANONICAL \
+                and (self._full_once or self._graph_box.get(what) != self.dirty_box):
+            g = None            # the captured conversion covers another part of the volume than the one that changed
         if g is not None:
             g.replay()
             if what in ("forward", "step"):     # the replayed launches leave the median of the current inputs
@@ -439,6 +456,13 @@ class CapturedStep:
                                    "or learnable_volume=True")
         return _SliceIntoVolume.apply(self, values, int(dim), int(index))
 
+    def _mark_slice(self, dim: int, index: int):
+        """learnable_volume="slice": the next conversion rebuilds the records of this slice only."""
+        if self.slice_only:
+            box = [(0, n) for n in self.dims]
+            box[dim % 3] = (index % self.dims[dim % 3], index % self.dims[dim % 3] + 1)
+            self.dirty_box = tuple(box)
+
     def slice_view(self, dim: int, index: int) -> torch.Tensor:
         """The step's volume at `index` along `dim`, as a view (no gradient): somewhere for a producer to write a slice in
         place -- `model(x, scale, out=step.slice_view(2, k))` -- before `volume_with_slice()` / `mse_loss()` get it."""
@@ -455,6 +479,7 @@ class CapturedStep:
                     raise _lib.DiffusError(f"{what}(): a volume other than the step's own needs learnable_volume=True "
                                            "(its converted copy must be rebuilt)")
                 self.vol.copy_(v)
+                self._full_once = True
                 self._stamp += 1
             if s.data_ptr() != self.src.data_ptr():
                 self.src.copy_(s.reshape(self.src.shape))

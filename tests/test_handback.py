@@ -224,6 +224,44 @@ def test_learnable_volume_step_with_a_dirty_box(Step, layout):
         assert float((part.gvol - whole.gvol).abs().max()) <= 1e-5 * float(whole.gvol.abs().max())
 
 
+@pytest.mark.parametrize("layout", ["bricked", "paired"])
+@pytest.mark.parametrize("captured", [False, True])
+def test_learnable_volume_slice_mode_tracks_the_written_slice(Step, layout, captured):
+    """learnable_volume="slice" (the reference's training loop: the volume changes only through the slice an MLP predicts):
+    mse_loss(slice_values=...) / volume_with_slice() mark the slice, the step re-converts that slice's records only --
+    same converted volume, loss and slice gradient as the whole-volume conversion; a captured step whose baked slice is
+    not the one written falls back to eager launches; a foreign volume passed in is converted whole."""
+    n, P, R, S = 48, 2, 16, 64
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, P, R)
+    s, dd = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+    g = torch.Generator().manual_seed(5)
+    tgt = (0.05 * torch.randn((P, R, S), generator=g)).cuda()
+    part = Step(vol.clone(), s, dd, S, 1e-4, "trilinear", layout=layout, learnable_volume="slice", target=tgt)
+    whole = Step(vol.clone(), s, dd, S, 1e-4, "trilinear", layout=layout, learnable_volume=True, target=tgt)
+    plan = [(2, 24), (2, 24), (2, 25), (0, 20), (1, 30), (2, 24)]
+    for it, (dim, k) in enumerate(plan):
+        base = (1.5e6 + 1e5 * torch.randn(tuple(vol.select(dim, k).shape), generator=g)).cuda()
+        grads = []
+        for st in (part, whole):
+            vals = base.clone().requires_grad_(True)
+            loss = st.mse_loss(slice_values=vals, slice_dim=dim, slice_index=k)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads.append((loss.detach().clone(), vals.grad.clone()))
+        assert torch.equal(part.vol_k, whole.vol_k), (it, dim, k)
+        assert torch.equal(grads[0][0], grads[1][0])
+        assert float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-5 * float(grads[1][1].abs().max())
+        if captured and it == 0:
+            part.capture("step")                                   # bakes the conversion of slice (2, 24)
+    # a volume that is not the step's own: copied in, converted whole
+    other = (vol * 1.01).contiguous()
+    for st in (part, whole):
+        st.mse_loss(other)
+    torch.cuda.synchronize()
+    assert torch.equal(part.vol_k, whole.vol_k) and torch.equal(part.loss, whole.loss)
+
+
 @pytest.mark.parametrize("P,n", [(1, 4), (3, 1000), (32, 256 * 512), (5, 131073)])
 def test_loss_sumsq_single_launch(P, n):
     from diffus_amd import _lib
