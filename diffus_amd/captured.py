@@ -33,6 +33,7 @@ import torch
 from . import _lib
 from .renderer import _stream_id
 
+_EMPTY_BOX = ((0, 0), (0, 0), (0, 0))
 _LAYOUT_ID = {"canonical": _lib.CANONICAL, "bricked": _lib.BRICKED, "paired": _lib.PAIRED}
 _SAMPLER_ID = {"nearest": _lib.NEAREST, "prop": _lib.NEAREST, "trilinear": _lib.TRILINEAR}
 
@@ -161,6 +162,7 @@ class CapturedStep:
         dev = volume.device
         self.dev = dev
         self.vol = volume
+        self.dims = tuple(int(x) for x in volume.shape)
         self.src = _pose_tensor(sources, dev).reshape(-1, 3)
         self.dirs = _pose_tensor(directions, dev)
         if self.dirs.dim() != 3 or self.dirs.shape[0] != self.src.shape[0] or self.dirs.shape[2] != 3:
@@ -175,8 +177,9 @@ class CapturedStep:
         # ((x0, x1), (y0, y1), (z0, z1)) -- only the part it rewrites between steps (refresh_volume).
         # learnable_volume="slice": the volume changes ONLY through volume_with_slice() / mse_loss(slice_values=...) (the
         # reference's training loop: one slice of predicted impedance per iteration); those calls then set the box themselves.
-        self.dirty_box = None
+        self._dirty_box = None
         self.slice_only = isinstance(learnable_volume, str) and learnable_volume == "slice"
+        self.eager_fallbacks = 0     # replay()s that ran eagerly because the captured launches did not fit the inputs
         if isinstance(learnable_volume, str) and not self.slice_only:
             raise ValueError("learnable_volume: False, True or 'slice'")
         self._full_once = False      # a volume copied in by _adopt(): the next conversion covers all of it
@@ -204,8 +207,7 @@ class CapturedStep:
         self.frame = torch.empty((self.P, self.R, self.N1), dtype=torch.float32, device=dev)
         self.gframe = torch.empty_like(self.frame)
         self.unit = torch.ones((), dtype=torch.float32, device=dev)     # `loss.backward(step.unit)`: see _CapturedMSE.backward
-        d0, d1, d2 = (int(x) for x in volume.shape)
-        self.dims = (d0, d1, d2)
+        d0, d1, d2 = self.dims
         # canonical gradient, what the caller gets.  persistent: the tensor is kept across steps and
         # diffus_gradbuf_flush(PERSISTENT) clears what the previous step left where this step adds nothing, so it
         # always equals this step's dense gradient without a 64 MiB memset per step.
@@ -224,7 +226,7 @@ class CapturedStep:
             self.vol_k = torch.empty(nk, dtype=torch.float32, device=dev)
             self.refresh_volume()
             if self.slice_only:
-                self.dirty_box = ((0, 0), (0, 0), (0, 0))     # nothing changes until a slice is written
+                self.dirty_box = _EMPTY_BOX                    # nothing changes until a slice is written
         else:
             self.vol_k = volume
         if self.grad_bricked:
@@ -274,6 +276,23 @@ class CapturedStep:
             self.dirs.copy_(directions.reshape(self.dirs.shape))
         self._stamp += 1            # a frame rendered before this call can no longer be back-propagated
 
+    @property
+    def dirty_box(self):
+        """The part of the canonical volume that changed since the last conversion, ((x0, x1), (y0, y1), (z0, z1)) half-open,
+        or None (= all of it).  Always held as a tuple of int pairs, so that a box given as lists compares equal to the one a
+        captured graph has baked in; checked against the volume's shape."""
+        return self._dirty_box
+
+    @dirty_box.setter
+    def dirty_box(self, box):
+        if box is None:
+            self._dirty_box = None
+            return
+        box = tuple((int(a), int(b)) for a, b in box)
+        if len(box) != 3 or any(not (0 <= a <= b <= n) for (a, b), n in zip(box, self.dims)):
+            raise ValueError(f"dirty_box: three half-open ranges inside {self.dims}; got {box}")
+        self._dirty_box = box
+
     def refresh_volume(self, box=None):
         """Rebuild the converted copy from `self.vol` (after the caller changed the volume in place).
         box = ((x0, x1), (y0, y1), (z0, z1)), half-open, or `self.dirty_box` when set: only that part of the canonical
@@ -281,9 +300,13 @@ class CapturedStep:
         the records / bricks that hold it are rebuilt (diffus_convert_volume_box)."""
         self._conv_stamp += 1
         self._stamp += 1
-        box = box if box is not None else self.dirty_box
+        explicit = box is not None
+        box = box if explicit else self.dirty_box
         if self._full_once:
             box, self._full_once = None, False
+        if self.slice_only and not explicit:
+            self._last_box = box                # what capture() bakes in when nothing is pending (the loop's slice)
+            self._dirty_box = _EMPTY_BOX        # everything marked so far is converted by this call: nothing pending
         if box is not None and self.layout != _lib.CANONICAL:
             (x0, x1), (y0, y1), (z0, z1) = box
             _lib.check(self.lib.diffus_convert_volume_box(_vp(self.vol), *self.dims, self.layout, _vp(self.vol_k), int(x0), int(x1),
@@ -398,6 +421,16 @@ class CapturedStep:
         captured); for the bare `step()` -- two C-ABI calls, three kernels, ~15 us of host time -- issuing it eagerly is
         FASTER than one graph per step (63.8 against 68.6 us), and a graph of `repeat=8` steps equals the eager rate."""
         one = getattr(self, what)
+        box_in = self.dirty_box          # what the captured conversion launch will cover
+        if self.slice_only and box_in == _EMPTY_BOX and getattr(self, "_last_box", None) is not None:
+            box_in = self._last_box      # capture() after a first eager iteration: that iteration's slice
+        if self.slice_only and what in ("forward", "step"):
+            # the warm-up calls below convert (and clear) the pending slice; the captured call must see it again
+            inner = one
+
+            def one():
+                self._dirty_box = box_in
+                inner()
         if repeat > 1:
             def fn():
                 for _ in range(repeat):
@@ -416,7 +449,7 @@ class CapturedStep:
         with torch.cuda.graph(g, stream=self._side):
             fn()
         self._graphs[what] = g
-        self._graph_box[what] = self.dirty_box
+        self._graph_box[what] = box_in
         self._graph_keeps_median = getattr(self, "_graph_keeps_median", {})
         self._graph_keeps_median[what] = keeps
         return g
@@ -442,7 +475,15 @@ class CapturedStep:
             if what in ("forward", "step"):     # the replayed launches leave the median of the current inputs
                 self._median_of = self._inputs_now()
                 self._stamp += 1
+                if self.slice_only and self.learnable_volume:
+                    self._dirty_box = _EMPTY_BOX    # the replayed conversion covered the pending slice
         else:
+            if what in self._graphs:
+                self.eager_fallbacks += 1
+                if self.eager_fallbacks == 1:
+                    import warnings
+                    warnings.warn(f"CapturedStep.replay({what!r}): the captured launches do not fit the current inputs (another "
+                                  "dirty box / a stale median); running eagerly -- see CapturedStep.eager_fallbacks", stacklevel=3)
             getattr(self, what)()
 
     # -- autograd ----------------------------------------------------------------------------------------------------
@@ -457,10 +498,17 @@ class CapturedStep:
         return _SliceIntoVolume.apply(self, values, int(dim), int(index))
 
     def _mark_slice(self, dim: int, index: int):
-        """learnable_volume="slice": the next conversion rebuilds the records of this slice only."""
+        """learnable_volume="slice": the next conversion rebuilds the records of this slice only -- or, when other slices
+        have been written since the last conversion, of the box that holds all of them (nothing written is ever left stale;
+        refresh_volume() empties the pending box)."""
         if self.slice_only:
             box = [(0, n) for n in self.dims]
             box[dim % 3] = (index % self.dims[dim % 3], index % self.dims[dim % 3] + 1)
+            old = self._dirty_box
+            if old is None and self.layout != _lib.CANONICAL:
+                return                      # the whole volume is pending already
+            if old is not None and old != _EMPTY_BOX:
+                box = [(min(a, c), max(b, d)) for (a, b), (c, d) in zip(old, box)]
             self.dirty_box = tuple(box)
 
     def slice_view(self, dim: int, index: int) -> torch.Tensor:

@@ -69,19 +69,43 @@ def cone_directions_np(direction, opening_angle: float, n_rays: int) -> np.ndarr
     return out.astype(np.float32)
 
 
-def pose_ring(n: int, P: int, R: int, opening_deg: float = 60.0, phase: float = 0.0):
+def pose_ring(n: int, P: int, R: int, opening_deg: float = 60.0, phase: float = 0.0, roll_deg: float = 0.0,
+              pitch_deg: float = 0.0, plane=(0, 1)):
     """P probe poses on a ring inside the head; `phase` (radians) turns the whole ring.
 
     -> sources (P,3) float32, directions (P,R,3) float32.  Apex p sits at
     (0.5n + 0.30n cos phi, 0.5n + 0.30n sin phi, 0.5n + 0.05n sin 3phi) and the
     fan looks at the volume centre, in the (0,1) plane like every demo fan.
+
+    Fans a pose optimisation produces (`plot_beam_frame` takes any `directions`, src/renderer.py:119-124): `roll_deg`
+    turns each fan's plane about its central ray (the plane's normal leaves dim 2 by that angle; the edge rays climb
+    along dim 2, the central ray does not), `pitch_deg` lifts the central ray itself out of the slice.  `plane=(a, b)`
+    puts the ring and the fans into the plane of dims (a, b) instead of (0, 1) -- a permutation of the coordinates.
+    Unit directions up to float32 rounding, computed in float64.
     """
     src = np.zeros((P, 3), dtype=np.float32)
     dirs = np.zeros((P, R, 3), dtype=np.float32)
+    roll, pitch = math.radians(roll_deg), math.radians(pitch_deg)
+    a, b = plane
+    c = 3 - a - b
+    perm = [0, 0, 0]
+    perm[a], perm[b], perm[c] = 0, 1, 2
     for p in range(P):
         phi = 2.0 * math.pi * p / P + phase
-        src[p] = (0.5 * n + 0.30 * n * math.cos(phi),
-                  0.5 * n + 0.30 * n * math.sin(phi),
-                  0.5 * n + 0.05 * n * math.sin(3 * phi))
-        dirs[p] = cone_directions_np((-math.cos(phi), -math.sin(phi)), math.radians(opening_deg), R)
+        s = np.array((0.5 * n + 0.30 * n * math.cos(phi),
+                      0.5 * n + 0.30 * n * math.sin(phi),
+                      0.5 * n + 0.05 * n * math.sin(3 * phi)))
+        d = cone_directions_np((-math.cos(phi), -math.sin(phi)), math.radians(opening_deg), R)
+        if roll_deg != 0.0 or pitch_deg != 0.0:
+            look = np.array((-math.cos(phi), -math.sin(phi), 0.0))
+            side = np.array((math.sin(phi), -math.cos(phi), 0.0))
+            up = np.array((0.0, 0.0, 1.0))
+            look2 = math.cos(pitch) * look + math.sin(pitch) * up
+            up2 = math.cos(pitch) * up - math.sin(pitch) * look
+            side2 = math.cos(roll) * side + math.sin(roll) * up2
+            d64 = d.astype(np.float64)
+            along, across = d64 @ look, d64 @ side                      # the flat fan in its own frame
+            d = (along[:, None] * look2[None, :] + across[:, None] * side2[None, :]).astype(np.float32)
+        src[p] = s[perm].astype(np.float32)
+        dirs[p] = d[:, perm]
     return src, dirs

@@ -262,6 +262,41 @@ def test_learnable_volume_slice_mode_tracks_the_written_slice(Step, layout, capt
     assert torch.equal(part.vol_k, whole.vol_k) and torch.equal(part.loss, whole.loss)
 
 
+@pytest.mark.parametrize("layout", ["bricked", "paired"])
+def test_slice_mode_two_writes_before_one_conversion(Step, layout):
+    """learnable_volume="slice" with TWO slices written before one conversion -- volume_with_slice(k1), then
+    volume_with_slice(k2), then render(); or volume_with_slice(k1) followed by mse_loss(slice_index=k2).  The pending box is
+    the union of what was written (nothing stale), and it is empty again after the conversion."""
+    n, P, R, S = 48, 2, 16, 64
+    vol = torch.from_numpy(phantom(n)).cuda()
+    src, dirs = pose_ring(n, P, R)
+    s, dd = torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda()
+    g = torch.Generator().manual_seed(9)
+    tgt = (0.05 * torch.randn((P, R, S), generator=g)).cuda()
+    part = Step(vol.clone(), s, dd, S, 1e-4, "trilinear", layout=layout, learnable_volume="slice", target=tgt)
+    whole = Step(vol.clone(), s, dd, S, 1e-4, "trilinear", layout=layout, learnable_volume=True, target=tgt)
+    for (d1, k1), (d2, k2), how in [((2, 24), (2, 27), "render"), ((2, 23), (0, 20), "render"), ((1, 11), (2, 24), "mse")]:
+        a = (1.5e6 + 1e5 * torch.randn(tuple(vol.select(d1, k1).shape), generator=g)).cuda()
+        b = (1.5e6 + 1e5 * torch.randn(tuple(vol.select(d2, k2).shape), generator=g)).cuda()
+        outs = []
+        for st in (part, whole):
+            st.volume_with_slice(a, d1, k1)
+            if how == "render":
+                v = st.volume_with_slice(b, d2, k2)
+                outs.append(st.render(v).clone())
+            else:
+                outs.append(st.mse_loss(slice_values=b, slice_dim=d2, slice_index=k2).clone())
+            torch.cuda.synchronize()
+        assert torch.equal(part.vol, whole.vol)
+        assert torch.equal(part.vol_k, whole.vol_k), (d1, k1, d2, k2, how)
+        assert torch.equal(outs[0], outs[1])
+        assert part.dirty_box == ((0, 0), (0, 0), (0, 0))
+    part.dirty_box = [[0, n], [0, n], [3, 4]]                 # lists are normalised to the tuple form graphs are compared with
+    assert part.dirty_box == ((0, n), (0, n), (3, 4))
+    with pytest.raises(ValueError):
+        part.dirty_box = ((0, n + 1), (0, n), (0, 1))
+
+
 @pytest.mark.parametrize("P,n", [(1, 4), (3, 1000), (32, 256 * 512), (5, 131073)])
 def test_loss_sumsq_single_launch(P, n):
     from diffus_amd import _lib

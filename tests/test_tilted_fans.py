@@ -1,0 +1,113 @@
+"""Fans that are NOT planar in dim 2, at full size.
+
+`plot_beam_frame` takes any `directions` (src/renderer.py:201-217, :119-124) and a probe-pose optimisation
+(`notebooks/[NW] alignement.ipynb` cells 13-14) produces exactly such fans: the plane tilted out of the slice (roll about
+the central ray), the central ray lifted out of it (pitch), or the fan lying in another coordinate plane altogether.
+Config-2 shape (256 rays x 512 steps, 256^3): frame <= 2e-5 against the float64 restatement at the float32 sample points
+of the reference, d/dvolume, d/dsource, d/ddirections <= 1e-3; and the per-voxel accumulation bound of the
+scatter on these patches (same formula as test_fixed_point_scatter_error_bound_per_voxel).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxnorm_rel
+from diffus_amd.phantom import phantom, pose_ring
+
+pytestmark = pytest.mark.gpu
+
+TILTS = [  # roll, pitch, plane, pose of the 32-ring
+    (5.0, 0.0, (0, 1), 3),
+    (20.0, 0.0, (0, 1), 3),
+    (45.0, 0.0, (0, 1), 11),
+    (0.0, 20.0, (0, 1), 7),
+    (20.0, 10.0, (0, 1), 18),
+    (0.0, 0.0, (0, 2), 3),
+    (0.0, 0.0, (1, 2), 5),
+    (20.0, 0.0, (0, 2), 3),
+]
+
+
+@pytest.fixture(scope="module")
+def da():
+    import diffus_amd
+    from diffus_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    return diffus_amd
+
+
+@pytest.fixture(scope="module")
+def vol256():
+    return phantom(256)
+
+
+@pytest.mark.parametrize("roll,pitch,plane,pose", TILTS)
+def test_tilted_fan_full_size_values_vs_float64_autograd(da, vol256, roll, pitch, plane, pose):
+    from oracle import autograd_ref as ar
+    n, R, S, alpha = 256, 256, 512, 1e-4
+    src, dirs = pose_ring(n, 32, R, roll_deg=roll, pitch_deg=pitch, plane=plane)
+    vol = torch.from_numpy(vol256).cuda().requires_grad_(True)
+    s = torch.from_numpy(src[pose:pose + 1]).cuda().requires_grad_(True)
+    d = torch.from_numpy(dirs[pose:pose + 1]).cuda().requires_grad_(True)
+    f = da.render_poses(vol, s, d, S, alpha, sampler="trilinear")
+    (f ** 2).sum().backward()
+    got = (f.detach()[0].cpu().numpy(), s.grad[0].cpu().numpy(), d.grad[0].cpu().numpy())
+    gv = vol.grad.cpu()
+    del vol, f
+    v64 = torch.from_numpy(vol256).double().requires_grad_(True)
+    s64 = torch.from_numpy(src[pose]).double().requires_grad_(True)
+    d64 = torch.from_numpy(dirs[pose]).double().requires_grad_(True)
+    fr = ar.render(v64, s64, d64, S, alpha, 0, "trilinear", points="f32")
+    (fr ** 2).sum().backward()
+    e_f = maxnorm_rel(got[0], fr.detach().numpy())
+    e_s = maxnorm_rel(got[1], s64.grad.numpy())
+    e_d = maxnorm_rel(got[2], d64.grad.numpy())
+    gref = v64.grad
+    den = float(gref.abs().max())
+    e_v = max(float((gv[i0:i0 + 64].double() - gref[i0:i0 + 64]).abs().max()) for i0 in range(0, n, 64)) / den
+    print("tilt roll %.0f pitch %.0f plane %s: frame %.2e gsrc %.2e gdir %.2e gvol %.2e" % (roll, pitch, plane, e_f, e_s, e_d, e_v))
+    assert e_f < 2e-5
+    assert e_s < 1e-3 and e_d < 1e-3
+    assert e_v < 1e-3
+    assert int((gv != 0).sum()) > 0.5 * int((gref != 0).sum())
+
+
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
+@pytest.mark.parametrize("alpha", [1e-4, 0.5])
+@pytest.mark.parametrize("roll,pitch,plane", [(20.0, 0.0, (0, 1)), (45.0, 10.0, (0, 1)), (0.0, 0.0, (0, 2)), (5.0, 0.0, (1, 2))])
+def test_scatter_error_bound_per_voxel_oblique(da, alpha, sampler, roll, pitch, plane):
+    """test_fixed_point_scatter_error_bound_per_voxel on fans that leave the slice: the kernel's own zbar scattered
+    exactly (float64, CPU) against what the scatter kernel left in the gradient, per voxel relative to the voxel's mass
+    m_v = sum_s |zbar_s| w_sv:  |g_v - exact_v| <= 4e-6 m_v + 2^-40 max m  -- with the reference's default
+    attenuation_coeff = 0.5 (zbar falls by 2^-46 across a patch) as well as 1e-4."""
+    from diffus_amd import CapturedStep, _lib
+    from oracle import autograd_ref as ar
+    n, R, S = 64, 64, 96
+    v = phantom(n)
+    src, dirs = pose_ring(n, 8, R, roll_deg=roll, pitch_deg=pitch, plane=plane)
+    hp = CapturedStep(torch.from_numpy(v).cuda(), torch.from_numpy(src[2:3]).cuda(), torch.from_numpy(dirs[2:3]).cuda(), S, alpha,
+                      sampler, persistent=False)
+    gather = ar.sample_trilinear if sampler == "trilinear" else (lambda vol, p: ar.sample_nearest(vol, p)[0])
+    hp.fwd(); hp.loss_and_grad(); hp.zero_grad()
+    hp.bwd(_lib.BWD_SCAN)
+    torch.cuda.synchronize()
+    off = _lib.load().diffus_workspace_zbar_offset(1, R, S, 0)
+    zbar = hp.ws[off:off + 4 * R * S].view(torch.float32).reshape(R, S).cpu().double()
+    hp.bwd(_lib.BWD_SCATTER); hp.finish_grad()
+    torch.cuda.synchronize()
+    g = hp.gvol.cpu().double()
+    pts = ar.ray_points_f32(torch.from_numpy(src[2]).double(), torch.from_numpy(dirs[2]).double(), S)
+    ve = torch.from_numpy(v).double().requires_grad_(True)
+    (zbar * gather(ve, pts)).sum().backward()
+    vm = torch.from_numpy(v).double().requires_grad_(True)
+    (zbar.abs() * gather(vm, pts)).sum().backward()
+    exact, mass = ve.grad, vm.grad
+    tol = 4e-6 * mass + 2.0 ** -40 * float(mass.max())
+    worst = float(((g - exact).abs() / tol).max())
+    print("oblique per-voxel bound: roll %.0f pitch %.0f plane %s alpha %g %s: worst %.3g of the bound" % (roll, pitch, plane, alpha, sampler, worst))
+    assert worst <= 1.0, worst
+    deep = (mass < 2.0 ** -30 * float(mass.max())) & (mass > 2.0 ** -38 * float(mass.max()))
+    if alpha == 0.5:
+        assert int(deep.sum()) > 10
+        assert int((g[deep] != 0).sum()) > 0.9 * int(deep.sum())
