@@ -28,6 +28,7 @@ DIFFUS_F32, DIFFUS_F64, DIFFUS_I64 = 0, 1, 2
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
 GRAD_BRICKED = 0x10   # OR'ed into `layout` of the backward calls: the gradient is the bricked scratch whatever the volume's layout
+FANS_PLANAR = 0x20    # OR'ed into `layout` of the backward calls: a hint that no ray moves along dim 2 (the scatter launch for planar fans)
 FLUSH_STORE, FLUSH_ACCUMULATE, FLUSH_PERSISTENT, FLUSH_DENSE = 0, 1, 2, 3   # diffus_gradbuf_flush modes
 BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
 BWD_KEEP_MEDIAN = 4         # start > 0: the workspace still holds the forward's median (include/diffus_hip.h)

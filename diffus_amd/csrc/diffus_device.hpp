@@ -601,6 +601,7 @@ struct Args {
     float *zcout;      // backward, nullable (P*R): contribution of this segment's first r to sample seg0-1
     float *gsrc_out;   // pose_finish_block, nullable (P,3): the per-pose sum of gsrc_part over rays goes here
     int finish_in_scatter; // the scatter launch carries P extra blocks that run pose_finish_block
+    int fans_planar;       // the caller vouches that no ray moves along dim 2 (DIFFUS_FANS_PLANAR): the scatter launch without the slab path
     int accum_pose;    // backward: add to (instead of overwrite) the per-ray pose-gradient partials
     float neg_alpha;     // -alpha
     float neg_alpha_l2e; // -alpha * log2(e): attenuation = exp2(neg_alpha_l2e * n), one multiply in front of v_exp_f32

@@ -672,7 +672,8 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
                     void *workspace, size_t workspace_bytes, diffus_stream_t stream)
 {
     const bool grad_bricked = (layout & DIFFUS_GRAD_BRICKED) != 0; // the gradient's layout, decoupled from the volume's
-    layout &= ~DIFFUS_GRAD_BRICKED;
+    const bool fans_planar = (layout & DIFFUS_FANS_PLANAR) != 0;   // a hint for the scatter launch (include/diffus_hip.h)
+    layout &= ~(DIFFUS_GRAD_BRICKED | DIFFUS_FANS_PLANAR);
     const int glayout = (layout == DIFFUS_PAIRED || grad_bricked) ? DIFFUS_BRICKED : layout;
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
     if (rc) return rc;
@@ -692,6 +693,7 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
     Args A = make_args(vol, d0, d1, d2, layout, src, src_dtype, dirs, dirs_dtype, P, R, S, start, alpha, ws);
     A.gframe = gframe;
     A.mse = mse;
+    A.fans_planar = fans_planar;
     A.frame = (mse == 2) ? frame_out : nullptr;
     A.target = target;
     A.loss_scale = loss_scale;
@@ -805,7 +807,7 @@ int diffus_render_step_mse(const float *vol, int d0, int d1, int d2, int layout,
         // runs its own carry-only forward passes anyway)
         if (!frame) return DIFFUS_EINVAL;
         if (stages & DIFFUS_BWD_SCAN) {
-            int rc = diffus_render_fwd(vol, d0, d1, d2, layout & ~DIFFUS_GRAD_BRICKED, src, src_dtype, dirs, dirs_dtype, P, R, S,
+            int rc = diffus_render_fwd(vol, d0, d1, d2, layout & ~(DIFFUS_GRAD_BRICKED | DIFFUS_FANS_PLANAR), src, src_dtype, dirs, dirs_dtype, P, R, S,
                                        start, alpha, sampler, frame, nullptr, workspace, workspace_bytes, stream);
             if (rc) return rc;
             if (start > 0) stages |= DIFFUS_BWD_KEEP_MEDIAN;

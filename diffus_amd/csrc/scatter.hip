@@ -61,7 +61,10 @@ __device__ __forceinline__ int tile_unit(int v, int axis)
 #endif
 constexpr int kScRays = DIFFUS_SC_PATCH_RAYS, kScSteps = DIFFUS_SC_PATCH_STEPS;
 constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kScRays * kScSteps / kSB;
-constexpr int kCapD = kTileCap / 2; // 64-bit entries in the tile
+// Tile capacities in 32-bit entries.  kTileCap (24 KiB, 6 blocks per CU): the launch for fans the caller KNOWS to be planar
+// in dim 2 (DIFFUS_FANS_PLANAR) and for canonical gradients.  kSlabCap (36 KiB, 4 blocks per CU): the launch that also
+// carries the slab path below for fans that leave the slice -- their tile holds several layers per column.
+constexpr int kSlabCap = 9216;
 #ifndef DIFFUS_SC_ROW_PAD
 #define DIFFUS_SC_ROW_PAD 1
 #endif
@@ -84,13 +87,14 @@ constexpr unsigned kRowPad = DIFFUS_SC_ROW_PAD; // planar tile: padding entries 
 //
 // Returns false -- nothing added, tile clear -- when some ray of the block is not planar (the caller then runs the
 // general 3-D path); true when the patch is done.
-template <int SAMPLER, int PM>
+template <int SAMPLER, int PM, int CAP>
 __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile, int (*s_box)[4], int *s_planar, int *s_live, const Pose &ps,
                                                      const float *rows, unsigned row_off, bool ray_ok, int nbase, int tid)
 {
     // rows: zbar at the block's first ray (block-uniform, a scalar base); row_off: this thread's ray and first step in
     // BYTES from there (32 bits: no 64-bit multiply per lane)
     const int wib = tid >> 6;
+    constexpr int kCapD = CAP / 2; // 64-bit entries in the tile
     // ---- loads first: a thread's kSPT consecutive zbar values (one 16-byte load when the row allows it) ...
     float zb[kSPT];
     {
@@ -118,8 +122,8 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
     {
         int4 *t4 = reinterpret_cast<int4 *>(tile);
 #pragma unroll
-        for (int e = 0; e < kTileCap / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
-        static_assert(kTileCap % (4 * kSB) == 0, "tile clear assumes whole int4 passes");
+        for (int e = 0; e < CAP / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
+        static_assert(CAP % (4 * kSB) == 0, "tile clear assumes whole int4 passes");
     }
     const bool ray_planar = (PM == 0 || ps.pmode != 2) ? (ps.df[2] == 0.f) : (ps.dd[2] == 0.0);
     const bool wave_planar = __ballot(ray_planar) == ~0ull;
@@ -409,16 +413,326 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
     return true;
 }
 
-template <int SAMPLER, int LAYOUT, int PM>
-__global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int has_finish, int step_groups, int sg_mul)
+
+// ---- SLAB patches (bricked gradient): fans that are NOT planar in dim 2 --------------------------------------------
+// `plot_beam_frame` takes any `directions` (src/renderer.py:119-124, :201-217), and a probe-pose optimisation produces
+// exactly such fans: the plane rolled about the central ray, the central ray pitched out of the slice, a fan lying in
+// another coordinate plane.  The 3-D brick tile of the general path below holds a box of WHOLE bricks; a patch of a
+// plane tilted by 20 degrees crosses ~12 depth layers, its box is ~9 x 9 x 6 bricks against a tile of 192, most waves
+// fall through to direct global atomics: 132 us at 20 degrees of roll, 488 us at 20 degrees of pitch against 26 us
+// for planar fans (profiles/r05_tilt_before.txt), in 32-bit fixed point.
+//
+// The rays of a patch share their source and -- for every fan that is a rigid motion of a planar one -- lie in ONE plane
+// through it.  Let A be the axis along which that plane's normal is largest ("minor axis") and (U, V) the other two:
+// the plane is a height field  h(U, V) = c0 + cu U + cv V  with |cu|, |cv| <= 1.  A sample INSIDE the volume at p touches
+// the columns (U, V) in floor(p_U, p_V) + {0, 1}^2 and, in each, the layers floor(p_A) + {0, 1}; since
+// |h(U, V) - p_A| <= |cu| + |cv| =: S, every layer a column can receive lies in the window [floor(h - S), floor(h + S) + 1]
+// of at most L = ceil(2 S) + 2 consecutive integers.  So the tile is 2-D over the box of touched columns x L SLOTS,
+// slot = layer mod L: unambiguous inside a window of L, no per-corner evaluation of the plane in the accumulation; the
+// flush recovers the layer from the column's window.  Doubles (ds_add_f64), like the planar tile: the per-voxel error
+// bound of the planar path holds here too (tests/test_tilted_fans.py).  The plane is not assumed, it is MEASURED: the
+// largest distance dev of any live sample from h (float rounding of the points included) widens S, and a patch whose
+// rays are not coplanar enough for L <= kSlabMaxL takes the general path.
+//
+// Samples OUTSIDE the volume are clamped onto its faces (grid_sample's border rule; reference :754-756 for nearest) and
+// leave the plane.  Those clamped on axis a form a 2-D set ON that face: the same tile with minor axis a, two slots
+// (layer 0 and layer dim_a - 1).  A patch is therefore scattered in up to four PASSES -- the samples clamped on axis 0,
+// those on axis 1 (and not 0), those on axis 2 (and not 0, 1), the inside ones -- of which a typical patch needs one.
+// A pass whose column box x L exceeds the tile goes through it in CHUNKS of rows (every thread offers its corners to
+// every chunk): no patch ever falls back to per-sample global atomics.
+constexpr int kSlabMaxL = 8;
+template <int AX> struct SlabAxes { // (U, V) for minor axis AX; V is the axis whose neighbours share a brick line most often
+    static constexpr int U = (AX == 2) ? 0 : 2, V = (AX == 1) ? 0 : 1;
+};
+__device__ __forceinline__ float sel3(float a, float b, float c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
+__device__ __forceinline__ int mod_small(unsigned x, unsigned L, unsigned magic) { return (int)(x - __umulhi(x, magic) * L); } // x < 2^32 / L
+
+struct SlabSample { // one of a thread's kSPT samples
+    int i0[3], i1[3];
+    float t[3];
+};
+
+// One pass.  `member`: bit q = sample q of this thread belongs to the pass.  face: the pass of the samples clamped on
+// axis AX (slots: layer 0 / layer dim - 1); else the inside samples on the plane (cu, cv, c0b = c0 - S; L slots).
+template <int SAMPLER, int AX, int CAPD>
+__device__ __forceinline__ void slab_pass(const Args &A, double *tile, int (*s_box)[4], const SlabSample (&sm)[kSPT], const float (&zb)[kSPT],
+                                          unsigned member, bool face, float cu, float cv, float c0b, int L, int tid)
 {
+    constexpr int U = SlabAxes<AX>::U, V = SlabAxes<AX>::V;
+    const int wib = tid >> 6;
+    const int dimA = AX == 0 ? A.G.d0 : (AX == 1 ? A.G.d1 : A.G.d2);
+    // ---- column box of the pass
+    int bx[4] = {0x7fffffff, -1, 0x7fffffff, -1};
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q)
+        if (member >> q & 1u) {
+            bx[0] = min(bx[0], sm[q].i0[U]); bx[1] = max(bx[1], sm[q].i1[U]);
+            bx[2] = min(bx[2], sm[q].i0[V]); bx[3] = max(bx[3], sm[q].i1[V]);
+        }
+    bx[0] = wave_reduce_minmax<true>(bx[0]);
+    bx[1] = wave_reduce_minmax<false>(bx[1]);
+    bx[2] = wave_reduce_minmax<true>(bx[2]);
+    bx[3] = wave_reduce_minmax<false>(bx[3]);
+    if ((tid & 63) == 63) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_box[wib][a] = bx[a];
+    }
+    __syncthreads();
+    int u0 = 0x7fffffff, u1 = -1, v0 = 0x7fffffff, v1 = -1;
+#pragma unroll
+    for (int wv = 0; wv < kSW; ++wv) {
+        u0 = min(u0, __builtin_amdgcn_readfirstlane(s_box[wv][0])); u1 = max(u1, __builtin_amdgcn_readfirstlane(s_box[wv][1]));
+        v0 = min(v0, __builtin_amdgcn_readfirstlane(s_box[wv][2])); v1 = max(v1, __builtin_amdgcn_readfirstlane(s_box[wv][3]));
+    }
+    if (u1 < u0 || v1 < v0) return; // nothing in this pass (block-uniform)
+    const int BV = v1 - v0 + 1, BVp = max(BV | 1, 3); // odd row stride (bank spread); >= 3: ceil(2^32 / 1) does not fit the 32-bit magic
+    if ((long)BVp * L > CAPD) {
+        // A single row of columns exceeds the tile (steps of hundreds of voxels): per-corner global atomics.  ONE copy of the
+        // corner code in a rolled loop, the sample picked by selects (unrolled, its 32 weight tests at a time spilled 130 registers)
+#pragma unroll 1
+        for (int qq = 0; qq < kSPT; ++qq) {
+            if (!(member >> qq & 1u)) continue;
+            Cell c;
+            float zq = 0.f;
+#pragma unroll
+            for (int q = 0; q < kSPT; ++q)
+                if (q == qq) {
+                    zq = zb[q];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { c.i0[a] = sm[q].i0[a]; c.i1[a] = sm[q].i1[a]; c.t[a] = sm[q].t[a]; }
+                }
+            for_each_corner<SAMPLER>(c, zq, [&](int i, int j, int k, float v) {
+                if (v != 0.f) {
+                    const unsigned g = vox_off<DIFFUS_BRICKED>(A.G, i, j, k);
+                    atomicAdd(A.gvol + g, v);
+                    if (A.gtouched) A.gtouched[g >> 5] = 1;
+                }
+            });
+        }
+        return;
+    }
+    const int rpc = min(CAPD / (BVp * L), u1 - u0 + 1); // rows of columns per chunk
+    const int NC = rpc * BVp;                           // columns per slot plane
+    const unsigned magicL = 0xffffffffu / (unsigned)L + 1u, magicV = 0xffffffffu / (unsigned)BVp + 1u;
+    char *tile_c = reinterpret_cast<char *>(tile);
+#pragma unroll 1
+    for (int uc = u0; uc <= u1; uc += rpc) { // block-uniform
+        const int rows = min(rpc, u1 - uc + 1);
+        // ---- accumulate: 8 (trilinear) / 1 (nearest) ds_add_f64 per sample, zero weights skipped
+#pragma unroll
+        for (int q = 0; q < kSPT; ++q) {
+            if (!(member >> q & 1u)) continue;
+            // (opaque copies: or else the per-sample offsets and weights are hoisted out of the chunk and pass loops -- which
+            // almost always run once -- and held for all four samples at a time)
+            SlabSample c = sm[q];
+            float zq = zb[q];
+            asm volatile("" : "+v"(zq), "+v"(c.i0[0]), "+v"(c.i0[1]), "+v"(c.i0[2]), "+v"(c.i1[0]), "+v"(c.i1[1]), "+v"(c.i1[2]),
+                         "+v"(c.t[0]), "+v"(c.t[1]), "+v"(c.t[2]));
+            const int ru0 = c.i0[U] - uc, ru1 = c.i1[U] - uc;
+            const bool in0 = (unsigned)ru0 < (unsigned)rows, in1 = (unsigned)ru1 < (unsigned)rows;
+            const int s0 = face ? (c.i0[AX] != 0 ? 1 : 0) : mod_small((unsigned)c.i0[AX], (unsigned)L, magicL);
+            const int s1 = face ? s0 : ((s0 + 1 == L) ? 0 : s0 + 1);
+            const int eS[2] = {s0 * NC * 8, s1 * NC * 8};
+            const int eU[2] = {ru0 * BVp * 8, ru1 * BVp * 8};
+            const int eV[2] = {(c.i0[V] - v0) * 8, (c.i1[V] - v0) * 8};
+            const bool inr[2] = {in0, in1};
+            if constexpr (SAMPLER == DIFFUS_NEAREST) {
+                if (in0) atomicAdd(reinterpret_cast<double *>(tile_c + (eS[0] + eU[0] + eV[0])), (double)zq);
+            } else {
+                const float w0[2] = {1.f - c.t[0], c.t[0]}, w1[2] = {1.f - c.t[1], c.t[1]}, w2[2] = {1.f - c.t[2], c.t[2]};
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float wij = zq * w0[i] * w1[j]; // the association of for_each_corner
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float wt = wij * w2[k];
+                            const int bit[3] = {i, j, k};
+                            if (wt != 0.f && inr[bit[U]])
+                                atomicAdd(reinterpret_cast<double *>(tile_c + (eS[bit[AX]] + eU[bit[U]] + eV[bit[V]])), (double)wt);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0); // one sample at a time (register budget)
+        }
+        __syncthreads();
+        // ---- flush: a lane takes a column (V fastest: neighbours in a brick line), reads its L slots, recovers the layers
+        // from the column's window and adds every non-zero entry to the gradient once; the tile is left all-zero
+        const int ncols = rows * BVp;
+#pragma unroll 1
+        for (int col = tid; col < ncols; col += kSB) {
+            const int r = (int)__umulhi((unsigned)col, magicV), cc = col - r * BVp;
+            double v[kSlabMaxL];
+#pragma unroll
+            for (int sl = 0; sl < kSlabMaxL; ++sl) v[sl] = (sl < L) ? tile[sl * NC + col] : 0.0; // (sl < L: wave-uniform)
+            const int Uc = uc + r, Vc = v0 + cc;
+            int base = 0, bm = 0;
+            if (!face) {
+                base = (int)floorf(__builtin_fmaf(cv, (float)Vc, __builtin_fmaf(cu, (float)Uc, c0b)));
+                bm = mod_small((unsigned)(base + 8 * L), (unsigned)L, magicL); // base > -L wherever something was added
+            }
+#pragma unroll
+            for (int sl = 0; sl < kSlabMaxL; ++sl) {
+                if (sl < L && v[sl] != 0.0) {
+                    tile[sl * NC + col] = 0.0;
+                    int d = sl - bm;
+                    d += (d < 0) ? L : 0;
+                    const int M = face ? (sl ? dimA - 1 : 0) : base + d;
+                    if ((unsigned)M >= (unsigned)dimA) continue; // cannot happen while the window holds; never an out-of-bounds atomic
+                    const int x = AX == 0 ? M : (U == 0 ? Uc : Vc), y = AX == 1 ? M : (U == 1 ? Uc : Vc), z = AX == 2 ? M : (U == 2 ? Uc : Vc);
+                    const unsigned g = vox_off<DIFFUS_BRICKED>(A.G, x, y, z);
+                    if (A.gtouched) A.gtouched[g >> 5] = 1;
+                    atomicAdd(A.gvol + g, (float)v[sl]);
+                }
+            }
+        }
+        __syncthreads(); // the next chunk / pass adds into the entries this one has just cleared
+    }
+}
+
+// Returns false -- nothing added, tile clear -- when the patch's rays are not coplanar enough (the caller then runs the
+// general 3-D path); true when the patch is done.  Enters with the tile clear.
+template <int SAMPLER, int PM, int CAP>
+__device__ __forceinline__ bool scatter_patch_slab(const Args &A, double *tile, int (*s_box)[kSW][4], int *s_cls, int *s_dev, const Pose &ps,
+                                                   long pose, long w0, int nrays, const float *rows, unsigned row_off, bool ray_ok,
+                                                   int nbase, int tid)
+{
+    constexpr int CAPD = CAP / 2;
+    const int wib = tid >> 6;
+    float zb[kSPT];
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) {
+        zb[q] = (ray_ok && nbase + q < A.N1) ? ldb_f32(rows, row_off + 4u * q) : 0.f;
+        if (!finitef(zb[q])) zb[q] = 0.f;
+    }
+    // ---- the plane of the patch: through the source, spanned by its first and last ray (block-uniform)
+    float nrm[3];
+    {
+        Pose pf, pl;
+        load_pose<PM>(pf, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w0);
+        load_pose<PM>(pl, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w0 + nrays - 1);
+        const float *a = pf.df, *b = pl.df;
+        nrm[0] = a[1] * b[2] - a[2] * b[1]; nrm[1] = a[2] * b[0] - a[0] * b[2]; nrm[2] = a[0] * b[1] - a[1] * b[0];
+        const float nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
+        const float aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], bb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+        if (!(nn > 1e-10f * aa * bb)) { // one ray, parallel rays, a zero direction: any plane through the first ray
+            const float f0 = fabsf(a[0]), f1 = fabsf(a[1]), f2 = fabsf(a[2]);
+            const int e = (f0 <= f1 && f0 <= f2) ? 0 : (f1 <= f2 ? 1 : 2); // a x e_min
+            nrm[0] = e == 1 ? -a[2] : (e == 2 ? a[1] : 0.f);
+            nrm[1] = e == 0 ? a[2] : (e == 2 ? -a[0] : 0.f);
+            nrm[2] = e == 0 ? -a[1] : (e == 1 ? a[0] : 0.f);
+            if (!(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2] > 0.f)) { nrm[0] = nrm[1] = 0.f; nrm[2] = 1.f; }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nrm[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nrm[c])));
+    }
+    const float m0 = fabsf(nrm[0]), m1 = fabsf(nrm[1]), m2 = fabsf(nrm[2]);
+    const int ax = (m2 >= m0 && m2 >= m1) ? 2 : (m0 >= m1 ? 0 : 1); // dim 2 on ties: the layout's cheap axis
+    const int axU = ax == 2 ? 0 : 2, axV = ax == 1 ? 0 : 1;
+    const float inv = -1.f / sel3(nrm[0], nrm[1], nrm[2], ax);
+    const float cu = sel3(nrm[0], nrm[1], nrm[2], axU) * inv, cv = sel3(nrm[0], nrm[1], nrm[2], axV) * inv;
+    const float sA = sel3(ps.sf[0], ps.sf[1], ps.sf[2], ax), sU = sel3(ps.sf[0], ps.sf[1], ps.sf[2], axU), sV = sel3(ps.sf[0], ps.sf[1], ps.sf[2], axV);
+    const float c0 = sA - cu * sU - cv * sV;
+    // ---- cells, classes, distance from the plane
+    SlabSample sm[kSPT];
+    unsigned cls = 0; // 2 bits per sample: 0 inside the volume, 1 + a clamped on axis a (the lowest such a)
+    float dev = 0.f;
+    const int dims[3] = {A.G.d0, A.G.d1, A.G.d2};
+#pragma unroll
+    for (int q = 0; q < kSPT; ++q) {
+        const float kf = (float)(A.start + nbase + q);
+        float p[3];
+        bool in[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            p[a] = ray_point_f<PM>(ps, a, kf);
+            if (SAMPLER == DIFFUS_NEAREST) {
+                const int i = nearest_index(p[a], dims[a]);
+                sm[q].i0[a] = sm[q].i1[a] = i;
+                sm[q].t[a] = 0.f;
+                in[a] = rintf(p[a]) == (float)i;
+            } else {
+                const Axis x = tri_axis(p[a], dims[a]);
+                sm[q].i0[a] = x.i0; sm[q].i1[a] = x.i1; sm[q].t[a] = x.t;
+                in[a] = x.m != 0.f;
+            }
+        }
+        const unsigned c = !in[0] ? 1u : (!in[1] ? 2u : (!in[2] ? 3u : 0u));
+        cls |= c << (2 * q);
+        if (c == 0u && zb[q] != 0.f) {
+            const float h = __builtin_fmaf(cv, sel3(p[0], p[1], p[2], axV), __builtin_fmaf(cu, sel3(p[0], p[1], p[2], axU), c0));
+            dev = fmaxf(dev, fabsf(sel3(p[0], p[1], p[2], ax) - h));
+        }
+    }
+    // ---- which passes the block needs, and the plane's measured thickness: one LDS word per wave each
+    unsigned present = 0;
+#pragma unroll
+    for (unsigned c = 0; c < 4; ++c) {
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < kSPT; ++q) any |= ((cls >> (2 * q)) & 3u) == c && zb[q] != 0.f;
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) present |= 1u << c;
+    }
+    const int devbits = wave_reduce_minmax<false>(__float_as_int(dev)); // dev >= 0 (NaN compares as a huge int: the patch then fails the test below)
+    if ((tid & 63) == 63) {
+        s_cls[wib] = (int)present;
+        s_dev[wib] = devbits;
+    }
+    __syncthreads();
+    present = 0;
+    int dmax = 0;
+#pragma unroll
+    for (int wv = 0; wv < kSW; ++wv) {
+        present |= (unsigned)__builtin_amdgcn_readfirstlane(s_cls[wv]);
+        dmax = max(dmax, __builtin_amdgcn_readfirstlane(s_dev[wv]));
+    }
+    if (present == 0u) return true; // nothing to add (block-uniform)
+    int L = 2;
+    float c0b = 0.f;
+    if (present & 1u) {
+        const float devmax = __int_as_float(dmax);
+        const float dU = (float)(axU == 0 ? dims[0] : (axU == 1 ? dims[1] : dims[2])), dV = (float)(axV == 0 ? dims[0] : (axV == 1 ? dims[1] : dims[2]));
+        const float T = fabsf(c0) + fabsf(cu) * dU + fabsf(cv) * dV + 2.f;
+        const float S = fabsf(cu) + fabsf(cv) + devmax + (1e-4f + T * 0x1p-19f); // + what float32 can err in h and in dev
+        if (!(S < 0.5f * (float)(kSlabMaxL - 2))) return false; // (also NaN) not a plane within kSlabMaxL layers: the general path
+        L = (int)ceilf(2.f * S) + 2;
+        c0b = c0 - S;
+    }
+    int pass_no = 0;
+    auto passes_of_axis = [&](auto axis_) {
+        constexpr int a = decltype(axis_)::value;
+#pragma unroll 1
+        for (int kind = 0; kind < 2; ++kind) { // 0: the samples clamped on axis a; 1: the inside samples, if a is the plane's minor axis
+            const bool face = kind == 0;
+            if (face ? !(present >> (a + 1) & 1u) : !((present & 1u) && ax == a)) continue; // block-uniform
+            const unsigned want = face ? (unsigned)(a + 1) : 0u;
+            unsigned member = 0;
+#pragma unroll
+            for (int q = 0; q < kSPT; ++q) member |= ((((cls >> (2 * q)) & 3u) == want && zb[q] != 0.f) ? 1u : 0u) << q;
+            slab_pass<SAMPLER, a, CAPD>(A, tile, s_box[pass_no & 1], sm, zb, member, face, cu, cv, c0b, face ? 2 : L, tid);
+            ++pass_no;
+        }
+    };
+    passes_of_axis(std::integral_constant<int, 0>{});
+    passes_of_axis(std::integral_constant<int, 1>{});
+    passes_of_axis(std::integral_constant<int, 2>{});
+    return true;
+}
+
+template <int SAMPLER, int LAYOUT, int PM, bool SLAB = false>
+__global__ __launch_bounds__(kSB, SLAB ? 4 : DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int has_finish, int step_groups, int sg_mul)
+{
+    constexpr int CAP = SLAB ? kSlabCap : kTileCap; // tile entries (32-bit)
+    static_assert(!SLAB || LAYOUT == DIFFUS_BRICKED, "the slab path scatters into a bricked gradient");
     // General (3-D) tile: 32-bit FIXED POINT with a per-patch power-of-two scale 2^fx chosen so that even all 1024 samples
     // landing on one voxel cannot overflow: (sum over the patch of |zbar|) * 2^fx < 2^30 (weights are <= 1, so no voxel
     // can receive more than that sum).  Quantum <= 2^-20 of the patch's largest contribution, typically 2^-23..2^-26;
     // integer adds commute, so a tile sum is bitwise reproducible.  (ds_add_f32 is ~194 cycles per wave-instruction on
     // gfx950, ds_add_u32 5-15: tools/lds_atomic_bench.hip.)  Planar patches -- every fan of the reference -- take the
     // 2-D double-precision tile of scatter_patch_planar instead.
-    __shared__ __attribute__((aligned(16))) int tile[kTileCap];
+    __shared__ __attribute__((aligned(16))) int tile[CAP];
+    __shared__ int s_slab_box[SLAB ? 2 : 1][kSW][4], s_cls[kSW], s_dev[kSW]; // slab path: per-wave column boxes (double-buffered by pass), classes, plane thickness
     __shared__ int s_wlo[kSW][3], s_whi[kSW][3]; // per-WAVE boxes (a wave = 64 / kPatchSteps * kSPT rays x kPatchSteps steps)
     __shared__ float s_sum[kSW];
     __shared__ int s_planar[kSW];
@@ -504,7 +818,7 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     }
     if constexpr (kCanPlanar) {
-        if (scatter_patch_planar<SAMPLER, PM>(A, reinterpret_cast<double *>(tile), s_box, s_planar, &s_live, ps, A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid)) return;
+        if (scatter_patch_planar<SAMPLER, PM, CAP>(A, reinterpret_cast<double *>(tile), s_box, s_planar, &s_live, ps, A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid)) return;
 #ifdef DIFFUS_SC_PLANAR_ONLY // timing probe: the general path compiled out (register budget of the planar path alone)
         return;
 #endif
@@ -514,6 +828,16 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
         asm volatile("" : "+s"(bx), "+s"(by));
         decode(bx, by);
         load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+        if constexpr (SLAB) { // a fan that leaves the slice: the height-field tile over its plane
+            const int rg0 = (int)(w0 - (long)pose * A.R);
+            if (scatter_patch_slab<SAMPLER, PM, CAP>(A, reinterpret_cast<double *>(tile), s_slab_box, s_cls, s_dev, ps, pose, w0,
+                                                     min(kScRays, A.R - rg0), A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid))
+                return;
+            __syncthreads(); // not a plane: every wave is done with the slab records before the general path starts over
+            asm volatile("" : "+s"(bx), "+s"(by));
+            decode(bx, by);
+            load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+        }
     }
     Cell cells[kSPT];
     float zb[kSPT];
@@ -529,8 +853,8 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
     {
         int4 *t4 = reinterpret_cast<int4 *>(tile);
 #pragma unroll
-        for (int e = 0; e < kTileCap / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
-        static_assert(kTileCap % (4 * kSB) == 0, "tile clear assumes whole int4 passes");
+        for (int e = 0; e < CAP / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
+        static_assert(CAP % (4 * kSB) == 0, "tile clear assumes whole int4 passes");
     }
     // the cells need the pose only: they are worked out while the zbar loads are still in flight
 #pragma unroll
@@ -582,7 +906,7 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
             wlo[wv][a] = __builtin_amdgcn_readfirstlane(s_wlo[wv][a]);
             whi[wv][a] = __builtin_amdgcn_readfirstlane(s_whi[wv][a]);
         }
-    // box of the waves [w0, w0 + cnt); tile entries it needs: 0 for an empty group, kTileCap + 1 when it does not fit
+    // box of the waves [w0, w0 + cnt); tile entries it needs: 0 for an empty group, CAP + 1 when it does not fit
     auto box_of = [&](int w0, int cnt, int (&l)[3], int (&b)[3]) -> int {
         unsigned v = UNIT;
         bool empty = false;
@@ -598,20 +922,20 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
             l[a] = mn;
             b[a] = mx - mn + 1;
             empty |= mx < 0;
-            // only "> kTileCap" matters: saturate so that the 32-bit product cannot overflow
+            // only "> CAP" matters: saturate so that the 32-bit product cannot overflow
             const unsigned e = (unsigned)min(max(b[a], 0), 0x7fff);
-            v = min(v, (unsigned)kTileCap + 1u) * e;
+            v = min(v, (unsigned)CAP + 1u) * e;
         }
-        return empty ? 0 : (int)min(v, (unsigned)kTileCap + 1u);
+        return empty ? 0 : (int)min(v, (unsigned)CAP + 1u);
     };
     static_assert(kSW == 4 || kSW == 8, "wave grouping below: 1, 2 or 4 groups of waves");
     int nsub = 1;
     int lb[3], bb[3];
     int vol_tile = box_of(0, kSW, lb, bb); // the whole patch: 85 % of the patches need nothing else
-    if (vol_tile > kTileCap) {
+    if (vol_tile > CAP) {
         int l[3], b[3];
         nsub = 2;
-        if (box_of(0, kSW / 2, l, b) > kTileCap || box_of(kSW / 2, kSW / 2, l, b) > kTileCap) nsub = 4;
+        if (box_of(0, kSW / 2, l, b) > CAP || box_of(kSW / 2, kSW / 2, l, b) > CAP) nsub = 4;
     }
     // (s_sum total) * 2^fx in [2^28, 2^29): headroom for the rounding of each contribution
     float ztot = 0.f; // >= every single |zbar| of the patch (a float sum of non-negative terms is monotone)
@@ -632,7 +956,7 @@ __global__ __launch_bounds__(kSB, DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kerne
 #pragma unroll
         for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(cells[q].t[a]), "+v"(cells[q].i0[a]), "+v"(cells[q].i1[a]));
     }
-    if (vol_tile > kTileCap) { // a single wave's strip does not fit (never seen with unit steps): direct atomics
+    if (vol_tile > CAP) { // a single wave's strip does not fit (never seen with unit steps): direct atomics
         if (mine) {
 #pragma unroll
             for (int q = 0; q < kSPT; ++q)
@@ -761,6 +1085,18 @@ int launch_scatter(const Args &A, int sampler, int layout, hipStream_t st)
     const int glayout = layout == DIFFUS_PAIRED ? DIFFUS_BRICKED : layout; // the scatter only sees the gradient
     return dispatch_sl(sampler, glayout, [&](auto S_, auto L_) {
         constexpr int SM = decltype(S_)::value, LY = (decltype(L_)::value == DIFFUS_PAIRED) ? DIFFUS_BRICKED : decltype(L_)::value;
+        // Fans the caller knows to be planar in dim 2 (DIFFUS_FANS_PLANAR), and canonical gradients: the 24 KiB tile at 6 blocks
+        // per CU.  Otherwise the launch that also carries the slab path (36 KiB, 4 blocks per CU): planar patches in it take
+        // the same planar path, ~10 % slower for the two blocks per CU it gives up; oblique ones no longer fall off a cliff.
+        if constexpr (LY == DIFFUS_BRICKED) {
+            if (!A.fans_planar) {
+                if (f32)
+                    hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0, true>), grid, dim3(kSB), 0, st, A, rgs, fin, sgs, sg_mul);
+                else
+                    hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 1, true>), grid, dim3(kSB), 0, st, A, rgs, fin, sgs, sg_mul);
+                return last_launch();
+            }
+        }
         if (f32)
             hipLaunchKernelGGL((scatter_patch_kernel<SM, LY, 0>), grid, dim3(kSB), 0, st, A, rgs, fin, sgs, sg_mul);
         else

@@ -71,6 +71,14 @@ extern "C" {
                               volume (one the caller updates in place, e.g. a slice per training step) then gets the
                               sparse, never-memset hand-back (diffus_gradbuf_flush) too */
 
+#define DIFFUS_FANS_PLANAR 0x20 /* backward entry points only, OR'ed into `layout`: a HINT that no ray of the call moves along
+                              dim 2 (every fan of the reference: src/cone.py:258 writes a zero dim-2 component).  The volume
+                              scatter then runs its launch for planar fans alone (24 KiB tile, 6 blocks per CU).  Without the
+                              hint it runs the launch that also carries the slab path for fans that leave the slice
+                              (`directions` may be anything: src/renderer.py:119-124, :201-217) -- 36 KiB tile, 4 blocks per
+                              CU, ~10 % slower on planar fans.  A wrong hint costs time, never correctness: oblique patches of
+                              a hinted call take the general 3-D tile */
+
 /* one wavefront marches one ray; a lane owns ceil(N1/64) consecutive samples, at most 16, so one launch
  * covers 1024 cropped samples.  Longer rays (N1 = S - start up to MAX_SAMPLES * MAX_SEGMENTS) are processed
  * as segments of 1024 samples, one launch each, chained through per-ray carries in the workspace (the running
