@@ -381,6 +381,7 @@ def callers_legs(args, vol, dev):
     import torch
     import diffus_amd
     from diffus_amd import CapturedStep
+    from diffus_amd import _lib as _lib_mod
     from diffus_amd.phantom import pose_ring
     out = {}
     n = args.n
@@ -469,7 +470,10 @@ def callers_legs(args, vol, dev):
     # (c) poses that move: a different ring of poses every step, copied in place into the captured step's buffers
     pool = [pose_ring(n, args.poses, args.rays, phase=0.013 * i) for i in range(16)]
     pool = [(torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)) for s, d in pool]
-    st = CapturedStep(vol, pool[0][0].clone(), pool[0][1].clone(), args.samples, args.alpha, args.sampler, layout=args.layout)
+    # (fans="planar": the rings are the reference's fans -- dim-2 component 0, src/cone.py:258 --, and with "auto" the first
+    # set_poses() would make that unknown and switch the scatter to its slab-capable launch)
+    st = CapturedStep(vol, pool[0][0].clone(), pool[0][1].clone(), args.samples, args.alpha, args.sampler, layout=args.layout,
+                      fans="planar")
     st.capture()
     k = [0]
 
@@ -503,6 +507,32 @@ def callers_legs(args, vol, dev):
         out["training_loops"] = loops
     except Exception as e:
         out["training_loops"] = {"failed": repr(e)}
+    del st
+    # (e) fans that are NOT planar in dim 2 -- what a probe-pose optimisation produces (`plot_beam_frame` takes any
+    #     `directions`, src/renderer.py:119-124; notebooks/[NW] alignement.ipynb cells 13-14): the headline's poses with every
+    #     fan rolled about its central ray, pitched out of the slice, or lying in another coordinate plane.  Same one-pass step.
+    tilt = {}
+    for name, kw in (("roll5", dict(roll_deg=5.0)), ("roll20", dict(roll_deg=20.0)), ("roll45", dict(roll_deg=45.0)),
+                     ("pitch20", dict(pitch_deg=20.0)), ("plane02", dict(plane=(0, 2)))):
+        s_t, d_t = pose_ring(n, args.poses, args.rays, **kw)
+        st = CapturedStep(vol, torch.from_numpy(s_t).to(dev), torch.from_numpy(d_t).to(dev), args.samples, args.alpha, args.sampler,
+                          layout=args.layout)
+        for _ in range(5):
+            st.step()
+        tilt[name + "_ms_per_step"] = time_events(st.step, 48)["median"]
+        tilt[name + "_scatter_ms"] = time_events(lambda: st.bwd(_lib_mod.BWD_SCATTER), 48, pre=st.finish_grad)["median"]
+        st.finish_grad()
+        del st
+    st = CapturedStep(vol, sa, da, args.samples, args.alpha, args.sampler, layout=args.layout, fans="oblique")
+    for _ in range(5):
+        st.step()
+    tilt["planar_fans_on_the_slab_capable_launch_ms_per_step"] = time_events(st.step, 48)["median"]
+    del st
+    tilt["note"] = ("eager one-pass steps of the headline workload (event-timed; the headline's own figure this way is ~2 us above "
+                    "its graph/eager best) with tilted fans: the scatter takes its slab path (height-field tile over the fan's "
+                    "plane, csrc/scatter.hip); before round 5 these fans fell to the 3-D brick tile and per-sample global "
+                    "atomics: 0.083 / 0.172 / 0.394 / 0.519 / 0.118 ms per step (profiles/r05_tilt_before.txt)")
+    out["tilted_fan"] = tilt
     out["moving_poses"] = {"ms_per_step": ms_move, "fixed_poses_ms_per_step": ms_fixed,
                            "note": "16 rings of poses, 0.013 rad apart, cycled: every step the persistent gradient tensor meets "
                                    "bricks the previous step wrote and this one does not (stale-brick clearing is exercised)"}

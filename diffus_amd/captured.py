@@ -153,7 +153,7 @@ class CapturedStep:
                  layout: str = "paired", sparse: bool = True, persistent: bool = True,
                  learnable_volume=False, alias_grads: bool = False, fused_loss: bool = True,
                  target: Optional[torch.Tensor] = None, loss_scale: float = 1.0, one_pass: bool = True,
-                 bricked_grad: Optional[bool] = None):
+                 bricked_grad: Optional[bool] = None, fans: str = "auto"):
         if not volume.is_cuda:
             raise _lib.DiffusError("CapturedStep needs a HIP-resident volume; there is no CPU fallback")
         if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous():
@@ -169,6 +169,15 @@ class CapturedStep:
             raise ValueError(f"directions must be (P,R,3) with P = {self.src.shape[0]}; got {tuple(self.dirs.shape)}")
         self.layout = _LAYOUT_ID[layout]
         self.sampler = _SAMPLER_ID[sampler]
+        # fans: "planar" -- the caller vouches that no ray moves along dim 2 (every fan of the reference: src/cone.py:258): the
+        # volume scatter runs its launch for planar fans alone (DIFFUS_FANS_PLANAR; a wrong promise costs time, never
+        # correctness); "oblique" -- the launch that also carries the slab path for fans that leave the slice; "auto" -- look
+        # at the directions now (one readback) and again never: set_poses() with new directions makes the answer unknown,
+        # and unknown means the slab-capable launch.
+        if fans not in ("auto", "planar", "oblique"):
+            raise ValueError("fans: 'auto', 'planar' or 'oblique'")
+        self.fans = fans
+        self._planar = (fans == "planar") or (fans == "auto" and bool((self.dirs[..., 2] == 0).all()))
         self.P, self.R = self.dirs.shape[0], self.dirs.shape[1]
         self.S, self.start, self.alpha = int(num_samples), int(start), float(attenuation_coeff)
         self.N1 = self.S - self.start
@@ -251,14 +260,23 @@ class CapturedStep:
         # every pointer below is fixed for the life of the object (inputs are updated in place)
         self.common = (_vp(self.vol_k), d0, d1, d2, self.layout, _vp(self.src), sdt, _vp(self.dirs), ddt, self.P, self.R,
                        self.S, self.start, self.alpha, self.sampler)
-        glay = self.layout | (_lib.GRAD_BRICKED if (self.grad_bricked and self.layout == _lib.CANONICAL) else 0)
-        self.common_bwd = self.common[:4] + (glay,) + self.common[5:]     # the backward entry points
+        self._glay = self.layout | (_lib.GRAD_BRICKED if (self.grad_bricked and self.layout == _lib.CANONICAL) else 0)
+        self._set_common_bwd()
         self._graphs: dict = {}
         self._side: Optional[torch.cuda.Stream] = None
 
     # -- plumbing ---------------------------------------------------------------------------------------------
     def stream(self):
         return _stream_id(self.dev)
+
+    def _set_common_bwd(self):
+        """Arguments of the backward entry points: the layout word carries the gradient's layout and the planar-fan hint."""
+        self.common_bwd = self.common[:4] + (self._glay | (_lib.FANS_PLANAR if self._planar else 0),) + self.common[5:]
+
+    @property
+    def fans_planar(self) -> bool:
+        """Whether the step launches the scatter for planar fans alone (see `fans`)."""
+        return self._planar
 
 
     # -- inputs, updated in place (a captured graph keeps reading the same buffers) -----------------------------
@@ -274,7 +292,13 @@ class CapturedStep:
         self.src.copy_(sources.reshape(self.src.shape))
         if directions is not None:
             self.dirs.copy_(directions.reshape(self.dirs.shape))
+            self._directions_changed()
         self._stamp += 1            # a frame rendered before this call can no longer be back-propagated
+
+    def _directions_changed(self):
+        if self.fans == "auto" and self._planar:
+            self._planar = False    # unknown from here on (no readback per step): the slab-capable launch; graphs captured
+            self._set_common_bwd()  # before keep the planar launch, which stays correct for any fan (the general 3-D tile)
 
     @property
     def dirty_box(self):
@@ -534,6 +558,7 @@ class CapturedStep:
                 self._stamp += 1
             if d.data_ptr() != self.dirs.data_ptr():
                 self.dirs.copy_(d.reshape(self.dirs.shape))
+                self._directions_changed()
                 self._stamp += 1
         return v, s, d
 

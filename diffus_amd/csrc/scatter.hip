@@ -21,8 +21,15 @@ __device__ unsigned long long *g_stamps = nullptr;
     do {                                                                                  \
         if (threadIdx.x == 0 && g_stamps) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
+#define STAMPV(i, v)                                                                     \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && g_stamps) g_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (unsigned long long)(v); \
+    } while (0)
+#define STAMP_NOW() __builtin_readcyclecounter()
 #else
 #define STAMP(i) ((void)0)
+#define STAMPV(i, v) ((void)0)
+#define STAMP_NOW() 0ull
 #endif
 
 // tile units: voxels (canonical) or bricks (bricked)
@@ -445,48 +452,46 @@ template <int AX> struct SlabAxes { // (U, V) for minor axis AX; V is the axis w
     static constexpr int U = (AX == 2) ? 0 : 2, V = (AX == 1) ? 0 : 1;
 };
 __device__ __forceinline__ float sel3(float a, float b, float c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
-__device__ __forceinline__ int mod_small(unsigned x, unsigned L, unsigned magic) { return (int)(x - __umulhi(x, magic) * L); } // x < 2^32 / L
+__device__ __forceinline__ int mod_rel(int x, int L, int magic16) { return x - __mul24(__mul24(x, magic16) >> 16, L); } // 0 <= x < 2^12, magic16 = ceil(2^16 / L)
 
 struct SlabSample { // one of a thread's kSPT samples
     int i0[3], i1[3];
     float t[3];
 };
 
-// One pass.  `member`: bit q = sample q of this thread belongs to the pass.  face: the pass of the samples clamped on
-// axis AX (slots: layer 0 / layer dim - 1); else the inside samples on the plane (cu, cv, c0b = c0 - S; L slots).
-template <int SAMPLER, int AX, int CAPD>
-__device__ __forceinline__ void slab_pass(const Args &A, double *tile, int (*s_box)[4], const SlabSample (&sm)[kSPT], const float (&zb)[kSPT],
-                                          unsigned member, bool face, float cu, float cv, float c0b, int L, int tid)
+// byte offset of voxel (x, y, z) in the bricked gradient as a part that depends on the column (U, V) and a part that depends
+// on the layer M along the minor axis AX
+template <int AX>
+__device__ __forceinline__ unsigned slab_col_part(const Geom &G, int Uc, int Vc)
+{
+    constexpr int U = SlabAxes<AX>::U;
+    const int a = U == 0 ? Uc : Vc, b = U == 0 ? Vc : Uc; // the two column coordinates in axis order (U, V are 0 < 1, 2 > 1, 2 > 0)
+    if (AX == 2) return (((unsigned)(a >> 2) * (unsigned)G.nb1 + (unsigned)(b >> 2)) * (unsigned)G.nb2 * kBrickFloats + (unsigned)(((a & 3) << 3) | ((b & 3) << 1))) * 4u; // (x, y)
+    if (AX == 1) return ((unsigned)(a >> 2) * (unsigned)G.nb1 * (unsigned)G.nb2 * kBrickFloats + (unsigned)(b >> 1) * kBrickFloats + (unsigned)(((a & 3) << 3) | (b & 1))) * 4u; // (x, z)
+    return ((unsigned)(a >> 2) * (unsigned)G.nb2 * kBrickFloats + (unsigned)(b >> 1) * kBrickFloats + (unsigned)(((a & 3) << 1) | (b & 1))) * 4u; // AX == 0: (y, z)
+}
+template <int AX>
+__device__ __forceinline__ unsigned slab_ax_part(const Geom &G, unsigned rowA, int M) // rowA: bricks per unit of M >> 2 (AX 0: nb1 nb2, AX 1: nb2)
+{
+    if (AX == 2) return ((unsigned)(M >> 1) * kBrickFloats + (unsigned)(M & 1)) * 4u;
+    if (AX == 1) return ((unsigned)(M >> 2) * rowA * kBrickFloats + (unsigned)((M & 3) << 1)) * 4u;
+    return ((unsigned)(M >> 2) * rowA * kBrickFloats + (unsigned)((M & 3) << 3)) * 4u;
+}
+
+// One pass.  `member`: bit q = sample q of this thread belongs to the pass.  FACE: the pass of the samples clamped on
+// axis AX (slots: layer 0 / layer dim - 1; the axis carries weight 1, so a sample has FOUR corners); else the inside
+// samples on the plane (cu, cv, c0b = c0 - S; L slots, eight corners).
+// (u0, u1, v0, v1): the pass's column box (block-uniform).  last: nothing follows this pass (no closing barrier).
+template <int SAMPLER, int AX, bool FACE, int CAPD>
+__device__ __forceinline__ void slab_pass(const Args &A, double *tile, const SlabSample (&sm)[kSPT], const float (&zb)[kSPT], unsigned member,
+                                          float cu, float cv, float c0b, int L, int u0, int u1, int v0, int v1, bool last, int tid,
+                                          unsigned long long (&prof)[5])
 {
     constexpr int U = SlabAxes<AX>::U, V = SlabAxes<AX>::V;
-    const int wib = tid >> 6;
+    (void)prof;
     const int dimA = AX == 0 ? A.G.d0 : (AX == 1 ? A.G.d1 : A.G.d2);
-    // ---- column box of the pass
-    int bx[4] = {0x7fffffff, -1, 0x7fffffff, -1};
-#pragma unroll
-    for (int q = 0; q < kSPT; ++q)
-        if (member >> q & 1u) {
-            bx[0] = min(bx[0], sm[q].i0[U]); bx[1] = max(bx[1], sm[q].i1[U]);
-            bx[2] = min(bx[2], sm[q].i0[V]); bx[3] = max(bx[3], sm[q].i1[V]);
-        }
-    bx[0] = wave_reduce_minmax<true>(bx[0]);
-    bx[1] = wave_reduce_minmax<false>(bx[1]);
-    bx[2] = wave_reduce_minmax<true>(bx[2]);
-    bx[3] = wave_reduce_minmax<false>(bx[3]);
-    if ((tid & 63) == 63) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) s_box[wib][a] = bx[a];
-    }
-    __syncthreads();
-    int u0 = 0x7fffffff, u1 = -1, v0 = 0x7fffffff, v1 = -1;
-#pragma unroll
-    for (int wv = 0; wv < kSW; ++wv) {
-        u0 = min(u0, __builtin_amdgcn_readfirstlane(s_box[wv][0])); u1 = max(u1, __builtin_amdgcn_readfirstlane(s_box[wv][1]));
-        v0 = min(v0, __builtin_amdgcn_readfirstlane(s_box[wv][2])); v1 = max(v1, __builtin_amdgcn_readfirstlane(s_box[wv][3]));
-    }
-    if (u1 < u0 || v1 < v0) return; // nothing in this pass (block-uniform)
-    const int BV = v1 - v0 + 1, BVp = max(BV | 1, 3); // odd row stride (bank spread); >= 3: ceil(2^32 / 1) does not fit the 32-bit magic
-    if ((long)BVp * L > CAPD) {
+    const int BV = v1 - v0 + 1, BVp = max(BV | 1, 3); // odd row stride (bank spread); >= 3: the magic of 1 does not fit 32 bits
+    if ((long)BVp * L > CAPD || BVp > 512 || (u1 - u0) + BVp > 4000) { // (512: the range the approximate magicV below is exact for; 4000: the 16-bit slot magic)
         // A single row of columns exceeds the tile (steps of hundreds of voxels): per-corner global atomics.  ONE copy of the
         // corner code in a rolled loop, the sample picked by selects (unrolled, its 32 weight tests at a time spilled 130 registers)
 #pragma unroll 1
@@ -511,52 +516,129 @@ __device__ __forceinline__ void slab_pass(const Args &A, double *tile, int (*s_b
         }
         return;
     }
-    const int rpc = min(CAPD / (BVp * L), u1 - u0 + 1); // rows of columns per chunk
+    // rows of columns per chunk = floor(CAPD / (BVp L)), without an integer division (block-uniform, but a division is ~40
+    // instructions wherever it runs): float estimate, corrected by one either way
+    const int per_row = BVp * L, BU = u1 - u0 + 1;
+    int rpc = (int)((float)CAPD * __builtin_amdgcn_rcpf((float)per_row));
+    rpc += ((rpc + 1) * per_row <= CAPD) ? 1 : 0;
+    rpc -= (rpc * per_row > CAPD) ? 1 : 0;
+    rpc = min(rpc, BU);
     const int NC = rpc * BVp;                           // columns per slot plane
-    const unsigned magicL = 0xffffffffu / (unsigned)L + 1u, magicV = 0xffffffffu / (unsigned)BVp + 1u;
+    const int NC8 = NC * 8, BVp8 = BVp * 8;
+    // slot = layer mod L on layers RELATIVE to a0, a block-uniform lower bound of every column's window (the plane is linear:
+    // its minimum over the box is at a corner): a few hundred at most, so x mod L = x - ((x m16) >> 16) L with m16 =
+    // ceil(2^16 / L) -- three full-rate instructions where the 32-bit magic costs two quarter-rate multiplies
+    const int magic16 = (65535 / L) + 1;
+    int a0 = 0;
+    if (!FACE) {
+        const float h00 = __builtin_fmaf(cv, (float)v0, __builtin_fmaf(cu, (float)u0, c0b)), h01 = __builtin_fmaf(cv, (float)v1, __builtin_fmaf(cu, (float)u0, c0b));
+        const float h10 = __builtin_fmaf(cv, (float)v0, __builtin_fmaf(cu, (float)u1, c0b)), h11 = __builtin_fmaf(cv, (float)v1, __builtin_fmaf(cu, (float)u1, c0b));
+        a0 = (int)floorf(fminf(fminf(h00, h01), fminf(h10, h11))) - 1; // - 1: the roundings of the two evaluation orders
+        a0 = __builtin_amdgcn_readfirstlane(a0);
+    }
+    // col / BVp for col < 2^13: any magic in [2^32 / BVp, (2^32 + 2^19) / BVp) is exact there; the float quotient is within 2^-22
+    // relative (<= 341 for BVp >= 3) of the true one, so + 512 puts it inside that window for every BVp <= 512
+    const unsigned magicV = (unsigned)(4294967296.f * __builtin_amdgcn_rcpf((float)BVp)) + 512u;
+    static_assert(CAPD <= 8192, "magicV is exact for column indices below 2^13 only");
     char *tile_c = reinterpret_cast<char *>(tile);
+#if defined(DIFFUS_SLAB_EXIT) && DIFFUS_SLAB_EXIT == 6
+    auto add_at = [&](int byte_off, double v) { asm volatile("" :: "v"(byte_off), "v"(v)); };
+#else
+    auto add_at = [&](int byte_off, double v) { atomicAdd(reinterpret_cast<double *>(tile_c + byte_off), v); };
+#endif
+    const unsigned rowA = AX == 0 ? (unsigned)A.G.nb1 * (unsigned)A.G.nb2 : (unsigned)A.G.nb2;
+    char *const gvol_b = reinterpret_cast<char *>(A.gvol);
 #pragma unroll 1
     for (int uc = u0; uc <= u1; uc += rpc) { // block-uniform
         const int rows = min(rpc, u1 - uc + 1);
-        // ---- accumulate: 8 (trilinear) / 1 (nearest) ds_add_f64 per sample, zero weights skipped
+        const bool whole = rpc >= BU; // the usual case: one chunk holds the pass, no corner needs a row test
+#ifdef DIFFUS_STAMP
+        const unsigned long long t_a = STAMP_NOW();
+        if (prof[2] == 0) prof[4] = t_a; // when the first accumulation starts
+#endif
+        // ---- accumulate: 8 (inside) / 4 (face) / 1 (nearest) ds_add_f64 per sample, zero weights skipped
 #pragma unroll
         for (int q = 0; q < kSPT; ++q) {
-            if (!(member >> q & 1u)) continue;
-            // (opaque copies: or else the per-sample offsets and weights are hoisted out of the chunk and pass loops -- which
-            // almost always run once -- and held for all four samples at a time)
-            SlabSample c = sm[q];
-            float zq = zb[q];
-            asm volatile("" : "+v"(zq), "+v"(c.i0[0]), "+v"(c.i0[1]), "+v"(c.i0[2]), "+v"(c.i1[0]), "+v"(c.i1[1]), "+v"(c.i1[2]),
-                         "+v"(c.t[0]), "+v"(c.t[1]), "+v"(c.t[2]));
+            const bool on = member >> q & 1u;
+            if (__builtin_amdgcn_ballot_w64(on) == 0ull) continue; // wave-uniform
+            const SlabSample &c = sm[q];
+            float zq = on ? zb[q] : 0.f; // a zero makes every weight below an exact zero: no add
+            asm volatile("" : "+v"(zq)); // opaque: every weight product depends on it, so none is hoisted out of the chunk and pass loops
             const int ru0 = c.i0[U] - uc, ru1 = c.i1[U] - uc;
-            const bool in0 = (unsigned)ru0 < (unsigned)rows, in1 = (unsigned)ru1 < (unsigned)rows;
-            const int s0 = face ? (c.i0[AX] != 0 ? 1 : 0) : mod_small((unsigned)c.i0[AX], (unsigned)L, magicL);
-            const int s1 = face ? s0 : ((s0 + 1 == L) ? 0 : s0 + 1);
-            const int eS[2] = {s0 * NC * 8, s1 * NC * 8};
-            const int eU[2] = {ru0 * BVp * 8, ru1 * BVp * 8};
+            const bool inr[2] = {whole || (unsigned)ru0 < (unsigned)rows, whole || (unsigned)ru1 < (unsigned)rows};
+            const int s0 = FACE ? (c.i0[AX] != 0 ? 1 : 0) : mod_rel(c.i0[AX] - a0, L, magic16);
+            const int eS0 = __mul24(s0, NC8);
+            const int eU[2] = {__mul24(ru0, BVp8), __mul24(ru1, BVp8)};
             const int eV[2] = {(c.i0[V] - v0) * 8, (c.i1[V] - v0) * 8};
-            const bool inr[2] = {in0, in1};
             if constexpr (SAMPLER == DIFFUS_NEAREST) {
-                if (in0) atomicAdd(reinterpret_cast<double *>(tile_c + (eS[0] + eU[0] + eV[0])), (double)zq);
+                if (inr[0] && zq != 0.f) add_at(eS0 + eU[0] + eV[0], (double)zq);
             } else {
-                const float w0[2] = {1.f - c.t[0], c.t[0]}, w1[2] = {1.f - c.t[1], c.t[1]}, w2[2] = {1.f - c.t[2], c.t[2]};
+                const float tu = c.t[U], tv = c.t[V];
+                const float wu[2] = {1.f - tu, tu}, wv[2] = {1.f - tv, tv};
+                if constexpr (FACE) {
+                    // zq * w0 * w1 * w2 in for_each_corner's association, the clamped axis contributing an exact 1
+                    float wc[2][2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int iu = 0; iu < 2; ++iu)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float wij = zq * w0[i] * w1[j]; // the association of for_each_corner
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const float wt = wij * w2[k];
-                            const int bit[3] = {i, j, k};
-                            if (wt != 0.f && inr[bit[U]])
-                                atomicAdd(reinterpret_cast<double *>(tile_c + (eS[bit[AX]] + eU[bit[U]] + eV[bit[V]])), (double)wt);
+                        for (int iv = 0; iv < 2; ++iv) {
+                            const float first = (U < V) ? wu[iu] : wv[iv], second = (U < V) ? wv[iv] : wu[iu]; // lower axis first
+                            wc[iu][iv] = inr[iu] ? zq * first * second : 0.f;
                         }
+                    // Samples clamped onto an EDGE or a corner of the volume stay on one voxel for the rest of their steps, and
+                    // the rays around them on the same one: 64 lanes, one address -- served one after the other (+23 cycles per
+                    // duplicate, tools/lds_atomic_bench.hip).  As in the planar path: if every live lane of the wave sits in the
+                    // same cell, the contributions are summed over the wave (DPP, double) and one lane adds them.
+                    const unsigned long long act = __builtin_amdgcn_ballot_w64(zq != 0.f);
+                    if (act == 0ull) continue; // wave-uniform
+                    const int lead = __builtin_ctzll(act);
+                    const int k0 = eS0 + eU[0] + eV[0], k1 = eU[1] + eV[1];
+                    const int f0 = __builtin_amdgcn_readlane(k0, lead), f1 = __builtin_amdgcn_readlane(k1, lead);
+                    const unsigned long long eq = __builtin_amdgcn_ballot_w64(k0 == f0) & __builtin_amdgcn_ballot_w64(k1 == f1);
+                    if ((eq & act) == act && __builtin_popcountll(act) > 4) {
+#pragma unroll
+                        for (int iu = 0; iu < 2; ++iu)
+#pragma unroll
+                            for (int iv = 0; iv < 2; ++iv) {
+                                const double t = wave_sum_to_lane63((double)wc[iu][iv]);
+                                const int off = __builtin_amdgcn_readlane(eS0 + eU[iu] + eV[iv], lead);
+                                if ((tid & 63) == 63 && t != 0.0) add_at(off, t);
+                            }
+                    } else {
+#pragma unroll
+                        for (int iu = 0; iu < 2; ++iu)
+#pragma unroll
+                            for (int iv = 0; iv < 2; ++iv)
+                                if (wc[iu][iv] != 0.f) add_at(eS0 + eU[iu] + eV[iv], (double)wc[iu][iv]);
                     }
+                } else {
+                    const int s1 = (s0 + 1 == L) ? 0 : s0 + 1;
+                    const int eS[2] = {eS0, __mul24(s1, NC8)};
+                    const float w0[2] = {1.f - c.t[0], c.t[0]}, w1[2] = {1.f - c.t[1], c.t[1]}, w2[2] = {1.f - c.t[2], c.t[2]};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float wij = zq * w0[i] * w1[j]; // the association of for_each_corner
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const float wt = wij * w2[k];
+                                const int bit[3] = {i, j, k};
+                                if (wt != 0.f && inr[bit[U]]) add_at(eS[bit[AX]] + eU[bit[U]] + eV[bit[V]], (double)wt);
+                            }
+                        }
+                }
             }
             __builtin_amdgcn_sched_barrier(0); // one sample at a time (register budget)
         }
         __syncthreads();
+#ifdef DIFFUS_STAMP
+        const unsigned long long t_f = STAMP_NOW();
+        prof[0] += t_f - t_a; prof[2] += 1; prof[3] += (unsigned long long)(rows * BVp * L);
+#endif
+#ifdef DIFFUS_SLAB_EXIT
+        if (DIFFUS_SLAB_EXIT == 4) return;
+#endif
         // ---- flush: a lane takes a column (V fastest: neighbours in a brick line), reads its L slots, recovers the layers
         // from the column's window and adds every non-zero entry to the gradient once; the tile is left all-zero
         const int ncols = rows * BVp;
@@ -568,51 +650,63 @@ __device__ __forceinline__ void slab_pass(const Args &A, double *tile, int (*s_b
             for (int sl = 0; sl < kSlabMaxL; ++sl) v[sl] = (sl < L) ? tile[sl * NC + col] : 0.0; // (sl < L: wave-uniform)
             const int Uc = uc + r, Vc = v0 + cc;
             int base = 0, bm = 0;
-            if (!face) {
+            if (!FACE) {
                 base = (int)floorf(__builtin_fmaf(cv, (float)Vc, __builtin_fmaf(cu, (float)Uc, c0b)));
-                bm = mod_small((unsigned)(base + 8 * L), (unsigned)L, magicL); // base > -L wherever something was added
+                bm = mod_rel(max(base - a0, 0), L, magic16); // (base >= a0 inside the box; the clamp only keeps padding columns tame)
             }
+            const unsigned cpart = slab_col_part<AX>(A.G, Uc, Vc);
 #pragma unroll
             for (int sl = 0; sl < kSlabMaxL; ++sl) {
                 if (sl < L && v[sl] != 0.0) {
                     tile[sl * NC + col] = 0.0;
                     int d = sl - bm;
                     d += (d < 0) ? L : 0;
-                    const int M = face ? (sl ? dimA - 1 : 0) : base + d;
+                    const int M = FACE ? (sl ? dimA - 1 : 0) : base + d;
                     if ((unsigned)M >= (unsigned)dimA) continue; // cannot happen while the window holds; never an out-of-bounds atomic
-                    const int x = AX == 0 ? M : (U == 0 ? Uc : Vc), y = AX == 1 ? M : (U == 1 ? Uc : Vc), z = AX == 2 ? M : (U == 2 ? Uc : Vc);
-                    const unsigned g = vox_off<DIFFUS_BRICKED>(A.G, x, y, z);
-                    if (A.gtouched) A.gtouched[g >> 5] = 1;
-                    atomicAdd(A.gvol + g, (float)v[sl]);
+                    const unsigned gb = cpart + slab_ax_part<AX>(A.G, rowA, M); // bytes
+#if defined(DIFFUS_SLAB_EXIT) && DIFFUS_SLAB_EXIT == 5
+                    asm volatile("" :: "v"(gb), "v"((float)v[sl]));
+#else
+                    if (A.gtouched) A.gtouched[gb >> 7] = 1;
+                    atomicAdd(reinterpret_cast<float *>(gvol_b + (size_t)gb), (float)v[sl]);
+#endif
                 }
             }
         }
-        __syncthreads(); // the next chunk / pass adds into the entries this one has just cleared
+        if (!(last && uc + rpc > u1)) __syncthreads(); // the next chunk / pass adds into the entries this one has just cleared
+#ifdef DIFFUS_STAMP
+        prof[1] += STAMP_NOW() - t_f;
+#endif
     }
 }
 
 // Returns false -- nothing added, tile clear -- when the patch's rays are not coplanar enough (the caller then runs the
 // general 3-D path); true when the patch is done.  Enters with the tile clear.
 template <int SAMPLER, int PM, int CAP>
-__device__ __forceinline__ bool scatter_patch_slab(const Args &A, double *tile, int (*s_box)[kSW][4], int *s_cls, int *s_dev, const Pose &ps,
-                                                   long pose, long w0, int nrays, const float *rows, unsigned row_off, bool ray_ok,
-                                                   int nbase, int tid)
+__device__ __forceinline__ bool scatter_patch_slab(const Args &A, double *tile, int (*s_rec)[18], const Pose &ps, const float (&dfl)[6],
+                                                   float (&zb)[kSPT], int nbase, int tid)
 {
+    // dfl: the directions of the patch's first and last ray; zb: the thread's zbar values (0 where it has no sample) --
+    // both requested by the kernel before anything waits on memory
     constexpr int CAPD = CAP / 2;
     const int wib = tid >> 6;
-    float zb[kSPT];
+    STAMP(1);
+#ifdef DIFFUS_SLAB_EXIT // stage probe (tools/time_slab_exits.py): return after stage n with the values so far forced live
+#define SLAB_EXIT(n, ...) if (DIFFUS_SLAB_EXIT == (n)) { asm volatile("" :: __VA_ARGS__); return true; }
+#else
+#define SLAB_EXIT(n, ...) ((void)0)
+#endif
+    SLAB_EXIT(1, "v"(zb[0]), "v"(zb[1]), "v"(zb[2]), "v"(zb[3]), "s"(dfl[0]), "s"(dfl[5]));
+    bool has = false;
 #pragma unroll
     for (int q = 0; q < kSPT; ++q) {
-        zb[q] = (ray_ok && nbase + q < A.N1) ? ldb_f32(rows, row_off + 4u * q) : 0.f;
         if (!finitef(zb[q])) zb[q] = 0.f;
+        has |= zb[q] != 0.f;
     }
     // ---- the plane of the patch: through the source, spanned by its first and last ray (block-uniform)
     float nrm[3];
     {
-        Pose pf, pl;
-        load_pose<PM>(pf, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w0);
-        load_pose<PM>(pl, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w0 + nrays - 1);
-        const float *a = pf.df, *b = pl.df;
+        const float *a = dfl, *b = dfl + 3;
         nrm[0] = a[1] * b[2] - a[2] * b[1]; nrm[1] = a[2] * b[0] - a[0] * b[2]; nrm[2] = a[0] * b[1] - a[1] * b[0];
         const float nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
         const float aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], bb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
@@ -634,58 +728,93 @@ __device__ __forceinline__ bool scatter_patch_slab(const Args &A, double *tile, 
     const float cu = sel3(nrm[0], nrm[1], nrm[2], axU) * inv, cv = sel3(nrm[0], nrm[1], nrm[2], axV) * inv;
     const float sA = sel3(ps.sf[0], ps.sf[1], ps.sf[2], ax), sU = sel3(ps.sf[0], ps.sf[1], ps.sf[2], axU), sV = sel3(ps.sf[0], ps.sf[1], ps.sf[2], axV);
     const float c0 = sA - cu * sU - cv * sV;
-    // ---- cells, classes, distance from the plane
+    // ---- how far this thread's RAY leaves that plane: p - h(p) is linear in the step (the source lies on the plane), so its
+    // largest value over the thread's samples is at the last one; plus what the float32 evaluation of the points themselves
+    // can be off by (the reference's rounding sequence, f64 poses included)
+    float dev = 0.f;
+    if (has) {
+        const float klast = (float)(A.start + nbase + kSPT - 1);
+        const float dA = sel3(ps.df[0], ps.df[1], ps.df[2], ax), dU = sel3(ps.df[0], ps.df[1], ps.df[2], axU), dV = sel3(ps.df[0], ps.df[1], ps.df[2], axV);
+        const float pmag = fmaxf(fmaxf(fabsf(ps.sf[0]) + klast * fabsf(ps.df[0]), fabsf(ps.sf[1]) + klast * fabsf(ps.df[1])),
+                                 fabsf(ps.sf[2]) + klast * fabsf(ps.df[2]));
+        dev = klast * fabsf(dA - cu * dU - cv * dV) + pmag * 0x1p-19f;
+    }
+    // ---- cells and classes
     SlabSample sm[kSPT];
     unsigned cls = 0; // 2 bits per sample: 0 inside the volume, 1 + a clamped on axis a (the lowest such a)
-    float dev = 0.f;
     const int dims[3] = {A.G.d0, A.G.d1, A.G.d2};
 #pragma unroll
     for (int q = 0; q < kSPT; ++q) {
         const float kf = (float)(A.start + nbase + q);
-        float p[3];
         bool in[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            p[a] = ray_point_f<PM>(ps, a, kf);
+            const float p = ray_point_f<PM>(ps, a, kf);
             if (SAMPLER == DIFFUS_NEAREST) {
-                const int i = nearest_index(p[a], dims[a]);
+                const int i = nearest_index(p, dims[a]);
                 sm[q].i0[a] = sm[q].i1[a] = i;
                 sm[q].t[a] = 0.f;
-                in[a] = rintf(p[a]) == (float)i;
+                in[a] = rintf(p) == (float)i;
             } else {
-                const Axis x = tri_axis(p[a], dims[a]);
+                const Axis x = tri_axis(p, dims[a]);
                 sm[q].i0[a] = x.i0; sm[q].i1[a] = x.i1; sm[q].t[a] = x.t;
                 in[a] = x.m != 0.f;
             }
         }
         const unsigned c = !in[0] ? 1u : (!in[1] ? 2u : (!in[2] ? 3u : 0u));
         cls |= c << (2 * q);
-        if (c == 0u && zb[q] != 0.f) {
-            const float h = __builtin_fmaf(cv, sel3(p[0], p[1], p[2], axV), __builtin_fmaf(cu, sel3(p[0], p[1], p[2], axU), c0));
-            dev = fmaxf(dev, fabsf(sel3(p[0], p[1], p[2], ax) - h));
-        }
     }
-    // ---- which passes the block needs, and the plane's measured thickness: one LDS word per wave each
+    STAMP(2);
+    SLAB_EXIT(2, "v"(cls), "v"(dev), "v"(sm[0].i0[0]), "v"(sm[1].i0[1]), "v"(sm[2].i0[2]), "v"(sm[3].i1[0]), "v"(sm[3].t[0]), "v"(sm[0].t[1]), "v"(sm[1].t[2]));
+    // ---- ONE barrier: which passes the block needs, the plane's measured thickness, and each pass's column box.  Record of a
+    // wave: [0] classes present, [1] largest distance from the plane, [2 + 4 c ..] box (U min, U max, V min, V max) of class c
+    // in the axes of ITS pass (class 0, the inside samples: the plane's minor axis; class 1 + a: axis a).
+    // The box of ALL FOUR samples of a thread is taken for whichever class the thread has a member of (consecutive steps of
+    // one ray: a box a few columns too large costs nothing; a select per sample per class costs instructions).
     unsigned present = 0;
 #pragma unroll
     for (unsigned c = 0; c < 4; ++c) {
         bool any = false;
 #pragma unroll
         for (int q = 0; q < kSPT; ++q) any |= ((cls >> (2 * q)) & 3u) == c && zb[q] != 0.f;
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) present |= 1u << c;
+        int bx[4] = {0x7fffffff, -1, 0x7fffffff, -1};
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) { // wave-uniform: a wave works out the boxes of the classes it has (one or two)
+            present |= 1u << c;
+            const int cU = c == 0 ? axU : (c == 3 ? 0 : 2), cV = c == 0 ? axV : (c == 2 ? 0 : 1); // SlabAxes of the pass
+            auto pick = [](const int (&v)[3], int a) { return a == 0 ? v[0] : (a == 1 ? v[1] : v[2]); };
+            int ulo = pick(sm[0].i0, cU), uhi = pick(sm[0].i1, cU), vlo = pick(sm[0].i0, cV), vhi = pick(sm[0].i1, cV);
+#pragma unroll
+            for (int q = 1; q < kSPT; ++q) { // (all four, not just the ends: a NaN or infinite direction is not monotone)
+                ulo = min(ulo, pick(sm[q].i0, cU)); uhi = max(uhi, pick(sm[q].i1, cU));
+                vlo = min(vlo, pick(sm[q].i0, cV)); vhi = max(vhi, pick(sm[q].i1, cV));
+            }
+            bx[0] = wave_reduce_minmax<true>(any ? ulo : 0x7fffffff);
+            bx[1] = wave_reduce_minmax<false>(any ? uhi : -1);
+            bx[2] = wave_reduce_minmax<true>(any ? vlo : 0x7fffffff);
+            bx[3] = wave_reduce_minmax<false>(any ? vhi : -1);
+        }
+        if ((tid & 63) == 63) { // (always written: the passes read all four waves' records without asking who has what)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s_rec[wib][2 + 4 * c + a] = bx[a];
+        }
     }
     const int devbits = wave_reduce_minmax<false>(__float_as_int(dev)); // dev >= 0 (NaN compares as a huge int: the patch then fails the test below)
     if ((tid & 63) == 63) {
-        s_cls[wib] = (int)present;
-        s_dev[wib] = devbits;
+        s_rec[wib][0] = (int)present;
+        s_rec[wib][1] = devbits;
     }
     __syncthreads();
     present = 0;
     int dmax = 0;
+    {
+        int rp[kSW], rd[kSW];
 #pragma unroll
-    for (int wv = 0; wv < kSW; ++wv) {
-        present |= (unsigned)__builtin_amdgcn_readfirstlane(s_cls[wv]);
-        dmax = max(dmax, __builtin_amdgcn_readfirstlane(s_dev[wv]));
+        for (int wv = 0; wv < kSW; ++wv) { rp[wv] = s_rec[wv][0]; rd[wv] = s_rec[wv][1]; }
+#pragma unroll
+        for (int wv = 0; wv < kSW; ++wv) {
+            present |= (unsigned)__builtin_amdgcn_readfirstlane(rp[wv]);
+            dmax = max(dmax, __builtin_amdgcn_readfirstlane(rd[wv]));
+        }
     }
     if (present == 0u) return true; // nothing to add (block-uniform)
     int L = 2;
@@ -694,29 +823,52 @@ __device__ __forceinline__ bool scatter_patch_slab(const Args &A, double *tile, 
         const float devmax = __int_as_float(dmax);
         const float dU = (float)(axU == 0 ? dims[0] : (axU == 1 ? dims[1] : dims[2])), dV = (float)(axV == 0 ? dims[0] : (axV == 1 ? dims[1] : dims[2]));
         const float T = fabsf(c0) + fabsf(cu) * dU + fabsf(cv) * dV + 2.f;
-        const float S = fabsf(cu) + fabsf(cv) + devmax + (1e-4f + T * 0x1p-19f); // + what float32 can err in h and in dev
+        const float S = fabsf(cu) + fabsf(cv) + devmax + (1e-4f + T * 0x1p-19f); // + what float32 can err in h
         if (!(S < 0.5f * (float)(kSlabMaxL - 2))) return false; // (also NaN) not a plane within kSlabMaxL layers: the general path
         L = (int)ceilf(2.f * S) + 2;
         c0b = c0 - S;
     }
-    int pass_no = 0;
-    auto passes_of_axis = [&](auto axis_) {
+    SLAB_EXIT(3, "s"(L), "s"(c0b), "v"(cls), "v"(sm[0].i0[0]), "v"(sm[1].i0[1]), "v"(sm[2].i0[2]), "v"(sm[3].i1[0]), "v"(sm[3].t[0]));
+#ifdef DIFFUS_STAMP
+    const unsigned long long t_rec = STAMP_NOW();
+#endif
+    STAMP(6);
+    unsigned long long prof[5] = {0ull, 0ull, 0ull, 0ull, 0ull}; // -DDIFFUS_STAMP: cycles in the accumulation / the flush, pass-chunks, tile entries
+    // the passes in the order they run: classes 1, 2, 3 and the inside samples right after the faces of the plane's minor axis
+    const unsigned last_class = (present & 1u) ? ((present >> (ax + 2)) ? (31u - (unsigned)__builtin_clz(present)) : 0u)
+                                               : (31u - (unsigned)__builtin_clz(present));
+    auto run_pass = [&](auto axis_, auto face_) {
         constexpr int a = decltype(axis_)::value;
-#pragma unroll 1
-        for (int kind = 0; kind < 2; ++kind) { // 0: the samples clamped on axis a; 1: the inside samples, if a is the plane's minor axis
-            const bool face = kind == 0;
-            if (face ? !(present >> (a + 1) & 1u) : !((present & 1u) && ax == a)) continue; // block-uniform
-            const unsigned want = face ? (unsigned)(a + 1) : 0u;
-            unsigned member = 0;
+        constexpr bool face = decltype(face_)::value;
+        const unsigned want = face ? (unsigned)(a + 1) : 0u;
+        unsigned member = 0;
 #pragma unroll
-            for (int q = 0; q < kSPT; ++q) member |= ((((cls >> (2 * q)) & 3u) == want && zb[q] != 0.f) ? 1u : 0u) << q;
-            slab_pass<SAMPLER, a, CAPD>(A, tile, s_box[pass_no & 1], sm, zb, member, face, cu, cv, c0b, face ? 2 : L, tid);
-            ++pass_no;
+        for (int q = 0; q < kSPT; ++q) member |= ((((cls >> (2 * q)) & 3u) == want && zb[q] != 0.f) ? 1u : 0u) << q;
+        // the four waves' boxes of this class: four unconditional LDS reads in flight at once, merged on the scalar unit
+        int rb[kSW][4];
+#pragma unroll
+        for (int wv = 0; wv < kSW; ++wv)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[wv][e] = s_rec[wv][2 + 4 * want + e];
+        int u0 = 0x7fffffff, u1 = -1, v0 = 0x7fffffff, v1 = -1;
+#pragma unroll
+        for (int wv = 0; wv < kSW; ++wv) {
+            u0 = min(u0, __builtin_amdgcn_readfirstlane(rb[wv][0])); u1 = max(u1, __builtin_amdgcn_readfirstlane(rb[wv][1]));
+            v0 = min(v0, __builtin_amdgcn_readfirstlane(rb[wv][2])); v1 = max(v1, __builtin_amdgcn_readfirstlane(rb[wv][3]));
         }
+        slab_pass<SAMPLER, a, face, CAPD>(A, tile, sm, zb, member, cu, cv, c0b, face ? 2 : L, u0, u1, v0, v1, want == last_class, tid, prof);
     };
-    passes_of_axis(std::integral_constant<int, 0>{});
-    passes_of_axis(std::integral_constant<int, 1>{});
-    passes_of_axis(std::integral_constant<int, 2>{});
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (present >> 1 & 1u) run_pass(std::integral_constant<int, 0>{}, T_{});
+    if ((present & 1u) && ax == 0) run_pass(std::integral_constant<int, 0>{}, F_{});
+    if (present >> 2 & 1u) run_pass(std::integral_constant<int, 1>{}, T_{});
+    if ((present & 1u) && ax == 1) run_pass(std::integral_constant<int, 1>{}, F_{});
+    if (present >> 3 & 1u) run_pass(std::integral_constant<int, 2>{}, T_{});
+    if ((present & 1u) && ax == 2) run_pass(std::integral_constant<int, 2>{}, F_{});
+#ifdef DIFFUS_STAMP
+    STAMPV(3, prof[0]); STAMPV(4, prof[1]); STAMP(5); STAMPV(7, ((prof[3] * 16ull + prof[2]) << 24) | ((prof[4] - t_rec) & 0xffffffull));
+#endif
     return true;
 }
 
@@ -732,7 +884,7 @@ __global__ __launch_bounds__(kSB, SLAB ? 4 : DIFFUS_SC_MIN_BLOCKS) void scatter_
     // gfx950, ds_add_u32 5-15: tools/lds_atomic_bench.hip.)  Planar patches -- every fan of the reference -- take the
     // 2-D double-precision tile of scatter_patch_planar instead.
     __shared__ __attribute__((aligned(16))) int tile[CAP];
-    __shared__ int s_slab_box[SLAB ? 2 : 1][kSW][4], s_cls[kSW], s_dev[kSW]; // slab path: per-wave column boxes (double-buffered by pass), classes, plane thickness
+    __shared__ int s_slab[SLAB ? kSW : 1][18]; // slab path: a record per wave (classes present, distance from the plane, a column box per class)
     __shared__ int s_wlo[kSW][3], s_whi[kSW][3]; // per-WAVE boxes (a wave = 64 / kPatchSteps * kSPT rays x kPatchSteps steps)
     __shared__ float s_sum[kSW];
     __shared__ int s_planar[kSW];
@@ -818,6 +970,24 @@ __global__ __launch_bounds__(kSB, SLAB ? 4 : DIFFUS_SC_MIN_BLOCKS) void scatter_
         load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
     }
     if constexpr (kCanPlanar) {
+        // The launch that carries the slab path asks the block's FIRST ray before it tries the planar path (a scalar load, no
+        // barrier): a fan that leaves the slice does so with every ray but, at most, its central one.
+        bool try_planar = true;
+        float dfl[6], zpre[kSPT]; // slab path: directions of the patch's first and last ray (block-uniform), the thread's zbar values
+        if constexpr (SLAB) {
+            // everything the slab path reads from memory is requested HERE, before the first wait: the zbar values (a vector
+            // load), the two directions (scalar loads)
+            const long wl = w0 + (long)min(kScRays, A.R - (int)(w0 - (long)pose * A.R)) - 1;
+#pragma unroll
+            for (int q = 0; q < kSPT; ++q) zpre[q] = (ray_ok && nbase + q < A.N1) ? ldb_f32(A.zbar + w0 * A.N1, row_off + 4u * q) : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dfl[c] = A.dir_f64 ? (float)((const double *)A.dirs)[w0 * 3 + c] : ((const float *)A.dirs)[w0 * 3 + c];
+                dfl[3 + c] = A.dir_f64 ? (float)((const double *)A.dirs)[wl * 3 + c] : ((const float *)A.dirs)[wl * 3 + c];
+            }
+            try_planar = __builtin_amdgcn_readfirstlane((int)(dfl[2] == 0.f)) != 0;
+        }
+        if (try_planar) {
         if (scatter_patch_planar<SAMPLER, PM, CAP>(A, reinterpret_cast<double *>(tile), s_box, s_planar, &s_live, ps, A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid)) return;
 #ifdef DIFFUS_SC_PLANAR_ONLY // timing probe: the general path compiled out (register budget of the planar path alone)
         return;
@@ -828,11 +998,13 @@ __global__ __launch_bounds__(kSB, SLAB ? 4 : DIFFUS_SC_MIN_BLOCKS) void scatter_
         asm volatile("" : "+s"(bx), "+s"(by));
         decode(bx, by);
         load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+        } else { // the tile the planar path would have cleared
+            int4 *t4 = reinterpret_cast<int4 *>(tile);
+#pragma unroll
+            for (int e = 0; e < CAP / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
+        }
         if constexpr (SLAB) { // a fan that leaves the slice: the height-field tile over its plane
-            const int rg0 = (int)(w0 - (long)pose * A.R);
-            if (scatter_patch_slab<SAMPLER, PM, CAP>(A, reinterpret_cast<double *>(tile), s_slab_box, s_cls, s_dev, ps, pose, w0,
-                                                     min(kScRays, A.R - rg0), A.zbar + w0 * A.N1, row_off, ray_ok, nbase, tid))
-                return;
+            if (scatter_patch_slab<SAMPLER, PM, CAP>(A, reinterpret_cast<double *>(tile), s_slab, ps, dfl, zpre, nbase, tid)) return;
             __syncthreads(); // not a plane: every wave is done with the slab records before the general path starts over
             asm volatile("" : "+s"(bx), "+s"(by));
             decode(bx, by);

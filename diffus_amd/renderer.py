@@ -325,6 +325,29 @@ def resolve_start(start, num_samples: int) -> int:
     return int(start)
 
 
+_planar_seen: list = []          # (weakref to a device `directions` tensor, version, planar): one readback per tensor version
+
+
+def _fans_planar(directions: torch.Tensor):
+    """Whether NO direction moves along dim 2 (every fan of the reference: src/cone.py:258) -- the hint that selects the
+    scatter launch for planar fans (DIFFUS_FANS_PLANAR).  Host tensors are looked at directly; a device tensor that is not
+    being optimised costs one readback per tensor version; directions that require grad (a pose optimisation changes them
+    every step, and tilts them) stay unknown (None): the launch that also carries the slab path."""
+    if directions.shape[-1] != 3:
+        return None
+    if not directions.is_cuda:
+        return bool((directions.detach()[..., 2] == 0).all())
+    if directions.requires_grad or directions.grad_fn is not None:
+        return None
+    _planar_seen[:] = [e for e in _planar_seen if e[0]() is not None][-8:]
+    for ref, ver, val in _planar_seen:
+        if ref() is directions and ver == directions._version:
+            return val
+    val = bool((directions[..., 2] == 0).all())
+    _planar_seen.append((weakref.ref(directions), directions._version, val))
+    return val
+
+
 class _Problem:
     """Validated, device-resident arguments of one (batched) call."""
 
@@ -346,6 +369,7 @@ class _Problem:
         self._layout_req, self._vol_src = layout, volume
         self._common = None
         sd, dd = _pose_dtype(sources), _pose_dtype(directions)
+        self.planar = _fans_planar(directions)
         if not sources.is_cuda and not directions.is_cuda:       # host poses: one packed, asynchronous upload
             with _Scope(self.dev):
                 up = _upload_small(self.dev, [(sources, sd), (directions, dd)])
@@ -384,6 +408,11 @@ class _Problem:
             c = self._common = (_ptr(v), d0, d1, d2, self.layout, _ptr(self.src), self.src_dt, _ptr(self.dirs), self.dir_dt,
                                 self.P, self.R, self.S, self.start, self.alpha, self.sampler)
         return c
+
+    def common_bwd(self):
+        """common() for the backward entry points: the layout word also carries the planar-fan hint."""
+        c = self.common()
+        return c[:4] + (c[4] | _lib.FANS_PLANAR,) + c[5:] if self.planar else c
 
     def workspace(self):
         return _workspace(self.dev, _render_ws_bytes(self.P, self.R, self.S, self.start))
@@ -448,7 +477,7 @@ class _RenderFn(torch.autograd.Function):
             gsrc = torch.empty((pb.P, 3), dtype=torch.float32, device=pb.dev) if need_s else None
             gdirs = torch.empty((pb.P, pb.R, 3), dtype=torch.float32, device=pb.dev) if need_d else None
             ws = pb.workspace()
-            rc = lib.diffus_render_bwd(*pb.common(), _ptr(g), _ptr(gvol), _ptr(touched), _ptr(gsrc), _ptr(gdirs),
+            rc = lib.diffus_render_bwd(*pb.common_bwd(), _ptr(g), _ptr(gvol), _ptr(touched), _ptr(gsrc), _ptr(gdirs),
                                        _lib.BWD_ALL, _ptr(ws), ws.numel(), _stream(pb.dev))
             _lib.check(rc, "diffus_render_bwd")
             if sparse:      # a fresh dense (d0,d1,d2) gradient in ONE launch: touched bricks' values, zeros elsewhere

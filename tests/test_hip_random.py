@@ -84,10 +84,10 @@ def test_random_backward_vs_autograd(seed):
             if np.max(np.abs(ref)) < 1e-14:          # degenerate pose (ray inside one or two voxels): everything cancels
                 assert np.max(np.abs(gv)) < 1e-9, (seed, sampler, layout)
                 continue
-            assert maxnorm_rel(gv, ref) < 2e-3, (seed, sampler, layout)
+            assert maxnorm_rel(gv, ref) < 1e-3, (seed, sampler, layout)
             if sampler == "trilinear":
-                assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 5e-3, (seed, layout)
-                assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 5e-3, (seed, layout)
+                assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 1e-3, (seed, layout)
+                assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 1e-3, (seed, layout)
 
 
 def _long_case(seed):
@@ -131,7 +131,7 @@ def test_random_long_rays_forward_and_backward(oracle, seed):
             assert maxnorm_rel(f[0].detach().cpu().numpy(), fo) < 5e-5, (seed, sampler, layout)
             (f[0] * up.float().cuda()).sum().backward()
             ref = v64.grad.numpy()
-            assert maxnorm_rel(v.grad.cpu().numpy(), ref) < 2e-3, (seed, sampler, layout)
+            assert maxnorm_rel(v.grad.cpu().numpy(), ref) < 1e-3, (seed, sampler, layout)
             if sampler == "trilinear":
-                assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 5e-3, (seed, layout)
-                assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 5e-3, (seed, layout)
+                assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 1e-3, (seed, layout)
+                assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 1e-3, (seed, layout)

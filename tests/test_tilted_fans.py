@@ -111,3 +111,68 @@ def test_scatter_error_bound_per_voxel_oblique(da, alpha, sampler, roll, pitch, 
     if alpha == 0.5:
         assert int(deep.sum()) > 10
         assert int((g[deep] != 0).sum()) > 0.9 * int(deep.sum())
+
+
+def _ring_step(Step, vol, src, dirs, S, **kw):
+    st = Step(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), S, 1e-3, "trilinear", **kw)
+    st.step()
+    torch.cuda.synchronize()
+    return st
+
+
+def test_fans_hint_never_changes_the_result(da):
+    """DIFFUS_FANS_PLANAR is a hint: a wrong promise (tilted fans on the planar launch: the general 3-D tile takes them) and
+    no promise at all (planar fans on the slab-capable launch) give the gradients of the right launch; `fans="auto"` looks at
+    the directions once, and set_poses() with new directions makes the answer unknown (the slab-capable launch)."""
+    from diffus_amd import CapturedStep
+    n, P, R, S = 64, 4, 64, 96
+    vol = torch.from_numpy(phantom(n)).cuda()
+    flat = pose_ring(n, P, R)
+    tilt = pose_ring(n, P, R, roll_deg=20.0, pitch_deg=5.0)
+    for (src, dirs), planar in ((flat, True), (tilt, False)):
+        a = _ring_step(CapturedStep, vol, src, dirs, S, fans="planar")
+        b = _ring_step(CapturedStep, vol, src, dirs, S, fans="oblique")
+        c = _ring_step(CapturedStep, vol, src, dirs, S)
+        assert a.fans_planar and not b.fans_planar and c.fans_planar == planar
+        den = float(b.gvol.abs().max())
+        assert den > 0
+        assert float((a.gvol - b.gvol).abs().max()) <= 2e-5 * den          # (the 3-D tile is 32-bit fixed point: 2^-20 of a patch's largest)
+        assert float((c.gvol - b.gvol).abs().max()) <= 2e-5 * den
+        assert torch.equal(a.frame, b.frame) and torch.equal(a.gsrc, b.gsrc) and torch.equal(a.gdirs, b.gdirs)
+    st = _ring_step(CapturedStep, vol, flat[0], flat[1], S)
+    assert st.fans_planar
+    st.set_poses(torch.from_numpy(tilt[0]).cuda(), torch.from_numpy(tilt[1]).cuda())
+    assert not st.fans_planar
+    st.step()
+    torch.cuda.synchronize()
+    ref = _ring_step(CapturedStep, vol, tilt[0], tilt[1], S, fans="oblique")
+    assert float((st.gvol - ref.gvol).abs().max()) <= 1e-6 * float(ref.gvol.abs().max())
+
+
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
+@pytest.mark.parametrize("step", [1.0, 1.7, 2.6, 6.0, 19.0])
+def test_slab_scatter_long_steps_every_chunking(da, sampler, step):
+    """The slab path keeps a pass in one tile when its column box x layers fits, walks it in chunks of rows when it does not,
+    and adds straight to memory when a single row is too wide.  Step lengths 1.7 ... 19 voxels on a tilted fan in a wide
+    volume walk through all of these; every one against float64 autograd of the same render (the reference accepts any
+    direction norm: renderer.py:94-110)."""
+    from oracle import autograd_ref as ar
+    rng = np.random.default_rng(13)
+    v = (1.5e6 + 2e5 * rng.standard_normal((300, 300, 40))).astype(np.float32)
+    R, S = 64, 96
+    ang = np.linspace(0.35, 1.2, R)
+    tilt = 0.3
+    dirs = (step * np.stack([np.cos(ang), np.sin(ang) * np.cos(tilt), np.sin(ang) * np.sin(tilt)], 1)).astype(np.float32)
+    src = np.array([6.3, 9.1, 3.4], np.float32)
+    v64 = torch.from_numpy(v).double().requires_grad_(True)
+    f64 = ar.render(v64, torch.from_numpy(src).double(), torch.from_numpy(dirs).double(), S, 2e-3, 0, sampler, points="f32")
+    up = torch.randn(f64.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    (f64 * up).sum().backward()
+    gv_ref = v64.grad.numpy()
+    for layout in ("paired", "canonical"):
+        vol = torch.from_numpy(v).cuda().requires_grad_(True)
+        f = da.render_poses(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), S, 2e-3, sampler=sampler, layout=layout)[0]
+        assert maxnorm_rel(f.detach().cpu().numpy(), f64.detach().numpy()) < 2e-5
+        (f * up.float().cuda()).sum().backward()
+        assert maxnorm_rel(vol.grad.cpu().numpy(), gv_ref) < 1e-3, (layout, step)
+        assert abs(float(vol.grad.double().sum()) - gv_ref.sum()) <= 1e-4 * np.abs(gv_ref).sum()

@@ -15,7 +15,7 @@ from diffus_amd.phantom import phantom, pose_ring  # noqa: E402
 N = int(os.environ.get("N", "256")); RAYS = int(os.environ.get("RAYS", "256")); SAMPLES = int(os.environ.get("SAMPLES", "512"))
 P = int(os.environ.get("POSES", "32")); STEPS = int(os.environ.get("STEPS", "6"))
 vol = torch.from_numpy(phantom(N)).cuda()
-src, dirs = pose_ring(N, P, RAYS)
+src, dirs = pose_ring(N, P, RAYS, roll_deg=float(os.environ.get("ROLL", "0")), pitch_deg=float(os.environ.get("PITCH", "0")))
 hp = CapturedStep(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), SAMPLES, 1e-4,
                   os.environ.get("SAMPLER", "trilinear"), layout=os.environ.get("LAYOUT", "paired"))
 for _ in range(STEPS):
