@@ -854,6 +854,19 @@ def verify_step(args, vol_of_pose, src_all, dirs_all, local_lo, hp, losses_all, 
         err = float(np.abs(hp.frame[q].cpu().numpy() - f64).max() / max(np.abs(f64).max(), 1e-300))
         frames.append({"pose": int(local_lo + q), "rel_err": err, "tol": tol})
         ok &= err <= tol
+    # the same poses through the FORWARD kernel (diffus_render_fwd: what plot_beam_frame / render_poses return).  It evaluates
+    # ill-conditioned rays (|echo| > 8: fans that graze the skull) again in float64 inside the kernel; the one-pass training step
+    # timed above does not unless asked to (DIFFUS_BWD_REPAIR_FRAME, ~10 us per step) -- its frame is a by-product.  Tolerance:
+    # 5e-5 (the reference's own float32 result is 4.2e-5 from this on pose 18, golden G19).
+    fwd_frames = []
+    if args.start == 0 and frame_poses:
+        hp.fwd()
+        for q in frame_poses:
+            f64, _ = oracle_frame(local_lo + q)
+            err = float(np.abs(hp.frame[q].cpu().numpy() - f64).max() / max(np.abs(f64).max(), 1e-300))
+            fwd_frames.append({"pose": int(local_lo + q), "rel_err": err, "tol": 5e-5})
+            ok &= err <= 5e-5
+        hp.step()       # leave the step's own frame in the buffer again
     lv = losses_all.cpu().numpy()
     for p in loss_poses:
         want = float((oracle_frame(p)[0] ** 2).sum())
@@ -862,7 +875,7 @@ def verify_step(args, vol_of_pose, src_all, dirs_all, local_lo, hp, losses_all, 
         ok &= err <= 1e-4
     return {"oracle": "oracle/diffus_oracle.c + oracle/conditioning.py (CPU restatement of reference src/renderer.py:201-275, "
                       "echo series in float64)",
-            "frames": frames, "losses": losses,
+            "frames": frames, "forward_kernel_frames": fwd_frames, "losses": losses,
             "max_rel_err": max([x["rel_err"] for x in frames + losses] or [0.0]), "ok": bool(ok)}
 
 

@@ -32,6 +32,7 @@ FANS_PLANAR = 0x20    # OR'ed into `layout` of the backward calls: a hint that n
 FLUSH_STORE, FLUSH_ACCUMULATE, FLUSH_PERSISTENT, FLUSH_DENSE = 0, 1, 2, 3   # diffus_gradbuf_flush modes
 BWD_SCAN, BWD_SCATTER, BWD_ALL = 1, 2, 3
 BWD_KEEP_MEDIAN = 4         # start > 0: the workspace still holds the forward's median (include/diffus_hip.h)
+BWD_REPAIR_FRAME = 8        # one-pass step: float64 frame rows for ill-conditioned rays (include/diffus_hip.h; ~10 us per step)
 MAX_SAMPLES = 1024          # cropped samples per launch; longer rays run as chained segments
 MAX_SEGMENTS = 64
 

@@ -153,7 +153,7 @@ class CapturedStep:
                  layout: str = "paired", sparse: bool = True, persistent: bool = True,
                  learnable_volume=False, alias_grads: bool = False, fused_loss: bool = True,
                  target: Optional[torch.Tensor] = None, loss_scale: float = 1.0, one_pass: bool = True,
-                 bricked_grad: Optional[bool] = None, fans: str = "auto"):
+                 bricked_grad: Optional[bool] = None, fans: str = "auto", repair_frames: bool = False):
         if not volume.is_cuda:
             raise _lib.DiffusError("CapturedStep needs a HIP-resident volume; there is no CPU fallback")
         if volume.dim() != 3 or volume.dtype != torch.float32 or not volume.is_contiguous():
@@ -174,6 +174,9 @@ class CapturedStep:
         # correctness); "oblique" -- the launch that also carries the slab path for fans that leave the slice; "auto" -- look
         # at the directions now (one readback) and again never: set_poses() with new directions makes the answer unknown,
         # and unknown means the slab-capable launch.
+        # repair_frames: the one-pass step evaluates the frame rows of ILL-CONDITIONED rays (a ray grazing the skull: |echo| > 8)
+        # again in float64 (DIFFUS_BWD_REPAIR_FRAME) -- what the forward kernel does by itself; here it costs ~10 us per step
+        self.repair_frames = bool(repair_frames)
         if fans not in ("auto", "planar", "oblique"):
             raise ValueError("fans: 'auto', 'planar' or 'oblique'")
         self.fans = fans
@@ -407,7 +410,8 @@ class CapturedStep:
         _lib.check(self.lib.diffus_render_step_mse(*self.common_bwd, _vp(self.target), self.loss_scale, _vp(self.frame),
                                                    _vp(self.loss if epilogue else None), _vp(self.gvol_k), _vp(self.touched),
                                                    _vp(self.gsrc if (epilogue and self._pose_grads) else None),
-                                                   _vp(self.gdirs if self._pose_grads else None), stages,
+                                                   _vp(self.gdirs if self._pose_grads else None),
+                                                   stages | (_lib.BWD_REPAIR_FRAME if (self.repair_frames and epilogue) else 0),
                                                    _vp(self.ws), self.ws.numel(), self.stream()),
                    "diffus_render_step_mse")
 

@@ -601,6 +601,8 @@ struct Args {
     float *zcout;      // backward, nullable (P*R): contribution of this segment's first r to sample seg0-1
     float *gsrc_out;   // pose_finish_block, nullable (P,3): the per-pose sum of gsrc_part over rays goes here
     int finish_in_scatter; // the scatter launch carries P extra blocks that run pose_finish_block
+    int vol_layout;        // layout of `vol` as a run-time value (pose_finish_block's float64 repair samples through it)
+    int *rflag;            // nullable (P,R,2): one-pass step, set by the scan for ray halves with |echo| > kEchoRecheck
     int fans_planar;       // the caller vouches that no ray moves along dim 2 (DIFFUS_FANS_PLANAR): the scatter launch without the slab path
     int accum_pose;    // backward: add to (instead of overwrite) the per-ray pose-gradient partials
     float neg_alpha;     // -alpha
@@ -1117,6 +1119,154 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
     }
 }
 
+// ---- the echo series of an ILL-CONDITIONED ray, in float64 (wave-uniform rare path of the scans) -----------------------
+// echo_n = b_n / d_n; on a ray that grazes the skull d_n is nearly cancelled for a sample or two (|echo| = 123 and 287 on the
+// two worst rays of BASELINE config 3, ~0.05 elsewhere) and every float32 evaluation carries (condition number) x eps of
+// noise there -- the reference's own dense LU 4.2e-5 of the ray's peak (golden G19), the wave scan's tree of 2x2 products
+// 2.5x that.  A wave that sees |echo| > kEchoRecheck anywhere (9 rays in 8192 at config 3: max |echo| x eps x ~10 is below
+// 1e-5 of the ray's peak under that) evaluates the SAME scan again in float64 and keeps those echoes: the result is then the
+// float64 series of its float32 reflection coefficients, i.e. better conditioned than any float32 evaluation, the
+// reference's included.  Well-conditioned rays never take the branch and stay bit-identical.
+#ifndef DIFFUS_ECHO_RECHECK
+#define DIFFUS_ECHO_RECHECK 8.f
+#endif
+constexpr float kEchoRecheck = DIFFUS_ECHO_RECHECK;
+struct DMat {
+    double a, b, c, d;
+};
+__device__ __forceinline__ DMat dmat_mul(const DMat &x, const DMat &y)
+{
+    return DMat{__builtin_fma(x.a, y.a, x.b * y.c), __builtin_fma(x.a, y.b, x.b * y.d), __builtin_fma(x.c, y.a, x.d * y.c),
+                __builtin_fma(x.c, y.b, x.d * y.d)};
+}
+__device__ __forceinline__ DMat dmat_step(const DMat &p, double r) // P * M(r)
+{
+    const double a = 1.0 - (2.0 * r) * r;
+    return DMat{__builtin_fma(p.a, a, -(p.b * r)), __builtin_fma(p.a, r, p.b), __builtin_fma(p.c, a, -(p.d * r)), __builtin_fma(p.c, r, p.d)};
+}
+__device__ __forceinline__ void dmat_renorm(DMat &m) // exact power-of-two rescale (the ratio b / d does not see it)
+{
+    const double mx = fmax(fmax(fabs(m.a), fabs(m.b)), fmax(fabs(m.c), fabs(m.d)));
+    const int ex = (mx > 0.0 && mx < __builtin_inf()) ? ilogb(mx) : 0;
+    m.a = ldexp(m.a, -ex); m.b = ldexp(m.b, -ex); m.c = ldexp(m.c, -ex); m.d = ldexp(m.d, -ex);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_d(double old, double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ DMat dmat_dpp_ident(const DMat &m) // the identity where a lane has no source
+{
+    return DMat{dpp_mov_d<CTRL, ROW_MASK>(1.0, m.a), dpp_mov_d<CTRL, ROW_MASK>(0.0, m.b), dpp_mov_d<CTRL, ROW_MASK>(0.0, m.c),
+                dpp_mov_d<CTRL, ROW_MASK>(1.0, m.d)};
+}
+// r[j]: the reflection coefficient entering sample n = lane * C + j (0 where there is none); e[j] gets echo_n (NaN -> 0,
+// reference :408).  carry: a product that precedes the whole wave (nullable).
+template <int C, typename T>
+__device__ __forceinline__ void echo_chunk_f64(const T (&r)[C], int lane, float (&e)[C], const DMat *carry = nullptr)
+{
+    DMat L{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int j = 0; j < C; ++j) L = dmat_step(L, (double)r[j]);
+    dmat_renorm(L);
+#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)             \
+    {                                                  \
+        const DMat o = dmat_dpp_ident<CTRL, RMASK>(L); \
+        L = dmat_mul(o, L);                            \
+        if (RN) dmat_renorm(L);                        \
+    }
+    DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
+#undef DIFFUS_ROUND
+    DMat Pm{dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.a), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.b), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.c),
+            dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.d)}; // exclusive prefix; lane 0: identity
+    if (carry) {
+        Pm = dmat_mul(*carry, Pm);
+        dmat_renorm(Pm);
+    }
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        Pm = dmat_step(Pm, (double)r[j]);
+        if ((j & 3) == 3) dmat_renorm(Pm);
+        const double v = Pm.b / Pm.d;
+        e[j] = (v == v) ? (float)v : 0.f;
+    }
+}
+// The float64 series of such a ray from its float32 impedance samples -- the samples taken AGAIN, with the stage-wise sampler
+// (tri_sample: the oracle's lerp sequence bit for bit, i.e. the reference's grid_sample / nearest gather): on these rays the
+// last bit of a sample is worth as much as the scan's own noise (the fused gather's one-fma lerps differ from that sequence by
+// a rounding: 1e-4 of the ray's peak on pose 18 of config 3 with the scan already in float64).
+// A cold branch (__builtin_expect at the call sites: what the register allocator must move is moved around THIS block, not
+// inside the hot code) -- but a wave that takes it is likely to be the kernel's TAIL, so it is written for its own latency: every
+// sample requested before the first is used, no IEEE division.  (As a called function the kernels inherit its 178 VGPRs; with
+// rolled loops that sample one point at a time the nine such waves of config 3 held the scan kernel for 25 us.)
+// CHUNKED mapping: lane owns samples n0 .. n0 + C - 1 of the segment; e[j] gets echo_n (NaN -> 0).
+template <int C, int SAMPLER, int LAYOUT, int PM>
+__device__ __forceinline__ void echo_f64_rare(const Args &A, const Pose &ps, int seg0, int segN, int n0, float medv, float (&e)[C])
+{
+    const int lane = n0 / C;
+    // all samples first (one memory round trip: a wave that takes this path is the kernel's tail), then the coefficients
+    float z[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int k = A.start + seg0 + n0 + j; // (past the end of the ray: any point is clamped into the volume; masked below)
+        const float p0 = ray_point<PM>(ps, 0, k), p1 = ray_point<PM>(ps, 1, k), p2 = ray_point<PM>(ps, 2, k);
+        if (SAMPLER == DIFFUS_NEAREST)
+            z[j] = A.vol[vox_off<LAYOUT>(A.G, nearest_index(p0, A.G.d0), nearest_index(p1, A.G.d1), nearest_index(p2, A.G.d2))];
+        else
+            z[j] = tri_sample<LAYOUT, false>(A.vol, A.G, p0, p1, p2).v;
+    }
+    const float zprev = lane_prev(z[C - 1], z[C - 1]);
+    double r[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const int nl = n0 + j, n = seg0 + nl;
+        const double zp = (double)((j == 0) ? zprev : z[j == 0 ? 0 : j - 1]), zc = (double)z[j];
+        // (zc - zp) / (zp + zc): v_rcp_f64 and two Newton steps (to the last bit or two of a double: far below the float32 samples'
+        // own rounding) instead of the ~40 instructions of an IEEE division
+        const double den = zp + zc;
+        double x = __builtin_amdgcn_rcp(den);
+        x = x * __builtin_fma(-den, x, 2.0);
+        x = x * __builtin_fma(-den, x, 2.0);
+        double v = (zc - zp) * x;
+        if (n == 1 && A.start > 0) v = (double)medv;
+        r[j] = (n >= 1 && nl < segN) ? v : 0.0;
+    }
+    DMat L{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int j = 0; j < C; ++j) L = dmat_step(L, r[j]);
+    dmat_renorm(L);
+#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)             \
+    {                                                  \
+        const DMat o = dmat_dpp_ident<CTRL, RMASK>(L); \
+        L = dmat_mul(o, L);                            \
+        if (RN) dmat_renorm(L);                        \
+    }
+    DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
+#undef DIFFUS_ROUND
+    DMat Pm{dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.a), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.b), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.c),
+            dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.d)}; // exclusive prefix; lane 0: identity
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        Pm = dmat_step(Pm, r[j]);
+        if ((j & 3) == 3) dmat_renorm(Pm);
+        // b and d are accurate now; their quotient needs no more than float32 (entries are within 2^4 of 1 in magnitude range)
+        const float v = fast_div((float)Pm.b, (float)Pm.d);
+        e[j] = (v == v) ? v : 0.f;
+    }
+}
+// wave-uniform: does any lane hold an echo that asks for the float64 evaluation?
+template <int C>
+__device__ __forceinline__ bool echo_needs_f64(const float (&e)[C])
+{
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) m = fmaxf(m, fabsf(e[j])); // (NaN-free: echo_chunk has zeroed them)
+    return __builtin_amdgcn_ballot_w64(m > kEchoRecheck) != 0ull;
+}
+
 // ---- patches of the (ray, step) grid: shared by the gradient scatter and the splat winner kernel ----
 // 32 adjacent rays x 32 consecutive steps: at unit steps and the demos' ray spacing this footprint is about square,
 // i.e. the smallest bounding box for 1024 samples (16 x 64: scatter 52 us, 32 x 32: 49, 64 x 16: 53)
@@ -1182,6 +1332,118 @@ __device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
 }
 
 
+// ---- float64 repair of an ill-conditioned ray's frame row (one-pass step; called from pose_finish_block by ONE wave, all lanes
+// active).  The scan kernel flags rays with |echo| > kEchoRecheck; here the row is evaluated again as the float64 pipeline
+// from float32 samples taken with the ORACLE's lerp sequence (the stage-wise tri_sample), the frame row and the ray's loss term are overwritten.  The gradients keep the float32 scan's values (they carry
+// the same condition number whatever the arithmetic).  Off the critical path -- the per-pose blocks sit at the head of the
+// scatter launch.
+// It shares its kernels' register budget (the scatter's patch path: 80) and must not spill: scratch under every wave of a launch
+// is paid by all of them (as a called function with 1.2 KB of stack the scatter went from 26 to 98 us), and what the register
+// allocator moves for it, it moves in the patch path too (+2.5 us with ~100 registers of unrolled float64 state inlined).  So:
+// the ray's samples wait in LDS (zbuf: 1024 floats of the caller's) and every loop over a lane's 16 samples is ROLLED -- two
+// 2x2 matrices of doubles and a sample's worth of temporaries are all that is live.  ~10 us per ray, beside the first patches.
+// element offset of voxel (x, y, z) for a layout known at run time only, branch-free (all three forms, two selects): the eight
+// corner loads of a sample stay in flight together, and the per-pose blocks carry ONE copy of the repair
+__device__ __forceinline__ unsigned vox_off_rt(int layout, const Geom &G, int x, int y, int z)
+{
+    const unsigned c = vox_off<DIFFUS_CANONICAL>(G, x, y, z), p = vox_off<DIFFUS_PAIRED>(G, x, y, z), b = vox_off<DIFFUS_BRICKED>(G, x, y, z);
+    return layout == DIFFUS_CANONICAL ? c : (layout == DIFFUS_PAIRED ? p : b);
+}
+template <int SAMPLER>
+__device__ __forceinline__ float sample_rt(const Args &A, const Pose &ps, int k)
+{
+    const float p0 = ray_point(ps, 0, k), p1 = ray_point(ps, 1, k), p2 = ray_point(ps, 2, k);
+    const int lay = A.vol_layout;
+    if (SAMPLER == DIFFUS_NEAREST)
+        return A.vol[vox_off_rt(lay, A.G, nearest_index(p0, A.G.d0), nearest_index(p1, A.G.d1), nearest_index(p2, A.G.d2))];
+    const Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1), c = tri_axis(p2, A.G.d2);
+    const unsigned o000 = vox_off_rt(lay, A.G, a.i0, b.i0, c.i0), o001 = vox_off_rt(lay, A.G, a.i0, b.i0, c.i1), o010 = vox_off_rt(lay, A.G, a.i0, b.i1, c.i0),
+                   o011 = vox_off_rt(lay, A.G, a.i0, b.i1, c.i1), o100 = vox_off_rt(lay, A.G, a.i1, b.i0, c.i0), o101 = vox_off_rt(lay, A.G, a.i1, b.i0, c.i1),
+                   o110 = vox_off_rt(lay, A.G, a.i1, b.i1, c.i0), o111 = vox_off_rt(lay, A.G, a.i1, b.i1, c.i1);
+    const float v000 = A.vol[o000], v001 = A.vol[o001], v010 = A.vol[o010], v011 = A.vol[o011];
+    const float v100 = A.vol[o100], v101 = A.vol[o101], v110 = A.vol[o110], v111 = A.vol[o111];
+    // tri_sample's sequence (= oracle/diffus_oracle.c orc_sample_trilinear): dim 2, dim 1, dim 0, a + t (b - a) as a separate multiply and add
+    const float e00 = v001 - v000, e01 = v011 - v010, e10 = v101 - v100, e11 = v111 - v110;
+    const float c00 = __fadd_rn(v000, __fmul_rn(c.t, e00)), c01 = __fadd_rn(v010, __fmul_rn(c.t, e01));
+    const float c10 = __fadd_rn(v100, __fmul_rn(c.t, e10)), c11 = __fadd_rn(v110, __fmul_rn(c.t, e11));
+    const float f0 = c01 - c00, f1 = c11 - c10;
+    const float q0 = __fadd_rn(c00, __fmul_rn(b.t, f0)), q1 = __fadd_rn(c10, __fmul_rn(b.t, f1));
+    return __fadd_rn(q0, __fmul_rn(a.t, q1 - q0));
+}
+template <int SAMPLER>
+__device__ __forceinline__ void repair_ray_f64(const Args &A, long pose, long w, float *zbuf)
+{
+    constexpr int C = DIFFUS_MAX_SAMPLES / kWave; // 16 samples per lane cover every ray of one launch
+    const int lane = threadIdx.x & 63;
+    const int N1 = A.N1, n0 = lane * C;
+    Pose ps;
+    load_pose(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    const float medv = (A.start > 0) ? A.med[pose] : 0.f;
+    // samples, INTERLEAVED (n = i 64 + lane), four in flight
+#pragma unroll 4
+    for (int i = 0; i < C; ++i) {
+        const int n = i * kWave + lane; // (past the end of the ray: any point is clamped into the volume; masked by coeff)
+        zbuf[n] = sample_rt<SAMPLER>(A, ps, A.start + n);
+    }
+    wave_lds_sync();
+    auto coeff = [&](int n, double zp, double zc) -> double { // r entering sample n (reference :33, :243-244)
+        const double den = zp + zc;
+        double x = __builtin_amdgcn_rcp(den); // + two Newton steps: to the last bits of a double
+        x = x * __builtin_fma(-den, x, 2.0);
+        x = x * __builtin_fma(-den, x, 2.0);
+        double v = (zc - zp) * x;
+        if (n == 1 && A.start > 0) v = (double)medv;
+        return (n >= 1 && n < N1) ? v : 0.0;
+    };
+    DMat L{1.0, 0.0, 0.0, 1.0};
+    {
+        double zp = (double)zbuf[max(n0 - 1, 0)];
+#pragma unroll 1
+        for (int j = 0; j < C; ++j) {
+            const double zc = (double)zbuf[n0 + j];
+            L = dmat_step(L, coeff(n0 + j, zp, zc));
+            zp = zc;
+            if ((j & 3) == 3) dmat_renorm(L);
+        }
+    }
+#define DIFFUS_ROUND(CTRL, RMASK, HAS, RN)             \
+    {                                                  \
+        const DMat o = dmat_dpp_ident<CTRL, RMASK>(L); \
+        L = dmat_mul(o, L);                            \
+        if (RN) dmat_renorm(L);                        \
+    }
+    DIFFUS_SCAN_UP_ROUNDS(lane, DIFFUS_ROUND)
+#undef DIFFUS_ROUND
+    DMat Pm{dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.a), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.b), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.c),
+            dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.d)}; // exclusive prefix; lane 0: identity
+    float ssq = 0.f;
+    float *const frow = A.frame + w * N1;
+    const float *const trow = A.target ? A.target + w * N1 : nullptr;
+    double zp = (double)zbuf[max(n0 - 1, 0)];
+#pragma unroll 1
+    for (int j = 0; j < C; ++j) {
+        const int n = n0 + j;
+        const double zc = (double)zbuf[n];
+        Pm = dmat_step(Pm, coeff(n, zp, zc));
+        zp = zc;
+        if ((j & 3) == 3) dmat_renorm(Pm);
+        float e = fast_div((float)Pm.b, (float)Pm.d); // b and d are accurate now; their quotient needs no more than float32
+        e = (e == e) ? e : 0.f;                       // nan_to_num (reference :408)
+        if (n < N1) {
+            const float fr = __fmul_rn(e, fast_exp2(A.neg_alpha_l2e * (float)n)); // the scan kernels' attenuation
+            const float dlt = fr - (trow ? trow[n] : 0.f);
+            ssq = __builtin_fmaf(dlt, dlt, ssq);
+            frow[n] = fr;
+        }
+    }
+    ssq = wave_sum_to_lane63(ssq);
+    if (lane == kWave - 1) {
+        A.loss_part[w * 2] = A.loss_scale * ssq;
+        A.loss_part[w * 2 + 1] = 0.f;
+    }
+    wave_lds_sync(); // zbuf may be refilled by this wave's next ray
+}
+
 // What is left of a pose's backward once every ray's adjoint scan has run (one block per pose; the first blocks of the
 // scatter launch, or pose_finish_kernel when there is no scatter):
 //   * start > 0: the first kept reflection coefficient of every ray was replaced by the per-pose median (reference
@@ -1190,14 +1452,37 @@ __device__ __forceinline__ void for_each_corner(const Cell &c, float zb, F &&f)
 //     nothing is sampled again: d r / d Z -> volume gradient (8 corner atomics per sample), d/d source and d/d direction
 //     of that ray;
 //   * d/d source[pose] = fixed-order sum over rays of the per-ray partials (+ the median ray's extra term).
-// GLAYOUT is the GRADIENT layout.  sm: 3*kBlock floats.
-template <int SAMPLER, int GLAYOUT>
+// GLAYOUT is the GRADIENT layout.  sm: 3 * kBlock floats; REPAIR: (blockDim.x / 64) * DIFFUS_MAX_SAMPLES (a row of samples per wave).
+template <int SAMPLER, int GLAYOUT, bool REPAIR>
 __device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float *sm)
 {
     // every sum of the epilogue at once: d/dsource partials (3), loss partials, the median's gradient shares; all loads
     // are issued before the one barrier
     float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+    if (REPAIR && A.rflag && A.frame && A.loss_part) { // one-pass step on request (pose_finish_kernel only): the ill-conditioned rays of this pose (rare), dealt out to the block's waves
+        const int lane = tid & 63, wib = tid >> 6, nw = nt >> 6;
+        int seen = 0;
+        for (int base = 0; base < A.R; base += kWave) { // (block-uniform trip count; the ballots below are wave-uniform)
+            const int i = base + lane;
+            int f = 0;
+            if (i < A.R) {
+                const int *rf = A.rflag + ((long)pose * A.R + i) * 2;
+                f = rf[0] | rf[1];
+            }
+            unsigned long long m = __builtin_amdgcn_ballot_w64(f != 0);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                if (seen++ % nw == wib) {
+                    const long wr = (long)pose * A.R + base + b;
+                    float *zbuf = sm + wib * DIFFUS_MAX_SAMPLES;
+                    repair_ray_f64<SAMPLER>(A, pose, wr, zbuf);
+                }
+            }
+        }
+        __syncthreads(); // the repaired loss terms are read below by other waves of the block
+    }
     if (A.gsrc_out)
         for (int i = tid; i < A.R; i += nt) {
             const float *q = A.gsrc_part + ((long)pose * A.R + i) * 3;

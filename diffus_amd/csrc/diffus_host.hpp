@@ -54,6 +54,7 @@ struct Workspace {
     float *gmed;
     float *medinfo;
     float *loss_part; // (P,R,2) fused-loss partial sums
+    int *rflag;       // (P,R,2) one-pass step: ray (half) whose frame row pose_finish_block evaluates again in float64
     float *gsrc_part;
     float *zbar;
     float *carry;  // (nseg-1, P*R, 5) per-segment carry-in of long rays
@@ -73,6 +74,7 @@ Workspace carve(void *base, int P, int R, int N1)
     ws.gmed = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R);
     ws.medinfo = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * 8);
     ws.loss_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 2);
+    ws.rflag = (int *)(p + o); o += align256(sizeof(int) * (size_t)P * R * 2);
     ws.gsrc_part = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * 3);
     ws.zbar = (float *)(p + o); o += align256(sizeof(float) * (size_t)P * R * (N1 > 0 ? N1 : 0));
     ws.nseg = N1 > 0 ? (N1 + DIFFUS_MAX_SAMPLES - 1) / DIFFUS_MAX_SAMPLES : 1;

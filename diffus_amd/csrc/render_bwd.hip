@@ -41,7 +41,7 @@ __device__ unsigned long long *g_bwd_stamps = nullptr;
 #ifdef DIFFUS_COUNT_FAST_ONLY // static analysis only (tools/issue_model.py): the rare wave-uniform repair passes compiled out
 #define DIFFUS_RARE(cond) false
 #else
-#define DIFFUS_RARE(cond) (cond)
+#define DIFFUS_RARE(cond) __builtin_expect((cond), 0)
 #endif
 // Waves per SIMD the C = 8 kernels of a bricked / paired volume are compiled for.  4 = a 128-VGPR budget: the kernel is
 // VALU-issue-bound (its time is resident waves x issue cycles), sits at 126-138 registers depending on what the
@@ -309,6 +309,19 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     {
         const float poison = seeds_pass(std::false_type{}, Pm);
         if (DIFFUS_RARE(__builtin_amdgcn_ballot_w64(poison != 0.f) != 0ull)) seeds_pass(std::true_type{}, Pin[0]); // wave-uniform; Pin[0] = the prefix the first pass started from
+    }
+    // One-pass step with DIFFUS_BWD_REPAIR_FRAME: a ray with |echo| > kEchoRecheck somewhere is ILL-CONDITIONED (9 rays of 8192 at
+    // config 3) and its frame row is evaluated again in float64 by the per-pose epilogue (repair_ray_f64, diffus_device.hpp).
+    // Not here: a wave that did it in place was this kernel's tail (+11 us for nine such waves); all that is left is a flag.
+    if (A.rflag) { // (kernel argument: uniform over the grid; off by default)
+        float emax = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) emax = fmaxf(emax, fabsf(rho[j])); // rho: the echoes, NaN -> 0
+        const bool illc = A.mse == 2 && __builtin_amdgcn_ballot_w64(emax > kEchoRecheck) != 0ull; // wave-uniform
+        if (lane == 0) {
+            A.rflag[w * 2 + part] = illc ? 1 : 0;
+            if (SPLIT == 1) A.rflag[w * 2 + 1] = 0; // (the second slot belongs to the second wave of a SPLIT ray)
+        }
     }
 
     if (A.mse == 2) {
@@ -606,8 +619,8 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
 template <int SAMPLER, int GLAYOUT>
 __global__ __launch_bounds__(kBlock) void pose_finish_kernel(Args A)
 {
-    __shared__ float sm[3 * kBlock];
-    pose_finish_block<SAMPLER, GLAYOUT>(A, blockIdx.x, sm);
+    __shared__ float sm[kWavesPerBlock * DIFFUS_MAX_SAMPLES];
+    pose_finish_block<SAMPLER, GLAYOUT, true>(A, blockIdx.x, sm);
 }
 
 template <int SM, int LY, bool GPOSE, int PM>
@@ -673,6 +686,8 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
 {
     const bool grad_bricked = (layout & DIFFUS_GRAD_BRICKED) != 0; // the gradient's layout, decoupled from the volume's
     const bool fans_planar = (layout & DIFFUS_FANS_PLANAR) != 0;   // a hint for the scatter launch (include/diffus_hip.h)
+    const bool repair = (stages & DIFFUS_BWD_REPAIR_FRAME) != 0;   // one-pass step: float64 frame rows for ill-conditioned rays
+    stages &= ~DIFFUS_BWD_REPAIR_FRAME;
     layout &= ~(DIFFUS_GRAD_BRICKED | DIFFUS_FANS_PLANAR);
     const int glayout = (layout == DIFFUS_PAIRED || grad_bricked) ? DIFFUS_BRICKED : layout;
     int rc = check_common(vol, d0, d1, d2, src, src_dtype, dirs, dirs_dtype, P, R, S, start, sampler, layout, true);
@@ -694,6 +709,8 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
     A.gframe = gframe;
     A.mse = mse;
     A.fans_planar = fans_planar;
+    A.vol_layout = layout;
+    A.rflag = (mse == 2 && ws.nseg == 1 && repair) ? ws.rflag : nullptr; // one-pass step, rays of one launch, on request: ill-conditioned rays are repaired in float64
     A.frame = (mse == 2) ? frame_out : nullptr;
     A.target = target;
     A.loss_scale = loss_scale;
@@ -746,9 +763,11 @@ int render_bwd_impl(const float *vol, int d0, int d1, int d2, int layout, const 
     // Per-pose epilogue (pose_finish_block): the median's gradient goes to the ray that supplied it (start > 0) and the
     // per-ray d/dsource partials are summed.  It rides along as P extra blocks of the scatter launch when that launch
     // follows in this call, else it is one launch of its own.
-    const bool finish = do_scan && (start > 0 || (pose && gsrc) || A.loss_out);
+    const bool finish = do_scan && (start > 0 || (pose && gsrc) || A.loss_out || A.rflag);
     A.gsrc_out = (pose && gsrc) ? gsrc : nullptr;
-    A.finish_in_scatter = finish && gvol && do_scatter;
+    // (with the float64 repair the epilogue is a launch of its own: inside the scatter kernel the repair's code and scalar registers
+    // cost the patch path 1.4 us -- measured: SGPR spills and 20 more instructions in its prologue --, whether a ray needs them or not)
+    A.finish_in_scatter = finish && gvol && do_scatter && !A.rflag;
     if (gvol && do_scatter) {
         rc = diffus::launch_scatter(A, sampler, glayout, st);
         if (rc) return rc;

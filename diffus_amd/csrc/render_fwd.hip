@@ -93,6 +93,9 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
         echo_chunk<C, true>(r, lane, e, nullptr, -1, nullptr, exchange);
     } else {
         echo_chunk<C, true>(r, lane, e, cin ? &K : nullptr, segN - 1, cout ? &Klast : nullptr);
+        // an ill-conditioned ray (wave-uniform, rare): the same scan in float64 (diffus_device.hpp).  Rays of one launch only
+        // (SEG / SPLIT rays would need their carries in float64 as well: they keep the float32 series)
+        if (!SEG && __builtin_expect(echo_needs_f64<C>(e), 0)) echo_f64_rare<C, SAMPLER, LAYOUT, PM>(A, ps, seg0, segN, n0, medv, e);
     }
 #endif
     if (cout) { // hand the running product and the last impedance sample to the next segment
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
         Mat Kl = K;
         echo_chunk<C>(r, lane, e, base ? &K : nullptr, kWave * C - 1, &Kl);
         K = mat_lane_bcast(Kl, kWave - 1);
+        if (N < kWave * C && __builtin_expect(echo_needs_f64<C>(e), 0)) echo_chunk_f64<C>(r, lane, e); // rows of one piece; diffus_device.hpp (a stage-wise kernel: inlined)
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = n0 + j;

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(kSB, SLAB ? 4 : DIFFUS_SC_MIN_BLOCKS) void scatter_
     // step group off blockIdx.y instead of dividing a linear index (uniform integer divisions are ~20 instructions each,
     // and every instruction of this kernel costs the same: fact 23).
     if (has_finish && blockIdx.y == 0) {
-        if (blockIdx.x < (unsigned)A.P) pose_finish_block<SAMPLER, LAYOUT>(A, (int)blockIdx.x, reinterpret_cast<float *>(tile));
+        if (blockIdx.x < (unsigned)A.P) pose_finish_block<SAMPLER, LAYOUT, false>(A, (int)blockIdx.x, reinterpret_cast<float *>(tile));
         return;
     }
     // block -> (row, pose, ray group) with the row SLOWEST, and the row -> step group mapping of decode() below: the blocks

@@ -209,6 +209,15 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
 #define DIFFUS_BWD_SCATTER 2
 #define DIFFUS_BWD_ALL     3
 #define DIFFUS_BWD_KEEP_MEDIAN 4
+#define DIFFUS_BWD_REPAIR_FRAME 8 /* diffus_render_step_mse only, OR'ed into `stages`: rays whose echo series is ILL-CONDITIONED
+                                     (|echo| > 8 somewhere: a ray grazing the skull, echo = b/d with d nearly cancelled -- 9 rays of
+                                     8192 at BASELINE config 3) get their frame row and loss term evaluated again in float64, from
+                                     float32 samples taken with the reference's own lerp sequence (reference src/renderer.py:33,
+                                     :407-457; golden G19).  Every float32 evaluation -- the reference's dense LU included -- carries
+                                     (condition number) x eps of noise there; diffus_render_fwd and diffus_echo_traces do this repair
+                                     inside their kernels.  Here it costs a launch of the per-pose epilogue after the scatter
+                                     (~10 us per step), so it is opt-in: the one-pass step's frame is a by-product of a training
+                                     step, and the gradients carry the same condition number whatever the arithmetic */
 int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout,
                       const void *src, int src_dtype,
                       const void *dirs, int dirs_dtype,

@@ -79,7 +79,7 @@ def test_conditioning_model_is_bracketed_by_the_references_noise(g19, vol256):
 
 
 @pytest.mark.gpu
-def test_hip_echo_kernel_within_three_times_the_references_noise_per_ray(g19):
+def test_hip_echo_kernel_within_1p5_times_the_references_noise_per_ray(g19):
     """diffus_echo_traces on the golden's float32 coefficients: the scan arithmetic alone, ray by ray (measured: 2.5x on
     the worst ray, below 2x on all but three rays of pose 18)"""
     import diffus_amd as da
@@ -87,13 +87,13 @@ def test_hip_echo_kernel_within_three_times_the_references_noise_per_ray(g19):
         r = torch.from_numpy(g19[f"r_{p}"]).cuda()
         e, _ = da.compute_echo_traces(r)
         err = _per_ray(e.cpu().numpy(), g19[f"echo64z_{p}"])
-        bound = _reference_bound(g19, p, k=3.0)
+        bound = _reference_bound(g19, p, k=1.5)
         assert np.all(err <= bound), (p, int(np.argmax(err / bound)), float((err / bound).max()))
         assert np.mean(err <= _reference_bound(g19, p, k=2.0)) >= 0.98
 
 
 @pytest.mark.gpu
-def test_hip_one_pass_frame_within_three_times_the_references_noise_per_ray(g19, vol256):
+def test_hip_frames_against_the_references_noise_per_ray(g19, vol256):
     """The fused kernel of the benchmark step on the ill-conditioned poses, every ray against the float64 pipeline.  It
     samples the volume itself (fused lerps, another rounding sequence than the oracle's samples the golden was made from):
     one input rounding's worth on top of the scan's own noise -- measured 2.3x the reference's noise on the worst ray."""
@@ -104,16 +104,26 @@ def test_hip_one_pass_frame_within_three_times_the_references_noise_per_ray(g19,
     step = da.CapturedStep(vol, torch.from_numpy(src[idx]).cuda(), torch.from_numpy(dirs[idx]).cuda(), S, ALPHA, "trilinear",
                            layout="paired")
     step.step()
+    fixed = da.CapturedStep(vol, torch.from_numpy(src[idx]).cuda(), torch.from_numpy(dirs[idx]).cuda(), S, ALPHA, "trilinear",
+                            layout="paired", repair_frames=True)
+    fixed.step()
     torch.cuda.synchronize()
     fwd = da.render_poses(vol, torch.from_numpy(src[idx]), torch.from_numpy(dirs[idx]), S, ALPHA, sampler="trilinear",
                           layout="paired").cpu().numpy()
     att = np.exp(-ALPHA * np.arange(S))
     for q, p in enumerate(POSES):
         want = g19[f"echo64z_{p}"] * att
-        bound = _reference_bound(g19, p, k=3.0)
-        for name, frame in (("one-pass", step.frame[q].cpu().numpy()), ("forward", fwd[q])):
+        # the forward kernel and the one-pass step with DIFFUS_BWD_REPAIR_FRAME: ill-conditioned rays in float64 -- 1.5 x the
+        # reference's float32 noise (measured 0.2 x on the worst ray); the default one-pass step (float32 scan, its frame a
+        # by-product of a training step): 3 x, as in rounds 3-4
+        for name, frame, k in (("one-pass", step.frame[q].cpu().numpy(), 3.0), ("one-pass + repair", fixed.frame[q].cpu().numpy(), 1.5),
+                               ("forward", fwd[q], 1.5)):
             err = _per_ray(frame, want)
+            bound = _reference_bound(g19, p, k=k)
             assert np.all(err <= bound), (name, p, int(np.argmax(err / bound)), float((err / bound).max()))
+        # the repaired step's loss is the repaired frame's (the epilogue replaces the ray's term), its gradients the default step's
+        assert abs(float(fixed.loss[q]) - float((fixed.frame[q].double() ** 2).sum())) <= 1e-5 * float(fixed.loss[q])
+        assert torch.equal(fixed.gsrc, step.gsrc) and torch.equal(fixed.gdirs, step.gdirs)
 
 
 @pytest.mark.gpu
