@@ -706,17 +706,37 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Bank swizzle of that buffer.  A lane's chunk is C floats = F = C / 4 sixteen-byte words at a stride of 4 C bytes: the lanes
+// l and l + 64 / C of a 16-lane pass of ds_read_b128 / ds_write_b128 sit on the same banks -- F-way conflicts (PMC, round 4:
+// 62 % of the adjoint scan's LDS cycles).  So lane l keeps its word k at slot k ^ s(l), s(l) = (l / (64 / C)) mod F: the F
+// aliasing lanes of a pass then use F different bank groups.  Seen from the INTERLEAVED side (sample n = j 64 + lane, owner
+// lane n / C) the owner's s is (n / 64) mod F = j mod F -- a compile-time constant per access: the float at n lives at
+// n ^ ((j mod F) << 2), a permutation inside an aligned group of 8 words (conflict-free like the natural order).
+template <int C>
+__device__ __forceinline__ int chunk_word(int lane, int k) // index (in floats) of word k of lane's chunk
+{
+    constexpr int F = C / 4;
+    if constexpr (F <= 1) return lane * C + 4 * k;
+    return lane * C + 4 * (k ^ ((lane / (kWave / C)) & (F - 1)));
+}
+template <int C>
+__device__ __forceinline__ int inter_index(int lane, int j) // index (in floats) of sample j * 64 + lane
+{
+    constexpr int F = C / 4;
+    if constexpr (F <= 1) return j * kWave + lane;
+    return (j * kWave + lane) ^ ((j & (F - 1)) << 2);
+}
+
 template <int C>
 __device__ __forceinline__ void to_chunked(float *wb, int lane, const float (&in)[C], float (&out)[C])
 {
 #pragma unroll
-    for (int j = 0; j < C; ++j) wb[j * kWave + lane] = in[j];
+    for (int j = 0; j < C; ++j) wb[inter_index<C>(lane, j)] = in[j];
     wave_lds_sync();
     if (C >= 4) {
-        const float4 *q = reinterpret_cast<const float4 *>(wb + lane * C);
 #pragma unroll
         for (int j = 0; j < C / 4; ++j) {
-            float4 v = q[j];
+            float4 v = *reinterpret_cast<const float4 *>(wb + chunk_word<C>(lane, j));
             out[4 * j] = v.x; out[4 * j + 1] = v.y; out[4 * j + 2] = v.z; out[4 * j + 3] = v.w;
         }
     } else {
@@ -730,16 +750,16 @@ template <int C>
 __device__ __forceinline__ void to_interleaved(float *wb, int lane, const float (&in)[C], float (&out)[C])
 {
     if (C >= 4) {
-        float4 *q = reinterpret_cast<float4 *>(wb + lane * C);
 #pragma unroll
-        for (int j = 0; j < C / 4; ++j) q[j] = make_float4(in[4 * j], in[4 * j + 1], in[4 * j + 2], in[4 * j + 3]);
+        for (int j = 0; j < C / 4; ++j)
+            *reinterpret_cast<float4 *>(wb + chunk_word<C>(lane, j)) = make_float4(in[4 * j], in[4 * j + 1], in[4 * j + 2], in[4 * j + 3]);
     } else {
 #pragma unroll
         for (int j = 0; j < C; ++j) wb[lane * C + j] = in[j];
     }
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < C; ++j) out[j] = wb[j * kWave + lane];
+    for (int j = 0; j < C; ++j) out[j] = wb[inter_index<C>(lane, j)];
     wave_lds_sync();
 }
 

@@ -134,9 +134,10 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         if (KEEP_GRAD) {
 #pragma unroll
             for (int j = 0; j < C; ++j) {
-                gst[(0 * C + j) * kWave + lane] = gi0[j];
-                gst[(1 * C + j) * kWave + lane] = gi1[j];
-                gst[(2 * C + j) * kWave + lane] = gi2[j];
+                const int at = inter_index<C>(lane, j); // (the bank swizzle of the transpose buffer: diffus_device.hpp)
+                gst[0 * C * kWave + at] = gi0[j];
+                gst[1 * C * kWave + at] = gi1[j];
+                gst[2 * C * kWave + at] = gi2[j];
             }
         }
     }
@@ -187,11 +188,14 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
         }
         float *pk = wb + 2 * n0;
         if constexpr (C >= 4) {
-            float4 *q = reinterpret_cast<float4 *>(pk);
+            // lane-private 16-byte slots, WORD-major (slot t of lane l at float4 index t 64 + l): consecutive lanes, consecutive
+            // words -- conflict-free where the lane-major order (a lane's 2 C floats contiguous: a 64-byte stride at C = 8) had
+            // four lanes of every 16-lane pass on the same banks
+            float4 *q = reinterpret_cast<float4 *>(wb) + lane;
 #pragma unroll
             for (int t = 0; t < C / 4; ++t) {
-                q[t] = make_float4(dzn[4 * t], dzn[4 * t + 1], dzn[4 * t + 2], dzn[4 * t + 3]);
-                q[C / 4 + t] = make_float4(dzp[4 * t], dzp[4 * t + 1], dzp[4 * t + 2], dzp[4 * t + 3]);
+                q[t * kWave] = make_float4(dzn[4 * t], dzn[4 * t + 1], dzn[4 * t + 2], dzn[4 * t + 3]);
+                q[(C / 4 + t) * kWave] = make_float4(dzp[4 * t], dzp[4 * t + 1], dzp[4 * t + 2], dzp[4 * t + 3]);
             }
         } else {
 #pragma unroll
@@ -461,10 +465,10 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
     {
         const float *pk = wb + 2 * n0;
         if constexpr (C >= 4) {
-            const float4 *q = reinterpret_cast<const float4 *>(pk);
+            const float4 *q = reinterpret_cast<const float4 *>(wb) + lane; // word-major slots, as written
 #pragma unroll
             for (int t = 0; t < C / 4; ++t) {
-                const float4 v = q[t], u = q[C / 4 + t];
+                const float4 v = q[t * kWave], u = q[(C / 4 + t) * kWave];
                 dzn[4 * t] = v.x; dzn[4 * t + 1] = v.y; dzn[4 * t + 2] = v.z; dzn[4 * t + 3] = v.w;
                 dzp[4 * t] = u.x; dzp[4 * t + 1] = u.y; dzp[4 * t + 2] = u.z; dzp[4 * t + 3] = u.w;
             }
@@ -540,10 +544,9 @@ __global__ __launch_bounds__(kWave *WPB, (SPLIT > 1 ? DIFFUS_SPLIT_MIN_WAVES : (
             wave_lds_sync();
             auto read_row = [&](int c, float (&q)[C]) { // a lane's C consecutive floats: 16-byte LDS reads
                 if constexpr (C >= 4) {
-                    const float4 *v4 = reinterpret_cast<const float4 *>(gst + c * C * kWave + n0);
 #pragma unroll
                     for (int t = 0; t < C / 4; ++t) {
-                        const float4 v = v4[t];
+                        const float4 v = *reinterpret_cast<const float4 *>(gst + c * C * kWave + chunk_word<C>(lane, t));
                         q[4 * t] = v.x; q[4 * t + 1] = v.y; q[4 * t + 2] = v.z; q[4 * t + 3] = v.w;
                     }
                 } else {

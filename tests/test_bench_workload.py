@@ -72,7 +72,14 @@ def test_config3_one_pass_step_values(oracle, vol256):
     d2 = torch.from_numpy(dirs).cuda().requires_grad_(True)
     f2 = da.render_poses(v2, s2, d2, S, ALPHA, sampler="trilinear", layout="paired")
     (f2 ** 2).sum().backward()
-    assert float((step.frame - f2.detach()).abs().max()) <= 2e-5 * float(f2.detach().abs().max())
+    # frames: the forward kernel evaluates ILL-CONDITIONED rays (|echo| > 8 somewhere: nine rays of this workload) again in
+    # float64, the one-pass step does not (DIFFUS_BWD_REPAIR_FRAME is opt-in): those rays differ by the float32 scan's noise
+    # there -- (condition number) x eps, 2.7e-4 of the batch's peak on pose 30 --, every other ray agrees to 2e-5
+    fmax = float(f2.detach().abs().max())
+    diff = (step.frame - f2.detach()).abs()
+    illc = f2.detach().abs().amax(dim=2) > 7.5
+    assert 1 <= int(illc.sum()) <= 16
+    assert float(diff[~illc].max()) <= 2e-5 * fmax and float(diff[illc].max()) <= 5e-4 * fmax
     assert float((step.gsrc - s2.grad).abs().max()) <= 1e-4 * float(s2.grad.abs().max())
     assert float((step.gdirs - d2.grad).abs().max()) <= 1e-4 * float(d2.grad.abs().max())
     assert float((step.gvol - v2.grad).abs().max()) <= 1e-4 * float(v2.grad.abs().max())
