@@ -82,8 +82,46 @@ def cone_us_to_mri_world(apex_us_vox, direction_vec_us_2d, US_affine, T1_affine)
     return apex_mri, _unit(heading[:2])
 
 
+def _nearest_voxel(idx_f):
+    return np.round(idx_f).astype(int)
+
+
+def mri_to_us_point(i_mri, j_mri, slice_idx, T1_vol, T1_affine, US_vol, US_affine):
+    """The ultrasound voxel that shows MRI voxel (i, j, slice): through world space with both affines, rounded to the nearest
+    index; returns (the ultrasound slice of constant third index through it, the index triple) -- reference
+    src/cone.py:21-39, same range check and message on the MRI indices."""
+    d0, d1, d2 = T1_vol.shape
+    if not (0 <= slice_idx < d2 and 0 <= i_mri < d0 and 0 <= j_mri < d1):
+        raise ValueError(f"T1 : indices are out of range (i={i_mri}, j={j_mri}, k={slice_idx})")
+    us_idx = _nearest_voxel(world_to_voxel(voxel_to_world(np.array([i_mri, j_mri, slice_idx]), T1_affine), US_affine))
+    return US_vol[:, :, us_idx[2]], us_idx
+
+
+def us_to_mri_point(i_us, j_us, slice_idx, US_vol, US_affine, T1_vol, T1_affine):
+    """The inverse map for an ultrasound voxel given as (slice, i, j) -- the ultrasound volume's FIRST index is the slice
+    here, as in the reference --: returns (the MRI slice of constant first index through the nearest MRI voxel, the index
+    triple).  Reference src/cone.py:41-59 (which does not range-check either)."""
+    mri_idx = _nearest_voxel(world_to_voxel(voxel_to_world(np.array([slice_idx, i_us, j_us]), US_affine), T1_affine))
+    return T1_vol[mri_idx[0], :, :], mri_idx
+
+
+def rotation_from_rotvec(rotvec: torch.Tensor) -> torch.Tensor:
+    """Rodrigues' formula, differentiable at 0: R = I + A K + B K^2 with K = [rotvec]x, A = sin t / t, B = (1 - cos t) / t^2,
+    both from their series below 1e-3 rad (so that R and its gradient are exact for the identity)."""
+    t2 = (rotvec * rotvec).sum()
+    small = t2 < 1e-6
+    t2s = torch.where(small, torch.ones_like(t2), t2)
+    t = torch.sqrt(t2s)
+    A = torch.where(small, 1.0 - t2 / 6.0, torch.sin(t) / t)
+    B = torch.where(small, 0.5 - t2 / 24.0, (1.0 - torch.cos(t)) / t2s)
+    x, y, z = rotvec[0], rotvec[1], rotvec[2]
+    o = torch.zeros_like(x)
+    K = torch.stack([torch.stack([o, -z, y]), torch.stack([z, o, -x]), torch.stack([-y, x, o])])
+    return torch.eye(3, dtype=rotvec.dtype, device=rotvec.device) + A * K + B * (K @ K)
+
+
 class FanPose(torch.nn.Module):
-    """Differentiable probe pose: (apex, median angle, opening angle) -> (source, directions).
+    """Differentiable probe pose: (apex, median angle, opening angle[, rotation vector]) -> (source, directions).
 
     The reference builds `source` / `directions` once with NumPy and cannot optimise them
     (SURVEY D3); the HIP backward produces d/d source and d/d directions, and this module carries
@@ -91,14 +129,22 @@ class FanPose(torch.nn.Module):
     opening, n_rays)) up to rounding.
     """
 
-    def __init__(self, apex, direction, opening_angle: float, n_rays: int, learn_opening: bool = False):
+    def __init__(self, apex, direction, opening_angle: float, n_rays: int, learn_opening: bool = False, rotvec=None):
         super().__init__()
         self.n_rays = int(n_rays)
         self.apex = torch.nn.Parameter(torch.as_tensor(apex, dtype=torch.float32).clone())
         self.median_angle = torch.nn.Parameter(torch.tensor(median_angle_of(direction), dtype=torch.float32))
         op = torch.tensor(float(opening_angle), dtype=torch.float32)
         self.opening_angle = torch.nn.Parameter(op) if learn_opening else op
+        # Six degrees of freedom: `rotvec` (axis x angle, radians; None = the reference's in-plane fan: apex + one angle)
+        # turns the whole fan about its apex -- directions = R(rotvec) . fan(median angle).  Its first two components tilt the
+        # fan's plane out of the slice (roll / pitch: what src/cone.py:242-258 cannot express, z = 0 there); the third is an
+        # in-plane turn like the median angle.  The HIP backward's d/d directions reaches it through R.
+        self.rotvec = None if rotvec is None else torch.nn.Parameter(torch.as_tensor(rotvec, dtype=torch.float32).clone())
 
     def forward(self):
         op = self.opening_angle.to(self.median_angle.device)
-        return self.apex, fan_directions_torch(self.median_angle, op, self.n_rays)
+        dirs = fan_directions_torch(self.median_angle, op, self.n_rays)
+        if self.rotvec is not None:
+            dirs = dirs @ rotation_from_rotvec(self.rotvec).T
+        return self.apex, dirs

@@ -472,6 +472,32 @@ def main():
         save("g18_echo_autograd", **out)
 
     # ---- G20: rasterize_fan (src/renderer.py:626-653; host-side SciPy griddata) on a small scattered fan ----------
+    # ---- G21: mri_to_us_point / us_to_mri_point of src/cone.py:21-59 (executed from the file via ast, like G12) -------
+    if want("g21"):
+        tree = ast.parse(open(os.path.join(REF, "src", "cone.py")).read())
+        names = ("voxel_to_world", "world_to_voxel", "mri_to_us_point", "us_to_mri_point")
+        fns = [n_ for n_ in tree.body if isinstance(n_, ast.FunctionDef) and n_.name in names]
+        ns = {"np": np, "torch": torch}
+        exec(compile(ast.Module(body=fns, type_ignores=[]), "cone.py", "exec"), ns)
+        rng = np.random.default_rng(21)
+        def aff(scale, shift):
+            A = np.eye(4); q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            # a mild rotation about the identity, so that points stay inside both volumes
+            R = np.eye(3) + 0.05 * (q - q.T); A[:3, :3] = R * scale; A[:3, 3] = shift
+            return A
+        T1 = rng.normal(size=(24, 20, 16)).astype(np.float32); US = rng.normal(size=(30, 26, 22)).astype(np.float32)
+        At, Au = aff(1.0, (-3.0, 2.0, 1.0)), aff(0.8, (-1.0, 0.5, -0.5))
+        out = {"T1": T1, "US": US, "At": At, "Au": Au}
+        pts = [(5, 7, 4), (12, 3, 9), (20, 15, 12)]
+        for j, (i, jj, k) in enumerate(pts):
+            sl, idx = ns["mri_to_us_point"](i, jj, k, T1, At, US, Au)
+            out[f"m2u{j}_in"] = np.array([i, jj, k]); out[f"m2u{j}_slice"] = sl; out[f"m2u{j}_idx"] = idx
+        for j, (i, jj, k) in enumerate([(6, 8, 10), (14, 12, 15), (3, 20, 5)]):
+            sl, idx = ns["us_to_mri_point"](i, jj, k, US, Au, T1, At)
+            out[f"u2m{j}_in"] = np.array([i, jj, k]); out[f"u2m{j}_slice"] = sl; out[f"u2m{j}_idx"] = idx
+        out["n"] = np.int64(3)
+        save("g21_point_maps", **out)
+
     if want("g20"):
         g = np.random.default_rng(20)
         ang = g.uniform(-0.5, 0.5, 60)

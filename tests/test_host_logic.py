@@ -85,6 +85,45 @@ def test_g12_pose_helpers_match_reference():
         diffus_amd.compute_us_apex_and_direction(1.0, 0.0, 1.0, 5.0)
 
 
+def test_g21_point_maps_match_reference():
+    """mri_to_us_point / us_to_mri_point (reference src/cone.py:21-59; eight notebooks incl. `[DEMO] REUBEN DATA 46` call
+    them): slices and index triples equal to the reference's on random volumes and affines, and its range check."""
+    import diffus_amd
+    from conftest import load_golden
+    g = load_golden("g21_point_maps")
+    T1, US, At, Au = g["T1"], g["US"], g["At"], g["Au"]
+    for j in range(int(g["n"])):
+        sl, idx = diffus_amd.mri_to_us_point(*[int(v) for v in g[f"m2u{j}_in"]], T1, At, US, Au)
+        np.testing.assert_array_equal(idx, g[f"m2u{j}_idx"]); np.testing.assert_array_equal(sl, g[f"m2u{j}_slice"])
+        sl, idx = diffus_amd.us_to_mri_point(*[int(v) for v in g[f"u2m{j}_in"]], US, Au, T1, At)
+        np.testing.assert_array_equal(idx, g[f"u2m{j}_idx"]); np.testing.assert_array_equal(sl, g[f"u2m{j}_slice"])
+    with pytest.raises(ValueError, match="T1 : indices are out of range"):
+        diffus_amd.mri_to_us_point(24, 0, 0, T1, At, US, Au)
+
+
+def test_fan_pose_six_degrees_of_freedom():
+    """FanPose(rotvec=...): directions = R(rotvec) . fan.  A zero rotation vector reproduces the in-plane fan exactly and has
+    a gradient; R is a rotation; tilting about the fan's central ray matches pose_ring(roll_deg=...)."""
+    import diffus_amd
+    from diffus_amd.phantom import pose_ring
+    flat = diffus_amd.FanPose((10.0, 20.0, 30.0), (0.6, 0.8), 0.9, 16)
+    six = diffus_amd.FanPose((10.0, 20.0, 30.0), (0.6, 0.8), 0.9, 16, rotvec=(0.0, 0.0, 0.0))
+    assert torch.equal(flat()[1], six()[1])
+    six()[1][:, 2].sum().backward()                       # d (dim-2 components) / d rotvec at the identity: not zero, not NaN
+    assert torch.isfinite(six.rotvec.grad).all() and float(six.rotvec.grad.abs().max()) > 0.1
+    Rm = diffus_amd.rotation_from_rotvec(torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64))
+    assert torch.allclose(Rm @ Rm.T, torch.eye(3, dtype=torch.float64), atol=1e-14) and abs(float(torch.linalg.det(Rm)) - 1) < 1e-14
+    # roll by 20 degrees about the central ray = rotation vector 20 deg x (unit central direction)
+    n, P, R = 64, 8, 16
+    src, dirs = pose_ring(n, P, R, roll_deg=20.0)
+    p = 3
+    phi = 2 * np.pi * p / P
+    look = np.array([-np.cos(phi), -np.sin(phi), 0.0])
+    fp = diffus_amd.FanPose(src[p], look[:2], np.radians(60.0), R, rotvec=np.radians(20.0) * look)
+    # (pose_ring turns `side` towards +dim 2: a right-handed turn about `look` by +20 degrees does the same)
+    assert torch.allclose(fp()[1], torch.from_numpy(dirs[p]), atol=1e-6)
+
+
 def test_fan_pose_module():
     import diffus_amd
     fp = diffus_amd.FanPose((88.0, -11.5, 110.0), (-0.3, -0.95), 0.85, 64, learn_opening=True)

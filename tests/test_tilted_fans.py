@@ -176,3 +176,44 @@ def test_slab_scatter_long_steps_every_chunking(da, sampler, step):
         (f * up.float().cuda()).sum().backward()
         assert maxnorm_rel(vol.grad.cpu().numpy(), gv_ref) < 1e-3, (layout, step)
         assert abs(float(vol.grad.double().sum()) - gv_ref.sum()) <= 1e-4 * np.abs(gv_ref).sum()
+
+
+def test_six_dof_pose_registration_by_gradient_descent(da):
+    """What `notebooks/[NW] alignement.ipynb` cells 13-14 attempt (and the reference cannot do: no pose gradient),
+    with all six degrees of freedom: a probe pose perturbed by a 5 degree tilt out of the slice (roll about the central ray
+    + pitch) and 3 voxels of apex offset is recovered by descending d loss / d (apex, median angle, rotation vector) through
+    the HIP backward -- d/d directions in 3-D, carried to the rotation vector by FanPose (which generalises
+    src/cone.py:187-209, :242-258: z = 0 there)."""
+    n, R, S, alpha = 64, 48, 96, 1e-3
+    u = np.arange(n, dtype=np.float64) / (n - 1)
+    smooth = 1.6e6 + 3e5 * np.sin(6 * u)[:, None, None] * np.cos(5 * u)[None, :, None] * np.sin(4 * u + 1)[None, None, :]
+    vol = torch.from_numpy(smooth.astype(np.float32)).cuda()
+    true = da.FanPose((20.0, 30.0, 31.3), (0.8, 0.6), 0.9, R, rotvec=(0.0, 0.0, 0.0)).cuda()
+    with torch.no_grad():
+        src, dirs = true()
+        target = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
+    look = np.array([0.8, 0.6, 0.0])
+    side = np.array([-0.6, 0.8, 0.0])
+    tilt = np.radians(4.0) * look + np.radians(3.0) * side             # 5 degrees in all, out of the slice both ways
+    pose = da.FanPose((21.8, 28.1, 32.8), (0.8, 0.6), 0.9, R, rotvec=tilt).cuda()   # |apex offset| = 3.0 voxels
+    assert abs(float(torch.linalg.norm(pose.apex.detach() - true.apex.detach())) - 3.0) < 0.1
+    opt = torch.optim.Adam([{"params": [pose.apex], "lr": 0.05}, {"params": [pose.median_angle, pose.rotvec], "lr": 0.004}])
+    losses = []
+    for _ in range(300):
+        opt.zero_grad()
+        src, dirs = pose()
+        f = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
+        loss = ((f - target) ** 2).sum()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    Rm = da.rotation_from_rotvec(pose.rotvec.detach().double().cpu())
+    # what is left of the rotation, median angle included: the angle between the recovered and the true central rays / planes
+    with torch.no_grad():
+        d_rec, d_true = pose()[1].double().cpu(), true()[1].double().cpu()
+    ang = torch.rad2deg(torch.acos(((d_rec * d_true).sum(1) / (d_rec.norm(dim=1) * d_true.norm(dim=1))).clamp(-1, 1))).max()
+    print("6-DoF registration: loss %.3g -> %.3g, apex error %.3f voxels, worst ray angle %.3f deg" % (
+        losses[0], losses[-1], float(torch.linalg.norm(pose.apex.detach() - true.apex.detach())), float(ang)), Rm.shape)
+    assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
+    assert torch.linalg.norm(pose.apex.detach() - true.apex.detach()) < 0.6
+    assert float(ang) < 1.0
