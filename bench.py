@@ -184,6 +184,53 @@ def visible_gpus(environ=None, kfd_nodes="/sys/class/kfd/kfd/topology/nodes"):
     return n
 
 
+def gpu_numa_cpus(local_rank, environ=None, kfd_nodes="/sys/class/kfd/kfd/topology/nodes", drm="/sys/class/drm",
+                  numa="/sys/devices/system/node"):
+    """The CPUs of the NUMA node the `local_rank`-th GPU hangs off, from sysfs alone (no HIP): KFD GPU nodes in node order ->
+    drm_render_minor -> renderD<minor>/device/numa_node -> node<k>/cpulist.  None when any link of that chain is missing, when
+    the node is unknown (-1), or when a *_VISIBLE_DEVICES variable reorders the devices (the rank -> node order then is not ours
+    to guess).  The per-step loss gather is HOST-bound (~50 us inside RCCL's enqueue): a rank that runs on the far socket pays
+    for it on every step."""
+    env = os.environ if environ is None else environ
+    if any(env.get(k) is not None for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        return None
+    try:
+        gpus = []
+        for node in sorted(os.listdir(kfd_nodes), key=lambda x: int(x)):
+            with open(os.path.join(kfd_nodes, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props["drm_render_minor"]))
+        with open(os.path.join(drm, "renderD%d" % gpus[local_rank], "device", "numa_node")) as fh:
+            k = int(fh.read().strip())
+        if k < 0:
+            return None
+        with open(os.path.join(numa, "node%d" % k, "cpulist")) as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        return cpus or None
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
+def pin_to_gpu_numa_node(local_rank) -> bool:
+    """Restrict this process to the CPUs of its GPU's NUMA node (never widening what it already may use).  Before torch starts
+    its threads."""
+    cpus = gpu_numa_cpus(local_rank)
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return False
+    try:
+        allowed = os.sched_getaffinity(0) & cpus
+        if len(allowed) < 2:
+            return False
+        os.sched_setaffinity(0, allowed)
+        return True
+    except OSError:
+        return False
+
+
 def launch_ranks(args) -> int:
     n = args.gpus
     if args.dist_backend == "nccl" and not args.dry_run:
@@ -533,6 +580,48 @@ def callers_legs(args, vol, dev):
                     "plane, csrc/scatter.hip); before round 5 these fans fell to the 3-D brick tile and per-sample global "
                     "atomics: 0.083 / 0.172 / 0.394 / 0.519 / 0.118 ms per step (profiles/r05_tilt_before.txt)")
     out["tilted_fan"] = tilt
+    # (f) a SHARED learnable volume on N ranks: what the gradient's collective moves per step (SURVEY §8e "Collective").  A
+    #     one-rank RCCL group on this GPU (the N = 8 job cannot be run here): the dense all_reduce of d/dvolume against
+    #     allreduce_box (the one slice the reference's training loop learns) and allreduce_touched (the bricks a step touched)
+    try:
+        import torch.distributed as dist
+        from diffus_amd.distributed import allreduce_box, allreduce_touched, allreduce_volume_grad
+        own_group = not dist.is_initialized()
+        if own_group:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+        st = CapturedStep(vol, sa, da, args.samples, args.alpha, args.sampler, layout=args.layout, learnable_volume="slice" if args.layout != "canonical" else True)
+        k = n // 2
+        box = ((0, n), (0, n), (k, k + 1))
+        scratch = torch.empty(n * n, dtype=torch.float32, device=dev)
+        moved = {}
+
+        def step_dense():
+            st.step(); allreduce_volume_grad(st.gvol)
+
+        def step_box():
+            st.step(); moved["box"] = allreduce_box(st.gvol, box, scratch=scratch)
+
+        def step_touched():
+            st._stamp += 1
+            st.zero_grad(); st.step_mse(_lib_mod.BWD_ALL)
+            moved["touched"] = allreduce_touched(st.gvol_k, st.touched)
+            st.finish_grad()
+
+        for f in (step_dense, step_box, step_touched):
+            for _ in range(3):
+                f()
+        shared = {"dense_all_reduce_ms_per_step": time_wall(step_dense, 30), "allreduce_box_one_slice_ms_per_step": time_wall(step_box, 30),
+                  "allreduce_touched_ms_per_step": time_wall(step_touched, 30), "step_alone_ms": time_wall(st.step, 30),
+                  "bytes_dense": int(st.gvol.numel() * 4), "bytes_box": int(moved["box"]), "bytes_touched": int(moved["touched"]),
+                  "note": "wall ms per step (eager one-pass step + the collective on a ONE-rank RCCL group: what the call costs this "
+                          "rank, not the xGMI transfer, which a one-rank group does not make); bytes = what goes through the "
+                          "collective per step.  allreduce_touched waits for the host once per step (the size of the union)"}
+        out["shared_volume_gradient"] = shared
+        del st
+        if own_group:
+            dist.destroy_process_group()
+    except Exception as e:
+        out["shared_volume_gradient"] = {"failed": repr(e)}
     out["moving_poses"] = {"ms_per_step": ms_move, "fixed_poses_ms_per_step": ms_fixed,
                            "note": "16 rings of poses, 0.013 rad apart, cycled: every step the persistent gradient tensor meets "
                                    "bricks the previous step wrote and this one does not (stale-brick clearing is exercised)"}
@@ -1185,6 +1274,7 @@ def worker(args):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": None if measured is None else measured / HBM_PEAK_GBS,
+                "frac_kind": "measured_hbm_traffic",   # counters over event time; the contract's model figure is `algorithmic.frac_of_peak`
                 "traffic": traffic,
                 "pmc_summary": pmc_file,
                 "algorithmic": {"GBs": achieved, "frac_of_peak": achieved / HBM_PEAK_GBS, "bytes_per_ray_step": b[dom],
@@ -1237,6 +1327,8 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.dry_run and args.dist_backend == "nccl":
+        pin_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")))      # (each rank, under our launcher or torch.distributed.run)
     worker(args)
 
 

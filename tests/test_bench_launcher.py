@@ -191,3 +191,26 @@ def test_two_ranks_on_the_gpu_box_strong_scaling_line():
     assert out["strong"]["one_gpu"]["poses_total"] == 256 and out["strong"]["speedup_vs_one_gpu"] > 0
     assert out["weak"]["poses_per_gpu"] == 32 and out["value"] > 0
     assert out["roofline"]["kernel"] in ("render_bwd_kernel", "scatter_patch_kernel") and out["roofline"]["algorithmic"]["GBs"] > 0
+
+
+def test_gpu_numa_cpus_from_sysfs(tmp_path):
+    """bench.gpu_numa_cpus: rank -> KFD GPU node -> render minor -> PCI device's NUMA node -> its CPU list, all from (a fake)
+    sysfs; None whenever the chain breaks or the devices are re-ordered by a *_VISIBLE_DEVICES variable."""
+    import bench
+    nodes, drm, numa = tmp_path / "nodes", tmp_path / "drm", tmp_path / "numa"
+    for i, (simd, minor) in enumerate([(0, -1), (0, -1), (256, 128), (256, 129), (256, 130)]):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    for minor, node in ((128, 0), (129, 1), (130, -1)):
+        (drm / f"renderD{minor}" / "device").mkdir(parents=True)
+        (drm / f"renderD{minor}" / "device" / "numa_node").write_text(f"{node}\n")
+    for k, cl in ((0, "0-3,16-19"), (1, "4-7,20")):
+        (numa / f"node{k}").mkdir(parents=True)
+        (numa / f"node{k}" / "cpulist").write_text(cl + "\n")
+    kw = dict(kfd_nodes=str(nodes), drm=str(drm), numa=str(numa))
+    assert bench.gpu_numa_cpus(0, {}, **kw) == {0, 1, 2, 3, 16, 17, 18, 19}
+    assert bench.gpu_numa_cpus(1, {}, **kw) == {4, 5, 6, 7, 20}
+    assert bench.gpu_numa_cpus(2, {}, **kw) is None                     # numa_node -1
+    assert bench.gpu_numa_cpus(3, {}, **kw) is None                     # no such GPU
+    assert bench.gpu_numa_cpus(0, {"HIP_VISIBLE_DEVICES": "1,0"}, **kw) is None
+    assert bench.gpu_numa_cpus(0, {}, kfd_nodes=str(tmp_path / "missing"), drm=str(drm), numa=str(numa)) is None

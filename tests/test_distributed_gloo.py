@@ -89,3 +89,51 @@ def test_two_ranks_even_split(tmp_path):
 
 def test_two_ranks_ragged_split(tmp_path):
     _run(3, tmp_path)
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffus_amd.distributed import allreduce_box, allreduce_touched, allreduce_volume_grad
+    g = torch.Generator().manual_seed(100 + rank)
+    # (a) one slice of a canonical gradient
+    shape = (12, 10, 8)
+    gv = torch.randn(shape, generator=g)
+    dense = gv.clone()
+    box = ((0, 12), (0, 10), (3, 4))
+    moved_box = allreduce_box(gv, box)
+    allreduce_volume_grad(dense)
+    # (b) the bricked scratch + touched flags of a scatter: each rank touches its own random third of 60 bricks
+    nb = 60
+    touched = (torch.rand(nb, generator=g) < 0.33).to(torch.int32)
+    touched[7] = 2 if rank == 0 else 0                          # a flag 2 ("stale", left by a PERSISTENT flush) is not live scratch
+    bricks = torch.randn(nb, 32, generator=g) * (touched == 1).unsqueeze(1)
+    want = bricks.clone()
+    allreduce_volume_grad(want)
+    t_before = touched.clone()
+    moved_t = allreduce_touched(bricks.view(-1), touched)
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), gv=gv.numpy(), dense=dense.numpy(), own=torch.randn(shape, generator=torch.Generator().manual_seed(100 + rank)).numpy(),
+             bricks=bricks.numpy(), want=want.numpy(), touched=touched.numpy(), t_before=t_before.numpy(), moved_box=moved_box, moved_t=moved_t)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_allreduce_of_a_shared_volume_gradient(tmp_path):
+    """allreduce_box / allreduce_touched against the dense all_reduce of the whole tensor (world 2, gloo): same sums where a
+    step can have written, nothing else touched, a fraction of the bytes (SURVEY §8e "Collective"; the reference's training
+    loop learns one slice: `[DEMO] Train MRI to Impedance MLP - GPU` cell 16)."""
+    world, port = 2, _free_port()
+    mp.spawn(_sparse_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(tmp_path, f"s{r}.npz")) for r in range(world)]
+    union = (outs[0]["t_before"] != 0) | (outs[1]["t_before"] != 0)
+    for r, o in enumerate(outs):
+        np.testing.assert_allclose(o["gv"][:, :, 3], o["dense"][:, :, 3], rtol=1e-6)        # the slice: summed over the ranks
+        rest = np.ones(o["gv"].shape, bool); rest[:, :, 3] = False
+        assert np.array_equal(o["gv"][rest], o["own"][rest])                                 # everything else: this rank's own values
+        assert int(o["moved_box"]) == 12 * 10 * 4
+        np.testing.assert_allclose(o["bricks"], o["want"], rtol=1e-6, atol=1e-7)             # bricked scratch: the dense sum
+        assert np.array_equal(o["touched"] != 0, union)                                     # every rank flushes the union
+        assert np.all(o["touched"][(o["t_before"] == 0) & union] == 1)
+        assert int(o["moved_t"]) == 60 + int(union.sum()) * 32 * 4 < 60 * 32 * 4
