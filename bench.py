@@ -725,14 +725,34 @@ class RawNccl:
         _fields_ = [("internal", C.c_char * 128)]
 
     def __init__(self, torch, dist, rank, world):
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self.lib = lib = C.CDLL(path)
-        lib.ncclGetErrorString.restype = C.c_char_p
-        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, RawNccl._Uid, C.c_int]
-        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
-        uid = RawNccl._Uid()
-        if rank == 0:
-            self._check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        # Everything that can fail on ONE rank alone (the library's path, dlopen, a missing symbol, ncclGetUniqueId) happens
+        # first and its outcome is agreed on by all ranks; only then do they enter the collectives below.  (a rank
+        # that failed here used to fall back to torch.distributed by itself while its peers waited in the broadcast.)
+        err, lib, uid = None, None, RawNccl._Uid()
+        try:
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            self.lib = lib = C.CDLL(path)
+            lib.ncclGetErrorString.restype = C.c_char_p
+            lib.ncclGetErrorString.argtypes = [C.c_int]
+            lib.ncclGetUniqueId.restype = C.c_int
+            lib.ncclGetUniqueId.argtypes = [C.POINTER(RawNccl._Uid)]
+            lib.ncclCommInitRank.restype = C.c_int
+            lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, RawNccl._Uid, C.c_int]
+            lib.ncclAllGather.restype = C.c_int
+            lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            lib.ncclCommDestroy.restype = C.c_int
+            lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            if rank == 0:
+                self._check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        except Exception as e:      # noqa: BLE001 -- reported below, on every rank
+            err = e
+        if world > 1:
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0:
+                raise RuntimeError(f"raw RCCL communicator unavailable on some rank (this rank: {err!r}); all ranks fall back together")
+        elif err is not None:
+            raise err
         box = [C.string_at(C.byref(uid), 128) if rank == 0 else None]     # (uid.internal would stop at the first NUL byte)
         if world > 1:
             dist.broadcast_object_list(box, src=0)

@@ -44,6 +44,7 @@ ws = pb.workspace()
 gb = R._gradbuf(pb.dev, pb.shape)
 gsrc = torch.empty((P, 3), device="cuda"); gd = torch.empty((P, 256, 3), device="cuda")
 dense = torch.empty(pb.shape, device="cuda")
+vd, sd_, dd_ = vol.detach(), s.detach(), d.detach()    # (the same objects every call: the converted-volume cache is keyed by identity)
 rows = [
     ("_Problem()", lambda: R._Problem(vol, s, d, 512, 0, 1e-4, "trilinear", "auto")),
     ("torch.empty(frame)", lambda: torch.empty((pb.P, pb.R, pb.N1), dtype=torch.float32, device=pb.dev)),
@@ -51,7 +52,7 @@ rows = [
     ("ctypes diffus_render_fwd", lambda: lib.diffus_render_fwd(*pb.common(), R._ptr(frame), None, R._ptr(ws), ws.numel(), R._stream(pb.dev))),
     ("ctypes diffus_render_bwd", lambda: lib.diffus_render_bwd(*pb.common(), R._ptr(frame), R._ptr(gb[0]), R._ptr(gb[1]), R._ptr(gsrc), R._ptr(gd), 3, R._ptr(ws), ws.numel(), R._stream(pb.dev))),
     ("ctypes gradbuf_flush DENSE", lambda: lib.diffus_gradbuf_flush(R._ptr(gb[0]), R._ptr(gb[1]), *pb.shape, R._ptr(dense), 3, R._stream(pb.dev))),
-    ("render_poses no_grad", lambda: da.render_poses(vol.detach(), s.detach(), d.detach(), 512, 1e-4, sampler="trilinear")),
+    ("render_poses no_grad", lambda: da.render_poses(vd, sd_, dd_, 512, 1e-4, sampler="trilinear")),
     ("render_poses (autograd node)", lambda: da.render_poses(vol, s, d, 512, 1e-4, sampler="trilinear")),
 ]
 for name, fn in rows:
