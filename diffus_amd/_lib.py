@@ -23,7 +23,7 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
            "diffus_echo_bwd_workspace_bytes", "diffus_echo_traces_bwd", "diffus_splat_axes", "diffus_rotate_around_apex",
            "diffus_ssim_workspace_bytes", "diffus_ssim_loss_fwd", "diffus_ssim_loss_bwd")
 
-ABI_VERSION = 6          # include/diffus_hip.h DIFFUS_ABI_VERSION
+ABI_VERSION = 7          # include/diffus_hip.h DIFFUS_ABI_VERSION
 DIFFUS_F32, DIFFUS_F64, DIFFUS_I64 = 0, 1, 2
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2

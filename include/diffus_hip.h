@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DIFFUS_ABI_VERSION 6 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd; 5: winner raster kept between diffus_splat_fwd / _bwd; 6: diffus_convert_volume_box */
+#define DIFFUS_ABI_VERSION 7 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd; 5: winner raster kept between diffus_splat_fwd / _bwd; 6: diffus_convert_volume_box; 7: DIFFUS_FANS_PLANAR / DIFFUS_BWD_REPAIR_FRAME flag bits, a per-ray flag array in the workspace (diffus_workspace_bytes grows) */
 
 /* error codes */
 #define DIFFUS_OK            0
