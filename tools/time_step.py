@@ -16,7 +16,10 @@ from diffus_amd.phantom import phantom, pose_ring  # noqa: E402
 
 N = int(os.environ.get("N", "256")); RAYS = int(os.environ.get("RAYS", "256")); SAMPLES = int(os.environ.get("SAMPLES", "512"))
 P = int(os.environ.get("POSES", "32")); IT = int(os.environ.get("ITERS", "300"))
-vol = torch.from_numpy(phantom(N)).cuda()
+vol_np = phantom(N)
+if os.environ.get("ZERO_BG"):       # a masked volume -- zero background, Z_{n-1} + Z_n == 0 along every ray outside the head
+    vol_np[vol_np == 400.0] = 0.0
+vol = torch.from_numpy(vol_np).cuda()
 src, dirs = pose_ring(N, P, RAYS, roll_deg=float(os.environ.get("ROLL", "0")), pitch_deg=float(os.environ.get("PITCH", "0")))
 hp = CapturedStep(vol, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), SAMPLES, 1e-4, "trilinear",
                   layout=os.environ.get("LAYOUT", "paired"))
