@@ -109,6 +109,24 @@ def test_echo_adversarial_growth(da, oracle, n):
     assert maxnorm_rel(e, ref) < 1e-4
 
 
+def test_echo_extreme_coefficients(da, oracle):
+    """what the scans' power-of-two renormalisation (mat_renorm: the scale from the exponent field) does at the ends
+    of its range.  A product that is exactly the zero matrix (r = -1 twice: M(-1)^2 = 0; echo 0/0 -> 0 like the reference's
+    nan_to_num, :408) and coefficients of 1e18 (1 - 2 r^2 = -2e36: entries near the top of float32 between rescales) follow the
+    float64 series; so do negative-impedance interfaces (|r| of a few 1e9).  (Above |r| ~ 6e18 a matrix entry reaches 2^126
+    between two rescales and the scale 2^(127 - e) leaves the normal range: out of reach for impedances -- it needs Z1 + Z2 to
+    cancel to 1e-19 of their size -- and a factor 2 below where float32 itself overflows, 1.3e19.)"""
+    cases = [np.array([[-1, -1, 0.3, 0.2, -0.5, 0.1]], np.float32),
+             np.array([[1e18, -1e18, 1e18, 0.5, -0.3, 0.2]], np.float32),
+             np.array([[3e9, 2e9, -4e9, 1e9, 0.5, -0.3, 0.2, 0.1]], np.float32)]
+    for r in cases:
+        e = da.compute_echo_traces(cuda(r))[0].cpu().numpy()
+        with np.errstate(all="ignore"):
+            ref = oracle.echo_scan(r.astype(np.float64), np.float64)
+        assert np.all(np.isfinite(e))
+        assert maxnorm_rel(e, ref) < 1e-5, r
+
+
 # ----------------------------------------------------------------------------- stage 1: sampling
 @pytest.mark.parametrize("layout", ["canonical", "bricked", "paired"])
 @pytest.mark.parametrize("sampler", ["nearest", "trilinear"])
