@@ -71,7 +71,13 @@ constexpr int kSB = DIFFUS_SCATTER_THREADS, kSW = kSB / kWave, kSPT = kScRays * 
 // Tile capacities in 32-bit entries.  kTileCap (24 KiB, 6 blocks per CU): the launch for fans the caller KNOWS to be planar
 // in dim 2 (DIFFUS_FANS_PLANAR) and for canonical gradients.  kSlabCap (36 KiB, 4 blocks per CU): the launch that also
 // carries the slab path below for fans that leave the slice -- their tile holds several layers per column.
-constexpr int kSlabCap = 9216;
+#ifndef DIFFUS_SLAB_CAP
+#define DIFFUS_SLAB_CAP 9216
+#endif
+#ifndef DIFFUS_SLAB_MIN_BLOCKS
+#define DIFFUS_SLAB_MIN_BLOCKS 4
+#endif
+constexpr int kSlabCap = DIFFUS_SLAB_CAP;
 #ifndef DIFFUS_SC_ROW_PAD
 #define DIFFUS_SC_ROW_PAD 1
 #endif
@@ -873,7 +879,7 @@ __device__ __forceinline__ bool scatter_patch_slab(const Args &A, double *tile, 
 }
 
 template <int SAMPLER, int LAYOUT, int PM, bool SLAB = false>
-__global__ __launch_bounds__(kSB, SLAB ? 4 : DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int has_finish, int step_groups, int sg_mul)
+__global__ __launch_bounds__(kSB, SLAB ? DIFFUS_SLAB_MIN_BLOCKS : DIFFUS_SC_MIN_BLOCKS) void scatter_patch_kernel(Args A, int ray_groups, int has_finish, int step_groups, int sg_mul)
 {
     constexpr int CAP = SLAB ? kSlabCap : kTileCap; // tile entries (32-bit)
     static_assert(!SLAB || LAYOUT == DIFFUS_BRICKED, "the slab path scatters into a bricked gradient");

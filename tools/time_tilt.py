@@ -19,6 +19,8 @@ N = int(os.environ.get("N", "256")); RAYS = int(os.environ.get("RAYS", "256")); 
 P = int(os.environ.get("POSES", "32")); IT = int(os.environ.get("ITERS", "200"))
 CASES = [(0, 0, (0, 1)), (5, 0, (0, 1)), (20, 0, (0, 1)), (45, 0, (0, 1)), (0, 20, (0, 1)), (20, 10, (0, 1)), (0, 0, (0, 2)),
          (0, 0, (1, 2)), (20, 0, (0, 2))]
+if os.environ.get("QUICK"):      # CASES_ENV: a short list for A/B runs of library variants
+    CASES = [(0, 0, (0, 1)), (5, 0, (0, 1)), (20, 0, (0, 1)), (0, 20, (0, 1))]
 vol = torch.from_numpy(phantom(N)).cuda()
 for roll, pitch, plane in CASES:
     src, dirs = pose_ring(N, P, RAYS, roll_deg=roll, pitch_deg=pitch, plane=plane)
