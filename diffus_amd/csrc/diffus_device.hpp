@@ -1390,10 +1390,9 @@ __device__ __forceinline__ float sample_rt(const Args &A, const Pose &ps, int k)
     const float q0 = __fadd_rn(c00, __fmul_rn(b.t, f0)), q1 = __fadd_rn(c10, __fmul_rn(b.t, f1));
     return __fadd_rn(q0, __fmul_rn(a.t, q1 - q0));
 }
-template <int SAMPLER>
+template <int SAMPLER, int C> // C samples per lane: 64 C >= N1 (8 for rays of up to 512 samples: half the serial chain of 16)
 __device__ __forceinline__ void repair_ray_f64(const Args &A, long pose, long w, float *zbuf)
 {
-    constexpr int C = DIFFUS_MAX_SAMPLES / kWave; // 16 samples per lane cover every ray of one launch
     const int lane = threadIdx.x & 63;
     const int N1 = A.N1, n0 = lane * C;
     Pose ps;
@@ -1497,7 +1496,8 @@ __device__ __forceinline__ void pose_finish_block(const Args &A, int pose, float
                 if (seen++ % nw == wib) {
                     const long wr = (long)pose * A.R + base + b;
                     float *zbuf = sm + wib * DIFFUS_MAX_SAMPLES;
-                    repair_ray_f64<SAMPLER>(A, pose, wr, zbuf);
+                    if (A.N1 <= 8 * kWave) repair_ray_f64<SAMPLER, 8>(A, pose, wr, zbuf);
+                    else repair_ray_f64<SAMPLER, DIFFUS_MAX_SAMPLES / kWave>(A, pose, wr, zbuf);
                 }
             }
         }

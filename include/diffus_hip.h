@@ -216,7 +216,7 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
                                      :407-457; golden G19).  Every float32 evaluation -- the reference's dense LU included -- carries
                                      (condition number) x eps of noise there; diffus_render_fwd and diffus_echo_traces do this repair
                                      inside their kernels.  Here it costs a launch of the per-pose epilogue after the scatter
-                                     (~10 us per step), so it is opt-in: the one-pass step's frame is a by-product of a training
+                                     (~15 us per step), so it is opt-in: the one-pass step's frame is a by-product of a training
                                      step, and the gradients carry the same condition number whatever the arithmetic */
 int diffus_render_bwd(const float *vol, int d0, int d1, int d2, int layout,
                       const void *src, int src_dtype,
