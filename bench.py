@@ -578,7 +578,7 @@ def callers_legs(args, vol, dev):
     tilt["note"] = ("eager one-pass steps of the headline workload (event-timed; the headline's own figure this way is ~2 us above "
                     "its graph/eager best) with tilted fans: the scatter takes its slab path (height-field tile over the fan's "
                     "plane, csrc/scatter.hip); before round 5 these fans fell to the 3-D brick tile and per-sample global "
-                    "atomics: 0.083 / 0.172 / 0.394 / 0.519 / 0.118 ms per step (profiles/r05_tilt_before.txt)")
+                    "atomics: 0.083 / 0.172 / 0.394 / 0.519 / 0.118 ms per step (profiles/r05_tilt_before.txt; after: profiles/r05_tilt_after.txt)")
     out["tilted_fan"] = tilt
     # (f) a SHARED learnable volume on N ranks: what the gradient's collective moves per step (SURVEY §8e "Collective").  A
     #     one-rank RCCL group on this GPU (the N = 8 job cannot be run here): the dense all_reduce of d/dvolume against

@@ -645,37 +645,95 @@ __device__ __forceinline__ void slab_pass(const Args &A, double *tile, const Sla
 #ifdef DIFFUS_SLAB_EXIT
         if (DIFFUS_SLAB_EXIT == 4) return;
 #endif
-        // ---- flush: a lane takes a column (V fastest: neighbours in a brick line), reads its L slots, recovers the layers
-        // from the column's window and adds every non-zero entry to the gradient once; the tile is left all-zero
-        const int ncols = rows * BVp;
+        // Two lane orders for the flush, chosen per pass (block-uniform).  BLOCK-shaped for face passes, for steep planes (L >= 4:
+        // the layers of neighbouring columns differ) and whenever dim 1 is the minor axis (the column-major order then runs
+        // along dim 0: a 32-byte stride inside a brick); column-major for flat planes whose columns run along dim 1.  Measured at
+        // the config 3 poses, scatter in us, column-major everywhere / this choice: roll 5 deg 56.5 / 55.4, roll 20 deg 64.0 / 58.0,
+        // roll 45 deg 73 / 63.6, pitch 20 deg 67.8 / 58.8, fan in the (0,2) plane 64.5 / 58.0, in the (1,2) plane 53 / 52.5
+        // (block-shaped there: 57.7; roll 5 deg block-shaped: 60.1).
+        const bool block_flush = FACE || L >= 4 || AX == 1;
+        // ---- flush, BLOCK-shaped: a wave takes a 4 x 4 block of columns (aligned to multiples of 4 in U and V: the brick grid) and,
+        // of each column, four slots -- lane = 4 (column in the block) + slot.  The 64 atomics of one instruction then land in the
+        // two to four bricks the block's windows span, where the column-major order below (64 consecutive V) spread them over
+        // 16-32 lines: the flush's global atomics were 12.8 us of the kernel at 20 degrees of roll (stage-exit probes), 5x the
+        // planar path's.  Recovers the layers from the columns' windows, adds every non-zero entry to the gradient once and
+        // leaves the tile all-zero.
+        if (block_flush) {
+            // (face passes have two slots: 8 x 4 columns x 2 slots per instruction instead of 4 x 4 x 4)
+            constexpr int SB = FACE ? 1 : 2, UB = FACE ? 3 : 2; // log2: slots per lane group, U rows of a block
+            const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int du = lane >> (SB + 2), dv = (lane >> SB) & 3, s_in = lane & ((1 << SB) - 1);
+            const int bu0 = uc >> UB, nbu = ((uc + rows - 1) >> UB) - bu0 + 1, bv0 = v0 >> 2, nbv = (v1 >> 2) - bv0 + 1;
+            const float rnbv = __builtin_amdgcn_rcpf((float)nbv);
+            const int nblk = nbu * nbv;
 #pragma unroll 1
-        for (int col = tid; col < ncols; col += kSB) {
-            const int r = (int)__umulhi((unsigned)col, magicV), cc = col - r * BVp;
-            double v[kSlabMaxL];
+            for (int blk = wv; blk < nblk; blk += kSW) { // wave-uniform
+                const int qb = (int)(((float)blk + 0.5f) * rnbv); // blk / nbv: exact for the few hundred blocks of a box
+                const int Uc = ((bu0 + qb) << UB) + du, Vc = ((bv0 + (blk - qb * nbv)) << 2) + dv;
+                const bool inbox = (unsigned)(Uc - uc) < (unsigned)rows && (unsigned)(Vc - v0) < (unsigned)BV;
+                const int col = (Uc - uc) * BVp + (Vc - v0);
+                int base = 0, bm = 0;
+                if (!FACE) {
+                    base = (int)floorf(__builtin_fmaf(cv, (float)Vc, __builtin_fmaf(cu, (float)Uc, c0b)));
+                    bm = mod_rel(max(base - a0, 0), L, magic16); // (base >= a0 inside the box)
+                }
+                const unsigned cpart = slab_col_part<AX>(A.G, Uc, Vc);
 #pragma unroll
-            for (int sl = 0; sl < kSlabMaxL; ++sl) v[sl] = (sl < L) ? tile[sl * NC + col] : 0.0; // (sl < L: wave-uniform)
-            const int Uc = uc + r, Vc = v0 + cc;
-            int base = 0, bm = 0;
-            if (!FACE) {
-                base = (int)floorf(__builtin_fmaf(cv, (float)Vc, __builtin_fmaf(cu, (float)Uc, c0b)));
-                bm = mod_rel(max(base - a0, 0), L, magic16); // (base >= a0 inside the box; the clamp only keeps padding columns tame)
-            }
-            const unsigned cpart = slab_col_part<AX>(A.G, Uc, Vc);
-#pragma unroll
-            for (int sl = 0; sl < kSlabMaxL; ++sl) {
-                if (sl < L && v[sl] != 0.0) {
-                    tile[sl * NC + col] = 0.0;
-                    int d = sl - bm;
-                    d += (d < 0) ? L : 0;
-                    const int M = FACE ? (sl ? dimA - 1 : 0) : base + d;
-                    if ((unsigned)M >= (unsigned)dimA) continue; // cannot happen while the window holds; never an out-of-bounds atomic
-                    const unsigned gb = cpart + slab_ax_part<AX>(A.G, rowA, M); // bytes
+                for (int sg = 0; sg < (FACE ? 2 : kSlabMaxL); sg += (1 << SB)) {
+                    if (sg >= L) break; // wave-uniform
+                    const int sl = sg + s_in;
+                    const bool mine = inbox && sl < L;
+                    const double v = mine ? tile[sl * NC + col] : 0.0;
+                    if (v != 0.0) {
+                        tile[sl * NC + col] = 0.0;
+                        int d = sl - bm;
+                        d += (d < 0) ? L : 0;
+                        const int M = FACE ? (sl ? dimA - 1 : 0) : base + d;
+                        if ((unsigned)M < (unsigned)dimA) { // always, while the window holds; never an out-of-bounds atomic
+                            const unsigned gb = cpart + slab_ax_part<AX>(A.G, rowA, M); // bytes
 #if defined(DIFFUS_SLAB_EXIT) && DIFFUS_SLAB_EXIT == 5
-                    asm volatile("" :: "v"(gb), "v"((float)v[sl]));
+                            asm volatile("" :: "v"(gb), "v"((float)v));
 #else
-                    if (A.gtouched) A.gtouched[gb >> 7] = 1;
-                    atomicAdd(reinterpret_cast<float *>(gvol_b + (size_t)gb), (float)v[sl]);
+                            if (A.gtouched) A.gtouched[gb >> 7] = 1;
+                            atomicAdd(reinterpret_cast<float *>(gvol_b + (size_t)gb), (float)v);
 #endif
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---- flush: a lane takes a column (V fastest: neighbours in a brick line), reads its L slots, recovers the layers
+            // from the column's window and adds every non-zero entry to the gradient once; the tile is left all-zero
+            const int ncols = rows * BVp;
+#pragma unroll 1
+            for (int col = tid; col < ncols; col += kSB) {
+                const int r = (int)__umulhi((unsigned)col, magicV), cc = col - r * BVp;
+                double v[kSlabMaxL];
+#pragma unroll
+                for (int sl = 0; sl < kSlabMaxL; ++sl) v[sl] = (sl < L) ? tile[sl * NC + col] : 0.0; // (sl < L: wave-uniform)
+                const int Uc = uc + r, Vc = v0 + cc;
+                int base = 0, bm = 0;
+                if (!FACE) {
+                    base = (int)floorf(__builtin_fmaf(cv, (float)Vc, __builtin_fmaf(cu, (float)Uc, c0b)));
+                    bm = mod_rel(max(base - a0, 0), L, magic16); // (base >= a0 inside the box; the clamp only keeps padding columns tame)
+                }
+                const unsigned cpart = slab_col_part<AX>(A.G, Uc, Vc);
+#pragma unroll
+                for (int sl = 0; sl < kSlabMaxL; ++sl) {
+                    if (sl < L && v[sl] != 0.0) {
+                        tile[sl * NC + col] = 0.0;
+                        int d = sl - bm;
+                        d += (d < 0) ? L : 0;
+                        const int M = FACE ? (sl ? dimA - 1 : 0) : base + d;
+                        if ((unsigned)M >= (unsigned)dimA) continue; // cannot happen while the window holds; never an out-of-bounds atomic
+                        const unsigned gb = cpart + slab_ax_part<AX>(A.G, rowA, M); // bytes
+#if defined(DIFFUS_SLAB_EXIT) && DIFFUS_SLAB_EXIT == 5
+                        asm volatile("" :: "v"(gb), "v"((float)v[sl]));
+#else
+                        if (A.gtouched) A.gtouched[gb >> 7] = 1;
+                        atomicAdd(reinterpret_cast<float *>(gvol_b + (size_t)gb), (float)v[sl]);
+#endif
+                    }
                 }
             }
         }
