@@ -118,6 +118,9 @@ def parse_args(argv=None):
                          "a few steps after the warm-up (outside the timed region) and the faster one is used.  On this stack "
                          "consecutive kernels of a stream or of one graph run back to back, but two graph LAUNCHES are ~8.6 us "
                          "apart (tools/graph_gaps.py), so the eager step is the faster one unless the host is slow")
+    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+                    help="untimed steps for this many milliseconds before the --warmup steps (clocks settle over tens of ms; "
+                         "reported as config.prewarm_steps).  0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callers", action="store_true", help="skip the `callers` legs (demo shape, learnable volume, moving poses)")
     ap.add_argument("--alpha", type=float, default=1e-4)
@@ -902,18 +905,48 @@ class StepRunner:
         j, b = ring_slot(self.kstep - 1, self.K, self.depth) if self.overlap else (0, 0)
         return self.ring[b][j]
 
+    def prewarm(self, ms):
+        """Untimed steps for ~`ms` milliseconds BEFORE the W warm-up steps of timed(): the chip's clocks settle over tens of
+        milliseconds of load (measured: the 20-step region the driver times reads 0.0566-0.0602 ms per step after 125 steps of
+        run-up and 0.0554 after 420), and a 1.1 ms timed region is all run-up otherwise."""
+        import gc
+        torch = self.torch
+        gc.collect()        # (here, not between the run-up and the timed region: see timed())
+        self._collected = True
+        t_end = time.perf_counter() + ms * 1e-3
+        n = 0
+        while time.perf_counter() < t_end:
+            for _ in range(16):
+                self.step()
+            torch.cuda.synchronize()
+            n += 16
+        return n
+
     def timed(self, steps, warmup):
         """-> dict(dt = seconds of the timed region, MAX over ranks; per_rank_ms; host_ms; world_seen)."""
+        import gc
         torch, dist = self.torch, self.dist
+        # No cyclic garbage collection inside the timed region (what `timeit` does too): a generation-2 pass over the ~1e6
+        # objects torch and numpy leave alive is ~10 ms -- ten times a 20-step region (seen once in four such runs).  Collected
+        # BEFORE the warm-up steps: the collection itself idles the GPU for tens of ms, and a chip that has idled that long
+        # starts the timed region at low clocks (0.063 ms per step instead of 0.055).
+        gc_was = gc.isenabled()
+        if not getattr(self, "_collected", False):      # (prewarm() has collected already: nothing may idle the GPU from there on)
+            gc.collect()
+        gc.disable()
         for _ in range(warmup):
             self.step()
         self.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
-        host_ms = (time.perf_counter() - t0) * 1e3 / steps    # host time to ENQUEUE one step (no device wait)
-        self.barrier()
-        dt = time.perf_counter() - t0
+        try:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            host_ms = (time.perf_counter() - t0) * 1e3 / steps    # host time to ENQUEUE one step (no device wait)
+            self.barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            if gc_was:
+                gc.enable()
         per_rank_ms = [dt / steps * 1e3]
         world_seen = 1
         if dist is not None:
@@ -1051,6 +1084,7 @@ def worker(args):
     # steps into one collective; that variant is timed as well and reported beside the headline.
     hp = make_step(src, dirs)
     run = StepRunner(hp, args, dev, dist, world, K=args.gather_every, eager=args.eager)
+    prewarm_steps = run.prewarm(args.prewarm_ms) if args.prewarm_ms > 0 else 0
     res = run.timed(args.steps, args.warmup)
     dt = res["dt"]
     ray_steps = P_total * args.rays * args.samples
@@ -1275,6 +1309,7 @@ def worker(args):
                 "grad_handback": "dense" if args.dense_grad else ("sparse (touched bricks), persistent tensor" if hp.persistent else "sparse (touched bricks), memset per step"), "issue": ("one captured hipGraph replayed per step" if run.graph is not None else
                                    "eager: the step's launches issued from Python through the C-ABI (two calls, three kernels)"),
                 "issue_probe": run.issue_probe,
+                "prewarm_steps": prewarm_steps,
                 "parallelism": f"poses sharded x{ngpu}, volume replicated" if args.n < 512 else f"one volume per GPU x{ngpu} (replicas only)",
                 "host_enqueue_ms_per_step": res["host_ms"],
                 "loss_gather": ("none (1 GPU)" if dist is None else
