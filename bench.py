@@ -905,14 +905,25 @@ class StepRunner:
         j, b = ring_slot(self.kstep - 1, self.K, self.depth) if self.overlap else (0, 0)
         return self.ring[b][j]
 
+    _frozen = [False]
+
+    @staticmethod
+    def _gc_quiet():
+        """Collect now; the first time also freeze what is alive (torch, numpy: ~1e6 objects), so that later collections
+        only walk what was allocated since and take microseconds instead of ~30 ms of idle GPU."""
+        import gc
+        gc.collect()
+        if not StepRunner._frozen[0]:
+            gc.freeze()
+            StepRunner._frozen[0] = True
+
     def prewarm(self, ms):
         """Untimed steps for ~`ms` milliseconds BEFORE the W warm-up steps of timed(): the chip's clocks settle over tens of
         milliseconds of load (measured: the 20-step region the driver times reads 0.0566-0.0602 ms per step after 125 steps of
         run-up and 0.0554 after 420), and a 1.1 ms timed region is all run-up otherwise."""
-        import gc
         torch = self.torch
-        gc.collect()        # (here, not between the run-up and the timed region: see timed())
-        self._collected = True
+        StepRunner._gc_quiet()      # (here, not between the run-up and the timed region: see timed())
+        self._prewarmed = True
         t_end = time.perf_counter() + ms * 1e-3
         n = 0
         while time.perf_counter() < t_end:
@@ -931,8 +942,9 @@ class StepRunner:
         # BEFORE the warm-up steps: the collection itself idles the GPU for tens of ms, and a chip that has idled that long
         # starts the timed region at low clocks (0.063 ms per step instead of 0.055).
         gc_was = gc.isenabled()
-        if not getattr(self, "_collected", False):      # (prewarm() has collected already: nothing may idle the GPU from there on)
-            gc.collect()
+        if not getattr(self, "_prewarmed", False):      # (the secondary legs: a short run-up of their own; the headline has had prewarm())
+            self.prewarm(20.0)
+        self._prewarmed = False                         # one timed region per run-up
         gc.disable()
         for _ in range(warmup):
             self.step()
