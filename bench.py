@@ -924,14 +924,30 @@ class StepRunner:
         torch = self.torch
         StepRunner._gc_quiet()      # (here, not between the run-up and the timed region: see timed())
         self._prewarmed = True
-        t_end = time.perf_counter() + ms * 1e-3
-        n = 0
-        while time.perf_counter() < t_end:
+        if self.dist is None:
+            t_end = time.perf_counter() + ms * 1e-3
+            n = 0
+            while time.perf_counter() < t_end:
+                for _ in range(16):
+                    self.step()
+                torch.cuda.synchronize()
+                n += 16
+            return n
+        # N > 1: every step is (or feeds) a collective, so every rank must run the SAME number of steps: each rank times 16 of
+        # them, the ranks agree on the largest count any of them proposes (one all_reduce), and all run exactly that many
+        t0 = time.perf_counter()
+        for _ in range(16):
+            self.step()
+        torch.cuda.synchronize()
+        per = max((time.perf_counter() - t0) / 16, 1e-6)
+        want = torch.tensor([min(max(int(ms * 1e-3 / per), 16), 20000)], dtype=torch.int64, device=self.dev if self.nccl else "cpu")
+        self.dist.all_reduce(want, op=self.dist.ReduceOp.MAX)
+        n = (int(want.item()) + 15) // 16 * 16
+        for _ in range(n // 16):
             for _ in range(16):
                 self.step()
             torch.cuda.synchronize()
-            n += 16
-        return n
+        return n + 16
 
     def timed(self, steps, warmup):
         """-> dict(dt = seconds of the timed region, MAX over ranks; per_rank_ms; host_ms; world_seen)."""
