@@ -1376,7 +1376,12 @@ def worker(args):
                                         f"1 pose x {args.rays} rays x {args.samples} steps, {args.n}^3 volume, fwd+bwd",
                             "eager_ms": sp["median"], "graph_ms": sp_graph["median"] if sp_graph else None,
                             "pose_gradient_only_ms": sp_pose["median"],
-                            "value": args.rays * args.samples / (min(sp["median"], (sp_graph or sp)["median"]) * 1e-3)},
+                            "value": args.rays * args.samples / (min(sp["median"], (sp_graph or sp)["median"]) * 1e-3),
+                            "value_pose_gradient_only": args.rays * args.samples / (sp_pose["median"] * 1e-3),
+                            "note": "`value`: forward + backward to volume, source and directions (three launches); "
+                                    "`value_pose_gradient_only`: forward + pose-gradient backward, what BASELINE config 2 names (two "
+                                    "launches: scan + per-pose epilogue).  Launch-bound: an ordinary launch is 3.3 us in a stream, a "
+                                    "cooperative one 21.7 us and a grid sync ~28 us (profiles/r05_grid_sync_bench.txt)"},
         }
         out.update(extra)
         out.update(scale_info)

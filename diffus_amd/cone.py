@@ -147,4 +147,8 @@ class FanPose(torch.nn.Module):
         dirs = fan_directions_torch(self.median_angle, op, self.n_rays)
         if self.rotvec is not None:
             dirs = dirs @ rotation_from_rotvec(self.rotvec).T
+        else:
+            # an in-plane fan by construction (dim-2 components are exact zeros): tell the renderer, which otherwise would have
+            # to read a device tensor back to know -- and does not do that for tensors that require grad (renderer._fans_planar)
+            dirs._diffus_planar = True
         return self.apex, dirs

@@ -358,6 +358,8 @@ def _fans_planar(directions: torch.Tensor):
     every step, and tilts them) stay unknown (None): the launch that also carries the slab path."""
     if directions.shape[-1] != 3:
         return None
+    if getattr(directions, "_diffus_planar", False):      # set by FanPose for an in-plane fan (exact zeros by construction)
+        return True
     if not directions.is_cuda:
         return bool((directions.detach()[..., 2] == 0).all())
     if directions.requires_grad or directions.grad_fn is not None:

@@ -124,6 +124,20 @@ def test_fan_pose_six_degrees_of_freedom():
     assert torch.allclose(fp()[1], torch.from_numpy(dirs[p]), atol=1e-6)
 
 
+def test_in_plane_fan_pose_carries_the_planar_hint():
+    """FanPose without a rotation vector marks its directions as planar (exact zeros in dim 2), so that a pose optimisation of
+    an in-plane fan -- directions that require grad, which the renderer never reads back -- still gets the planar scatter launch;
+    a 6-DoF pose, or anything computed from the directions afterwards, does not carry the mark."""
+    import diffus_amd
+    from diffus_amd.renderer import _fans_planar
+    flat = diffus_amd.FanPose((10.0, 20.0, 30.0), (0.6, 0.8), 0.9, 16)
+    six = diffus_amd.FanPose((10.0, 20.0, 30.0), (0.6, 0.8), 0.9, 16, rotvec=(0.0, 0.1, 0.0))
+    d = flat()[1]
+    assert d.requires_grad and _fans_planar(d) is True and bool((d[:, 2] == 0).all())
+    assert _fans_planar(six()[1]) is False                      # a host tensor: looked at directly
+    assert not getattr(d * 2.0, "_diffus_planar", False)
+
+
 def test_fan_pose_module():
     import diffus_amd
     fp = diffus_amd.FanPose((88.0, -11.5, 110.0), (-0.3, -0.95), 0.85, 64, learn_opening=True)
