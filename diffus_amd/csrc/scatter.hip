@@ -15,6 +15,12 @@ namespace {
 // the tile is a box of whole bricks, so the flush is made of 128-B contiguous atomic
 // runs (the full-rate shape of that atomic).  A patch whose box exceeds the tile goes
 // through it as 2 or 4 groups of waves, each with its own box.
+// Three paths, tried in this order by every block (bricked gradients):
+//   scatter_patch_planar  no ray of the patch moves along dim 2 (every fan of the reference): a 2-D tile of doubles;
+//   scatter_patch_slab    the rays lie in one plane through their source (a tilted fan): a height-field tile over that plane,
+//                         doubles, one pass per class of samples (inside the volume / clamped onto a face); only in the launch
+//                         without the DIFFUS_FANS_PLANAR hint (a larger tile, 4 blocks per CU);
+//   the 3-D brick tile in the kernel body: anything else (rays that are not coplanar), and canonical gradients.
 #ifdef DIFFUS_STAMP // diagnostic build only (tools/): per-block phase timestamps of the scatter kernel
 __device__ unsigned long long *g_stamps = nullptr;
 #define STAMP(i)                                                                          \
