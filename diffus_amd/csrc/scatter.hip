@@ -433,6 +433,232 @@ __device__ __forceinline__ bool scatter_patch_planar(const Args &A, double *tile
 }
 
 
+// ---- MERGED planar patches: the part of a fan that has left the volume -------------------------------------------------
+// Rays that have left the volume are clamped onto its faces (grid_sample's border rule): a patch of them touches a line or a
+// corner of border voxels -- a few dozen tile entries -- and still pays the whole skeleton of a block (pose and zbar loads,
+// tile clear, boxes, two barriers, bookkeeping, flush walk): 16-18 k cycles whatever the tile holds, tools/scatter_stamps.py;
+// 39 % of the blocks of config 3 are of that kind.  A ray that is outside stays outside (the volume is convex), so once the two
+// EDGE rays of a ray group are outside at the first step of a step group, the kernel lets ONE block (the "leader") take that
+// step group and the following ones up to the next multiple of four, through ONE tile and ONE skeleton; the blocks of the
+// groups it covers ("followers") exit at once.  Leader and followers decide by the same rule from the same two rays, so every
+// sample is scattered exactly once whatever the rays in between do (if they are NOT all outside, the union box is merely
+// larger; if it does not fit the tile, or a ray turns out not to be planar, the leader adds its samples straight to memory --
+// correct, slow, and not seen in any fan of the reference).
+// rows / row_off / nbase: as in scatter_patch_planar, for the leader's own (first) step group; ng: step groups it takes.
+template <int SAMPLER, int PM, int CAP>
+__device__ __forceinline__ void scatter_patch_planar_merged(const Args &A, double *tile, int (*s_box)[4], int *s_planar, int *s_live, const Pose &ps,
+                                                            const float *rows, unsigned row_off, bool ray_ok, int nbase, int ng, int tid)
+{
+    constexpr int kCapD = CAP / 2, kMaxG = 4;
+    const int wib = tid >> 6;
+    // every group's zbar values first (ng x 16 bytes per thread in flight), the tile cleared under them
+    float zb[kMaxG][kSPT];
+    {
+        const char *rb = reinterpret_cast<const char *>(rows);
+#pragma unroll
+        for (int g = 0; g < kMaxG; ++g) {
+            const int n0 = nbase + g * kScSteps;
+            const unsigned off = row_off + (unsigned)(g * kScSteps) * 4u;
+            if (g < ng && ray_ok && n0 + kSPT <= A.N1) {
+                if constexpr (kSPT == 4) {
+                    const F4a4 t = *reinterpret_cast<const F4a4 *>(rb + (size_t)off);
+                    zb[g][0] = t.x; zb[g][1] = t.y; zb[g][2] = t.z; zb[g][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < kSPT; ++q) zb[g][q] = ldb_f32(rows, off + 4u * q);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < kSPT; ++q) zb[g][q] = (g < ng && ray_ok && n0 + q < A.N1) ? ldb_f32(rows, off + 4u * q) : 0.f;
+            }
+        }
+    }
+    {
+        int4 *t4 = reinterpret_cast<int4 *>(tile);
+#pragma unroll
+        for (int e = 0; e < CAP / 4 / kSB; ++e) t4[e * kSB + tid] = make_int4(0, 0, 0, 0);
+    }
+    const bool ray_planar = (PM == 0 || ps.pmode != 2) ? (ps.df[2] == 0.f) : (ps.dd[2] == 0.0);
+    const bool wave_planar = __ballot(ray_planar) == ~0ull;
+    auto cell_xy = [&](int n, int &x0, int &x1, int &y0, int &y1, float &tx, float &ty) {
+        const float kf = (float)(A.start + n);
+        const float p0 = ray_point_f<PM>(ps, 0, kf), p1 = ray_point_f<PM>(ps, 1, kf);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            x0 = x1 = nearest_index(p0, A.G.d0); y0 = y1 = nearest_index(p1, A.G.d1);
+            tx = ty = 0.f;
+        } else {
+            const Axis a = tri_axis(p0, A.G.d0), b = tri_axis(p1, A.G.d1);
+            x0 = a.i0; x1 = a.i1; tx = a.t; y0 = b.i0; y1 = b.i1; ty = b.t;
+        }
+    };
+    // box: a ray is a straight line and clamp / floor are monotone, so the extremes of a thread's samples over the whole merged
+    // range sit at its first and its last one
+    int bx[4];
+    {
+        int ax0, ax1, ay0, ay1, bx0, bx1, by0, by1;
+        float t0, t1;
+        cell_xy(nbase, ax0, ax1, ay0, ay1, t0, t1);
+        cell_xy(nbase + (ng - 1) * kScSteps + kSPT - 1, bx0, bx1, by0, by1, t0, t1);
+        const bool has = ray_ok && nbase < A.N1;
+        bx[0] = has ? min(ax0, bx0) : 0x7fffffff; bx[1] = has ? max(ax1, bx1) : -1;
+        bx[2] = has ? min(ay0, by0) : 0x7fffffff; bx[3] = has ? max(ay1, by1) : -1;
+    }
+    if (tid == 0) *s_live = 0;
+    bx[0] = wave_reduce_minmax<true>(bx[0]);
+    bx[1] = wave_reduce_minmax<false>(bx[1]);
+    bx[2] = wave_reduce_minmax<true>(bx[2]);
+    bx[3] = wave_reduce_minmax<false>(bx[3]);
+    if ((tid & 63) == 63) {
+        s_planar[wib] = wave_planar;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s_box[wib][a] = bx[a];
+    }
+    __syncthreads(); // also: the tile is clear
+    int all_planar = 1, mn0 = 0x7fffffff, mx0 = -1, mn1 = 0x7fffffff, mx1 = -1;
+#pragma unroll
+    for (int wv = 0; wv < kSW; ++wv) {
+        all_planar &= s_planar[wv];
+        mn0 = min(mn0, __builtin_amdgcn_readfirstlane(s_box[wv][0]) >> 2); mx0 = max(mx0, __builtin_amdgcn_readfirstlane(s_box[wv][1]) >> 2);
+        mn1 = min(mn1, __builtin_amdgcn_readfirstlane(s_box[wv][2]) >> 2); mx1 = max(mx1, __builtin_amdgcn_readfirstlane(s_box[wv][3]) >> 2);
+    }
+    if (mx0 < 0 || mx1 < 0) return; // no sample at all (block-uniform)
+    const int l0 = mn0, l1 = mn1, b0 = mx0 - mn0 + 1, b1 = mx1 - mn1 + 1;
+    const unsigned need = min(4u * (unsigned)min(b0, 0x3fff) * (4u * (unsigned)min(b1, 0x3fff) + kRowPad), (unsigned)kCapD + 1u);
+    if (!__builtin_amdgcn_readfirstlane(all_planar) || need > (unsigned)kCapD) {
+        // not planar after all (a wrong DIFFUS_FANS_PLANAR promise), or the union box exceeds the tile: every sample straight to
+        // memory with its full 3-D cell
+#pragma unroll 1
+        for (int g = 0; g < ng; ++g)
+#pragma unroll 1
+            for (int q = 0; q < kSPT; ++q) {
+                float v = 0.f;
+#pragma unroll
+                for (int gg = 0; gg < kMaxG; ++gg)
+#pragma unroll
+                    for (int qq = 0; qq < kSPT; ++qq) v = (gg == g && qq == q) ? zb[gg][qq] : v;
+                if (!finitef(v) || v == 0.f) continue;
+                const Cell c = cell_of<SAMPLER, PM>(A, ps, A.start + nbase + g * kScSteps + q);
+                for_each_corner<SAMPLER>(c, v, [&](int i, int j, int k, float w) {
+                    if (w != 0.f) {
+                        const unsigned gi = vox_off<DIFFUS_BRICKED>(A.G, i, j, k);
+                        atomicAdd(A.gvol + gi, w);
+                        if (A.gtouched) A.gtouched[gi >> 5] = 1;
+                    }
+                });
+            }
+        return;
+    }
+    // the patch's dim-2 cell: the same for every sample of a planar fan
+    int iz0, iz1;
+    float tz;
+    {
+        const float p2 = ray_point_f<PM>(ps, 2, 0.f);
+        if (SAMPLER == DIFFUS_NEAREST) {
+            iz0 = iz1 = nearest_index(p2, A.G.d2);
+            tz = 0.f;
+        } else {
+            const Axis c = tri_axis(p2, A.G.d2);
+            iz0 = c.i0; iz1 = c.i1; tz = c.t;
+        }
+        iz0 = __builtin_amdgcn_readfirstlane(iz0); iz1 = __builtin_amdgcn_readfirstlane(iz1);
+        tz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tz)));
+    }
+    const int BY = 4 * b1 + kRowPad;
+    const int org = -(4 * l0) * BY - 4 * l1;
+    const int BY8 = BY * 8, org8 = org * 8;
+    char *tile_c = reinterpret_cast<char *>(tile);
+    auto add_at = [&](int byte_off, double v) { atomicAdd(reinterpret_cast<double *>(tile_c + byte_off), v); };
+    unsigned nz = 0;
+    // ---- accumulate, group after group (the code of scatter_patch_planar's accumulation; see there for the same-cell path)
+#pragma unroll
+    for (int g = 0; g < kMaxG; ++g) {
+        if (g >= ng) break; // block-uniform
+#pragma unroll
+        for (int q = 0; q < kSPT; ++q) {
+            float zq = zb[g][q];
+            if (!finitef(zq)) zq = 0.f;
+            nz |= __float_as_uint(zq) & 0x7fffffffu;
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(zq != 0.f);
+            if (act == 0ull) continue; // wave-uniform
+            int x0, x1, y0, y1;
+            float tx, ty;
+            cell_xy(nbase + g * kScSteps + q, x0, x1, y0, y1, tx, ty);
+            const int r0 = __mul24(x0, BY8) + org8, r1 = __mul24(x1, BY8) + org8;
+            const int e00 = r0 + 8 * y0, e11 = r1 + 8 * y1;
+            float c00, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+            if constexpr (SAMPLER == DIFFUS_NEAREST) {
+                c00 = zq;
+            } else {
+                const float wa1 = tx, wa0 = 1.f - wa1, wb1 = ty, wb0 = 1.f - wb1;
+                const float s0 = zq * wa0, s1 = zq * wa1;
+                c00 = s0 * wb0; c01 = s0 * wb1; c10 = s1 * wb0; c11 = s1 * wb1;
+            }
+            const int lead = __builtin_ctzll(act);
+            const int f00 = __builtin_amdgcn_readlane(e00, lead), f11 = __builtin_amdgcn_readlane(e11, lead);
+            const unsigned long long eq = __builtin_amdgcn_ballot_w64(e00 == f00) & __builtin_amdgcn_ballot_w64(e11 == f11);
+            if ((eq & act) == act && __builtin_popcountll(act) > 4) { // wave-uniform: one cell for every live lane
+                const int f01 = __builtin_amdgcn_readlane(r0 + 8 * y1, lead), f10 = __builtin_amdgcn_readlane(r1 + 8 * y0, lead);
+                const double t00 = wave_sum_to_lane63((double)c00);
+                double t01 = 0.0, t10 = 0.0, t11 = 0.0;
+                if constexpr (SAMPLER != DIFFUS_NEAREST) {
+                    t01 = wave_sum_to_lane63((double)c01);
+                    t10 = wave_sum_to_lane63((double)c10);
+                    t11 = wave_sum_to_lane63((double)c11);
+                }
+                if ((tid & 63) == 63) {
+                    if (t00 != 0.0) add_at(f00, t00);
+                    if (t01 != 0.0) add_at(f01, t01);
+                    if (t10 != 0.0) add_at(f10, t10);
+                    if (t11 != 0.0) add_at(f11, t11);
+                }
+            } else {
+                if (c00 != 0.f) add_at(e00, (double)c00);
+                if constexpr (SAMPLER != DIFFUS_NEAREST) {
+                    if (c01 != 0.f) add_at(r0 + 8 * y1, (double)c01);
+                    if (c10 != 0.f) add_at(r1 + 8 * y0, (double)c10);
+                    if (c11 != 0.f) add_at(e11, (double)c11);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(nz != 0u) != 0ull && (tid & 63) == 63) *s_live = 1;
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(*s_live) == 0) return; // nothing added: the tile is still clear (block-uniform)
+    // ---- flush (scatter_patch_planar's, for one group of waves): a wave takes two adjacent brick columns of one brick row
+    {
+        const int lane = tid & 63, o = lane & 31, h = lane >> 5;
+        const int zz = (o & 1) ? iz1 : iz0;
+        const float wz = (iz1 == iz0) ? ((o & 1) ? 0.f : 1.f) : ((o & 1) ? tz : 1.f - tz);
+        const bool adds = wz != 0.f, h0 = h == 0;
+        const unsigned lc_tile = (unsigned)((__mul24(o >> 3, BY) + 4 * h + ((o >> 1) & 3)) * 8);
+        const unsigned lc_g = (__umul24((unsigned)h, (unsigned)A.G.nb2) + (unsigned)(zz >> 1)) * kBrickFloats * 4u
+                              + (unsigned)(((o >> 1) << 1) + (zz & 1)) * 4u;
+        const unsigned lc_t = (__umul24((unsigned)h, (unsigned)A.G.nb2) + (unsigned)(zz >> 1)) * 4u;
+        unsigned lc_tile_o = lc_tile;
+        asm volatile("" : "+v"(lc_tile_o));
+        const char *tile_b = reinterpret_cast<const char *>(tile);
+        const int wv = __builtin_amdgcn_readfirstlane(wib);
+        const unsigned nb2u = (unsigned)A.G.nb2;
+        char *const gvol_b = reinterpret_cast<char *>(A.gvol);
+        char *const gt_b = reinterpret_cast<char *>(A.gtouched);
+        const int npr = (b1 + 1) >> 1;
+        for (int ci = wv >> 1; ci < b0; ci += 2) {
+            const unsigned trow = (unsigned)(4 * ci * BY) * 8u;
+            const unsigned grow = ((unsigned)(l0 + ci) * (unsigned)A.G.nb1 + (unsigned)l1) * nb2u;
+            for (int cp = wv & 1; cp < npr; cp += 2) {
+                const bool second = 2 * cp + 1 < b1; // wave-uniform
+                const double v = (h0 || second) ? *reinterpret_cast<const double *>(tile_b + trow + 64u * (unsigned)cp + lc_tile_o) : 0.0;
+                if (v != 0.0 && adds) {
+                    const unsigned gb = grow + 2u * (unsigned)cp * nb2u;
+                    if (A.gtouched) *reinterpret_cast<int *>(gt_b + (size_t)gb * 4u + (size_t)lc_t) = 1;
+                    atomicAdd(reinterpret_cast<float *>(gvol_b + (size_t)gb * (kBrickFloats * 4u) + (size_t)lc_g), (float)v * wz);
+                }
+            }
+        }
+    }
+}
+
 // ---- SLAB patches (bricked gradient): fans that are NOT planar in dim 2 --------------------------------------------
 // `plot_beam_frame` takes any `directions` (src/renderer.py:119-124, :201-217), and a probe-pose optimisation produces
 // exactly such fans: the plane rolled about the central ray, the central ray pitched out of the slice, a fan lying in
@@ -976,7 +1202,7 @@ __global__ __launch_bounds__(kSB, SLAB ? DIFFUS_SLAB_MIN_BLOCKS : DIFFUS_SC_MIN_
     // in flight at any time are then spread over all poses and ray groups (round 1: all depths of a few neighbouring fans
     // at a time was 58 against 52 us) AND over all depths (round 4).  Within a row the XCD remap keeps a pose on one XCD.
     const int tid = threadIdx.x;
-    int pose, nbase;
+    int pose, nbase, sg_blk = 0; // (sg_blk: the block's step group)
     bool ray_ok;
     long w, w0;        // this thread's ray, the block's first ray (block-uniform)
     unsigned row_off;  // bytes from zbar[w0][0] to the thread's first sample
@@ -994,6 +1220,7 @@ __global__ __launch_bounds__(kSB, SLAB ? DIFFUS_SLAB_MIN_BLOCKS : DIFFUS_SC_MIN_
         // window of rows AND every row a mix of depths: 28.4 -> 25.5 us at 32 poses, 178.6 -> 145.2 us at 256 (round 4).
         const int row = (int)by - has_finish;
         const int sg = (int)(((unsigned)row * (unsigned)sg_mul + 3u * (unsigned)pose) % (unsigned)step_groups);
+        sg_blk = sg;
         // thread -> ray (tid / 8) and 4 consecutive steps ((tid % 8) * 4 ..).  (Tried: a wave taking every 4th ray of the
         // patch instead of 8 adjacent ones, so that near the apex -- adjacent rays less than a voxel apart -- fewer lanes of
         // one LDS atomic share an address: 29.9 -> 30.5 us.)
@@ -1038,6 +1265,43 @@ __global__ __launch_bounds__(kSB, SLAB ? DIFFUS_SLAB_MIN_BLOCKS : DIFFUS_SC_MIN_
         ps.pmode = 0;
     } else {
         load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    }
+#ifndef DIFFUS_SC_MERGE
+#define DIFFUS_SC_MERGE 1 // step groups a leader takes at most (1, 2 or 4).  OFF: measured slower at 32 and 64 poses, DESIGN fact 42
+#endif
+    if constexpr (kCanPlanar && !SLAB && PM == 0 && DIFFUS_SC_MERGE > 1) {
+        // The part of the fan that has left the volume: one block per up to four step groups (scatter_patch_planar_merged).
+        // The rule, evaluated identically by the leader and by the blocks it relieves: a step group is "outside" when the ray
+        // group's two edge rays are outside the slice at its first step; outside groups are taken in runs that end at multiples of
+        // four -- the leader of a run is its first group (a multiple of four, or an outside group whose predecessor is not).
+        if (A.fans_planar) {
+            const float *sp = (const float *)A.src + (long)pose * 3;
+            const int nr = min(kScRays, A.R - (int)(w0 - (long)pose * A.R));
+            const float *da = (const float *)A.dirs + w0 * 3, *db = (const float *)A.dirs + (w0 + nr - 1) * 3; // block-uniform: scalar loads
+            const float hx = (float)(A.G.d0 - 1), hy = (float)(A.G.d1 - 1);
+            auto outside = [&](int sgq) -> bool {
+                const float kf = (float)(A.start + sgq * kScSteps);
+                const float ax = __fadd_rn(sp[0], __fmul_rn(kf, da[0])), ay = __fadd_rn(sp[1], __fmul_rn(kf, da[1]));
+                const float bxp = __fadd_rn(sp[0], __fmul_rn(kf, db[0])), byp = __fadd_rn(sp[1], __fmul_rn(kf, db[1]));
+                const bool oa = !(ax > 0.f && ax < hx && ay > 0.f && ay < hy), ob = !(bxp > 0.f && bxp < hx && byp > 0.f && byp < hy);
+                return oa && ob;
+            };
+            if (__builtin_amdgcn_readfirstlane((int)outside(sg_blk))) {
+                constexpr int kMg = DIFFUS_SC_MERGE;
+                const bool leader = (sg_blk & (kMg - 1)) == 0 || !__builtin_amdgcn_readfirstlane((int)outside(sg_blk - 1));
+                if (!leader) return; // covered by the leader of its run (block-uniform, before any barrier)
+                // its run: the consecutive outside groups from here to the next multiple of four (a source outside the volume makes
+                // "outside" true BEFORE the rays enter as well: a run must end where the rule stops relieving blocks)
+                const int lim = min(kMg - (sg_blk & (kMg - 1)), step_groups - sg_blk);
+                int ng = 1;
+                while (ng < lim && __builtin_amdgcn_readfirstlane((int)outside(sg_blk + ng))) ++ng;
+                if (ng > 1) {
+                    scatter_patch_planar_merged<SAMPLER, PM, CAP>(A, reinterpret_cast<double *>(tile), s_box, s_planar, &s_live, ps, A.zbar + w0 * A.N1,
+                                                                  row_off, ray_ok, nbase, ng, tid);
+                    return;
+                }
+            }
+        }
     }
     if constexpr (kCanPlanar) {
         // The launch that carries the slab path asks the block's FIRST ray before it tries the planar path (a scalar load, no
