@@ -21,9 +21,9 @@ EXPORTS = ("diffus_abi_version", "diffus_strerror", "diffus_workspace_bytes", "d
            "diffus_brain_mask", "diffus_masked_stats_workspace_bytes", "diffus_masked_stats", "diffus_rows_conv1d",
            "diffus_prop_single_ray", "diffus_propagate_rays", "diffus_sample_points",
            "diffus_echo_bwd_workspace_bytes", "diffus_echo_traces_bwd", "diffus_splat_axes", "diffus_rotate_around_apex",
-           "diffus_ssim_workspace_bytes", "diffus_ssim_loss_fwd", "diffus_ssim_loss_bwd")
+           "diffus_ssim_workspace_bytes", "diffus_ssim_loss_fwd", "diffus_ssim_loss_bwd", "diffus_fan_pose_fwd", "diffus_fan_pose_bwd")
 
-ABI_VERSION = 7          # include/diffus_hip.h DIFFUS_ABI_VERSION
+ABI_VERSION = 8          # include/diffus_hip.h DIFFUS_ABI_VERSION
 DIFFUS_F32, DIFFUS_F64, DIFFUS_I64 = 0, 1, 2
 NEAREST, TRILINEAR = 0, 1
 CANONICAL, BRICKED, PAIRED = 0, 1, 2
@@ -106,6 +106,10 @@ def load():
     lib.diffus_ssim_loss_bwd.argtypes = [vp, vp, i, i, i, i, f, f, f, vp, vp, i, vp, sz, vp]
     lib.diffus_rotate_around_apex.restype = i
     lib.diffus_rotate_around_apex.argtypes = [vp, vp, C.c_long, vp, vp, f, vp, vp, vp]
+    lib.diffus_fan_pose_fwd.restype = i
+    lib.diffus_fan_pose_fwd.argtypes = [vp, vp, i, vp, i, i, vp, vp]
+    lib.diffus_fan_pose_bwd.restype = i
+    lib.diffus_fan_pose_bwd.argtypes = [vp, vp, i, vp, vp, i, i, vp, vp, vp, vp]
     lib.diffus_splat_axes.restype = i
     lib.diffus_splat_axes.argtypes = [vp, i, vp, i, vp, i, C.c_long, vp, vp, vp, vp]
     lib.diffus_splat_fwd.restype = i

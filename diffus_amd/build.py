@@ -1,5 +1,5 @@
 """Builds diffus_amd/libdiffus_hip.so (gfx950) with hipcc.  No torch involved: the library is a
-plain C-ABI shared object (include/diffus_hip.h).  The seven translation units under csrc/ are
+plain C-ABI shared object (include/diffus_hip.h).  The eight translation units under csrc/ are
 compiled in parallel and linked."""
 from __future__ import annotations
 
@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ("render_fwd", "render_bwd", "scatter", "splat", "artifacts", "impedance", "ssim")
+UNITS = ("render_fwd", "render_bwd", "scatter", "splat", "artifacts", "impedance", "ssim", "pose")
 HEADERS = (os.path.join(CSRC, "diffus_device.hpp"), os.path.join(CSRC, "diffus_host.hpp"),
            os.path.join(ROOT, "include", "diffus_hip.h"))
 OBJDIR = os.path.join(HERE, "build")

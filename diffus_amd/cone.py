@@ -120,20 +120,98 @@ def rotation_from_rotvec(rotvec: torch.Tensor) -> torch.Tensor:
     return torch.eye(3, dtype=rotvec.dtype, device=rotvec.device) + A * K + B * (K @ K)
 
 
+class _FanDirsFn(torch.autograd.Function):
+    """(median angle, opening angle[, rotation vector]) -> directions and the adjoint, one HIP launch each way
+    (diffus_fan_pose_fwd / _bwd, csrc/pose.hip).  Batched: median (P,), opening () or (P,), rotvec (P,3) or None."""
+
+    @staticmethod
+    def forward(ctx, median, opening, rotvec, n_rays):
+        from . import _lib
+        from .renderer import _Scope, _ptr, _stream
+        lib = _lib.load()
+        dev = median.device
+        m = median.detach().to(torch.float32).contiguous()
+        op = opening.detach().to(device=dev, dtype=torch.float32).contiguous()
+        rv = None if rotvec is None else rotvec.detach().to(torch.float32).contiguous()
+        P = m.numel()
+        stride = 0 if op.numel() == 1 else 1
+        if stride and op.numel() != P:
+            raise ValueError("opening angle: one value, or one per pose")
+        dirs = torch.empty((P, int(n_rays), 3), dtype=torch.float32, device=dev)
+        with _Scope(dev):
+            _lib.check(lib.diffus_fan_pose_fwd(_ptr(m), _ptr(op), stride, _ptr(rv), P, int(n_rays), _ptr(dirs), _stream(dev)),
+                       "diffus_fan_pose_fwd")
+        ctx.save_for_backward(m, op, rv)
+        ctx.meta = (P, int(n_rays), stride, median.shape, opening.shape, opening.device, None if rotvec is None else rotvec.shape)
+        return dirs
+
+    @staticmethod
+    def backward(ctx, gdirs):
+        from . import _lib
+        from .renderer import _Scope, _ptr, _stream
+        lib = _lib.load()
+        m, op, rv = ctx.saved_tensors
+        P, R, stride, mshape, oshape, odev, rshape = ctx.meta
+        dev = m.device
+        need_m, need_o, need_r = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and rv is not None
+        g = gdirs.to(torch.float32).contiguous()
+        out = torch.empty((5, P), dtype=torch.float32, device=dev)     # rows: median, opening, rotvec x 3 (as (P,3) in rows 2..4's storage)
+        g_m = out[0] if need_m else None
+        g_o = out[1] if need_o else None
+        g_r = out[2:].view(-1)[:3 * P].view(P, 3) if need_r else None
+        with _Scope(dev):
+            _lib.check(lib.diffus_fan_pose_bwd(_ptr(m), _ptr(op), stride, _ptr(rv), _ptr(g), P, R, _ptr(g_m), _ptr(g_o), _ptr(g_r),
+                                               _stream(dev)), "diffus_fan_pose_bwd")
+        if need_o:
+            g_o = (g_o.sum() if stride == 0 else g_o).reshape(oshape).to(odev)
+        return (g_m.reshape(mshape) if need_m else None, g_o, g_r.reshape(rshape) if need_r else None, None)
+
+
+def fan_directions(median_angle: torch.Tensor, opening_angle, n_rays: int, rotvec=None) -> torch.Tensor:
+    """The fan(s) of `fan_directions_torch` turned by `rotation_from_rotvec(rotvec)`, differentiable in all three, as ONE
+    launch each way when the parameters live on the GPU (csrc/pose.hip; float64 inside): a scalar median angle gives
+    (n_rays, 3), a (P,) one (P, n_rays, 3) with rotvec (P, 3) and the opening angle shared or (P,).  On host tensors: the
+    same map composed from torch ops (what the HIP pair is tested against)."""
+    median_angle = torch.as_tensor(median_angle)
+    opening_angle = torch.as_tensor(opening_angle, dtype=torch.float32)
+    if median_angle.device.type != "cuda":
+        if median_angle.dim() == 0:
+            d = fan_directions_torch(median_angle, opening_angle.to(median_angle.device), n_rays)
+            return d if rotvec is None else d @ rotation_from_rotvec(rotvec).T
+        op = opening_angle.to(median_angle.device).expand(median_angle.shape)
+        return torch.stack([fan_directions(median_angle[p], op[p], n_rays, None if rotvec is None else rotvec[p])
+                            for p in range(median_angle.shape[0])])
+    single = median_angle.dim() == 0
+    rv = rotvec
+    if rv is not None:
+        rv = torch.as_tensor(rv).to(median_angle.device)
+        rv = rv.reshape(1, 3) if single else rv
+    d = _FanDirsFn.apply(median_angle.reshape(-1), opening_angle, rv, n_rays)
+    return d[0] if single else d
+
+
 class FanPose(torch.nn.Module):
     """Differentiable probe pose: (apex, median angle, opening angle[, rotation vector]) -> (source, directions).
 
     The reference builds `source` / `directions` once with NumPy and cannot optimise them
     (SURVEY D3); the HIP backward produces d/d source and d/d directions, and this module carries
-    them to the three pose parameters.  forward() == (apex, generate_cone_directions((cos m, sin m),
+    them to the pose parameters.  forward() == (apex, generate_cone_directions((cos m, sin m),
     opening, n_rays)) up to rounding.
+
+    One pose: apex (3,), direction (2,).  A SWEEP of P poses optimised together (the batch `render_poses` takes): apex (P,3),
+    direction (P,2), rotvec (P,3) -> source (P,3), directions (P, n_rays, 3).
     """
 
     def __init__(self, apex, direction, opening_angle: float, n_rays: int, learn_opening: bool = False, rotvec=None):
         super().__init__()
         self.n_rays = int(n_rays)
         self.apex = torch.nn.Parameter(torch.as_tensor(apex, dtype=torch.float32).clone())
-        self.median_angle = torch.nn.Parameter(torch.tensor(median_angle_of(direction), dtype=torch.float32))
+        direction = np.asarray(direction.detach().cpu() if isinstance(direction, torch.Tensor) else direction, dtype=np.float64)
+        if self.apex.dim() == 1:
+            med = torch.tensor(median_angle_of(direction), dtype=torch.float32)
+        else:
+            med = torch.tensor([median_angle_of(d) for d in direction], dtype=torch.float32)
+        self.median_angle = torch.nn.Parameter(med)
         op = torch.tensor(float(opening_angle), dtype=torch.float32)
         self.opening_angle = torch.nn.Parameter(op) if learn_opening else op
         # Six degrees of freedom: `rotvec` (axis x angle, radians; None = the reference's in-plane fan: apex + one angle)
@@ -143,11 +221,8 @@ class FanPose(torch.nn.Module):
         self.rotvec = None if rotvec is None else torch.nn.Parameter(torch.as_tensor(rotvec, dtype=torch.float32).clone())
 
     def forward(self):
-        op = self.opening_angle.to(self.median_angle.device)
-        dirs = fan_directions_torch(self.median_angle, op, self.n_rays)
-        if self.rotvec is not None:
-            dirs = dirs @ rotation_from_rotvec(self.rotvec).T
-        else:
+        dirs = fan_directions(self.median_angle, self.opening_angle, self.n_rays, self.rotvec)
+        if self.rotvec is None:
             # an in-plane fan by construction (dim-2 components are exact zeros): tell the renderer, which otherwise would have
             # to read a device tensor back to know -- and does not do that for tensors that require grad (renderer._fans_planar)
             dirs._diffus_planar = True

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Six-degree-of-freedom probe registration on one full-size frame (BASELINE config 2: 256 rays x 512 steps, 256^3).
+
+What `notebooks/[NW] alignement.ipynb` cells 13-14 of the reference set out to do -- move `source` / `directions` until the
+rendered frame matches an observed one -- and cannot: `plot_beam_frame` (src/renderer.py:201-275) rounds the sample points
+(:754-756), so no gradient reaches the pose.  Here the trilinear sampler carries d loss / d source and
+d loss / d directions out of the HIP backward, and `FanPose` carries them on to apex, median angle and rotation vector.
+
+    python examples/register_probe_pose.py [iterations]
+
+The observed frame is rendered from a "true" pose; the start pose is 3 voxels and 5 degrees (roll + pitch, out of the slice)
+away.  Prints the loss, the apex error and the worst ray angle as the descent goes, and the time per iteration.
+"""
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diffus_amd as da  # noqa: E402
+
+
+def smooth_head(n):
+    """A head-like volume WITHOUT hard edges: registration by gradient descent needs a loss that varies smoothly with the
+    pose, and the phantom's skull (400 -> 6.4e6 in one voxel) makes the frame a step function of it."""
+    u = np.arange(n, dtype=np.float64) / (n - 1)
+    c = u - 0.5
+    r2 = (c / 0.46)[:, None, None] ** 2 + (c / 0.40)[None, :, None] ** 2 + (c / 0.44)[None, None, :] ** 2
+    vol = 1.5e6 + 2.5e5 * np.exp(-3.0 * r2) + 1.2e5 * (np.sin(19 * u)[:, None, None] * np.cos(17 * u)[None, :, None]
+                                                       * np.sin(13 * u + 1)[None, None, :])
+    return vol.astype(np.float32)
+
+
+def worst_ray_angle(pose, true):
+    with torch.no_grad():
+        a, b = pose()[1].double().cpu(), true()[1].double().cpu()
+    cosang = (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))
+    return float(torch.rad2deg(torch.acos(cosang.clamp(-1, 1))).max())
+
+
+def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50):
+    vol = torch.from_numpy(smooth_head(n)).cuda()
+    look = np.array([0.8, 0.6, 0.0])
+    side = np.array([-0.6, 0.8, 0.0])
+    apex_true = np.array([0.5 * n, 0.5 * n, 0.5 * n]) - 0.30 * n * look
+    true = da.FanPose(apex_true, look[:2], math.radians(60.0), R, rotvec=(0.0, 0.0, 0.0)).cuda()
+    with torch.no_grad():
+        target = da.render_poses(vol, *true(), S, alpha, sampler="trilinear")
+    tilt = np.radians(4.0) * look + np.radians(3.0) * side                        # 5 degrees in all, out of the slice both ways
+    pose = da.FanPose(apex_true + np.array([1.8, -1.9, 1.5]), look[:2], math.radians(60.0), R, rotvec=tilt).cuda()
+    opt = torch.optim.Adam([{"params": [pose.apex], "lr": 0.05}, {"params": [pose.median_angle, pose.rotvec], "lr": 0.002}], fused=True)
+    err0 = float(torch.linalg.norm(pose.apex.detach() - true.apex.detach()))
+    print("start: apex error %.2f voxels, worst ray angle %.2f deg" % (err0, worst_ray_angle(pose, true)))
+    history = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(iters):
+        opt.zero_grad(set_to_none=True)
+        src, dirs = pose()
+        frame = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
+        loss = ((frame - target) ** 2).sum()
+        loss.backward()
+        opt.step()
+        if it % report == 0 or it == iters - 1:
+            history.append((it, float(loss.detach())))
+            print("iter %4d  loss %.4g  apex error %.3f voxels  worst ray angle %.3f deg" % (
+                it, history[-1][1], float(torch.linalg.norm(pose.apex.detach() - true.apex.detach())), worst_ray_angle(pose, true)))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%d iterations, %.3f ms each (render fwd + bwd + Adam, the reports included)" % (iters, 1e3 * dt / iters))
+    return history, float(torch.linalg.norm(pose.apex.detach() - true.apex.detach())), worst_ray_angle(pose, true)
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 400)

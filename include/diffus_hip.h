@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DIFFUS_ABI_VERSION 7 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd; 5: winner raster kept between diffus_splat_fwd / _bwd; 6: diffus_convert_volume_box; 7: DIFFUS_FANS_PLANAR / DIFFUS_BWD_REPAIR_FRAME flag bits, a per-ray flag array in the workspace (diffus_workspace_bytes grows) */
+#define DIFFUS_ABI_VERSION 8 /* 2: 40-float PAIRED records + one-pass step workspace (round 2); 3: round-3 entry points; 4: strided y / gy in diffus_mlp_fwd / _bwd; 5: winner raster kept between diffus_splat_fwd / _bwd; 6: diffus_convert_volume_box; 7: DIFFUS_FANS_PLANAR / DIFFUS_BWD_REPAIR_FRAME flag bits, a per-ray flag array in the workspace (diffus_workspace_bytes grows); 8: diffus_fan_pose_fwd / _bwd */
 
 /* error codes */
 #define DIFFUS_OK            0
@@ -368,6 +368,22 @@ int diffus_ssim_loss_bwd(const float *img, const float *ref, int H, int W, int n
  */
 int diffus_rotate_around_apex(const float *x, const float *z, long n, const float *apex, const float *median, float shift,
                               float *x_rot, float *z_rot, diffus_stream_t stream);
+
+/*
+ * The probe-pose parameterisation, both ways.  Forward: P fans of n_rays unit directions each,
+ *     dirs[p][i] = R(rotvec[p]) (cos(median[p] + a_i), sin(median[p] + a_i), 0),  a_i = opening * linspace(-1/2, 1/2, n_rays)[i]
+ * -- without a rotation vector (rotvec = NULL) the fan of generate_cone_directions((cos m, sin m), opening, n_rays)
+ * (reference src/cone.py:242-258: in the (0,1) plane, third component an exact 0) that cone_us_to_mri_world (:187-209)
+ * places; with one, that fan turned about its apex by the rotation vector (axis x angle, radians; Rodrigues), i.e. rolled /
+ * pitched out of the slice: the six-degree-of-freedom pose a registration optimises.  All pointers DEVICE float32:
+ * median (P), opening (P when opening_stride = 1, one shared value when 0), rotvec (P,3) or NULL, dirs (P, n_rays, 3).
+ * Backward: gdirs (P, n_rays, 3) = dL/ddirs (what diffus_render_bwd returns in gdirs) -> g_median (P), g_opening (P: per
+ * pose also when the opening angle is shared -- the caller sums), g_rotvec (P,3); each output nullable.  Evaluated in float64.
+ */
+int diffus_fan_pose_fwd(const float *median, const float *opening, int opening_stride, const float *rotvec, int n_poses,
+                        int n_rays, float *dirs, diffus_stream_t stream);
+int diffus_fan_pose_bwd(const float *median, const float *opening, int opening_stride, const float *rotvec, const float *gdirs,
+                        int n_poses, int n_rays, float *g_median, float *g_opening, float *g_rotvec, diffus_stream_t stream);
 
 /*
  * The axis choice of differentiable_splat (reference src/renderer.py:702-710), on the device: x, y, z are the three

@@ -31,7 +31,7 @@ def test_header_and_exports_agree(lib):
     assert sorted(_lib.EXPORTS) == names
     for n in names:
         assert getattr(lib, n) is not None          # dlsym succeeds
-    assert lib.diffus_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.diffus_abi_version() == _lib.ABI_VERSION == 8
     assert lib.diffus_strerror(0) == b"ok"
     assert b"workspace" in lib.diffus_strerror(-4)
 

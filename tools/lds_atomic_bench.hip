@@ -6,7 +6,7 @@
 #include <vector>
 
 constexpr int kIters = 256;
-template <int MODE, int PAT>
+template <int MODE, int PAT, int LM = 0> // LM: only lanes with (lane & LM) == 0 issue the atomic (does the cost follow the active lanes?)
 __global__ __launch_bounds__(256) void k(const int *__restrict__ addr, float *out)
 {
     __shared__ float tf[8192];
@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void k(const int *__restrict__ addr, float *ou
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int e = (a[j] + it * 37) & 8191;
-            if (PAT == 2) e = a[j];
+            if (PAT >= 2) e = a[j];
+            if (LM != 0 && (threadIdx.x & LM) != 0) continue;
             if (MODE == 0) atomicAdd(&tf[e], 1.0f);
             if (MODE == 1) atomicAdd(&ti[e], 3);
             if (MODE == 2) tf[e] += 1.0f; // racy plain RMW: rate reference only
@@ -36,13 +37,15 @@ __global__ __launch_bounds__(256) void k(const int *__restrict__ addr, float *ou
 
 int main()
 {
-    std::vector<int> h(3 * 8 * 256);
+    std::vector<int> h(5 * 8 * 256);
     srand(1);
     for (int j = 0; j < 8; ++j)
         for (int t = 0; t < 256; ++t) {
             h[(0 * 8 + j) * 256 + t] = t * 1 + j * 256;          // conflict-free, distinct addresses
             h[(1 * 8 + j) * 256 + t] = rand() & 8191;            // random
             h[(2 * 8 + j) * 256 + t] = ((t >> 2) * 33 + j) & 8191; // 4 lanes share an address (adjacent rays)
+            h[(3 * 8 + j) * 256 + t] = ((t >> 1) * 33 + j) & 8191; // 2 lanes share an address
+            h[(4 * 8 + j) * 256 + t] = ((t >> 3) * 33 + j) & 8191; // 8 lanes share an address
         }
     int *d; float *o;
     hipMalloc(&d, h.size() * 4); hipMalloc(&o, 4);
@@ -75,6 +78,17 @@ int main()
     run(k<4, 0>, "ds_add_f64 conflict-free");
     run(k<4, 1>, "ds_add_f64 random");
     run(k<4, 2>, "ds_add_f64 4-lanes-same");
+    run(k<4, 3>, "ds_add_f64 2-lanes-same");
+    run(k<4, 4>, "ds_add_f64 8-lanes-same");
+    run(k<4, 0, 1>, "ds_add_f64 c-free, 32 lanes");
+    run(k<4, 0, 3>, "ds_add_f64 c-free, 16 lanes");
+    run(k<4, 0, 7>, "ds_add_f64 c-free, 8 lanes");
+    run(k<4, 0, 63>, "ds_add_f64 c-free, 1 lane");
+    run(k<4, 2, 3>, "ds_add_f64 4-same, 1 of each");
+    run(k<1, 0, 3>, "ds_add_u32 c-free, 16 lanes");
+    run(k<3, 0, 3>, "ds_add_u64 c-free, 16 lanes");
+    run(k<3, 4>, "ds_add_u64 8-lanes-same");
+    run(k<1, 4>, "ds_add_u32 8-lanes-same");
     run(k<5, 1>, "ds_max_i32 random");
     run(k<2, 0>, "plain rmw conflict-free");
     run(k<2, 1>, "plain rmw random");
