@@ -583,6 +583,24 @@ def callers_legs(args, vol, dev):
                     "plane, csrc/scatter.hip); before round 5 these fans fell to the 3-D brick tile and per-sample global "
                     "atomics: 0.083 / 0.172 / 0.394 / 0.519 / 0.118 ms per step (profiles/r05_tilt_before.txt; after: profiles/r05_tilt_after.txt)")
     out["tilted_fan"] = tilt
+    # (e') a six-degree-of-freedom probe registration on ONE full-size frame (config 2's: 256 rays x 512 steps), the loop
+    #      `[NW] alignement` cells 13-14 attempt: FanPose (csrc/pose.hip) -> render -> sum of squares -> backward -> Adam, eager
+    #      through torch autograd and as one captured graph per iteration (examples/register_probe_pose.py)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        from register_probe_pose import run as register_run
+        reg = {}
+        for name, graph in (("eager", False), ("graph", True)):
+            stats = {}
+            hist, apex_err, ang = register_run(iters=400, n=n, R=args.rays, S=args.samples, alpha=args.alpha, report=399, graph=graph,
+                                               quiet=True, stats=stats)
+            reg[name + "_ms_per_iteration"] = stats["ms_per_iteration"]
+            reg[name + "_final"] = {"loss": hist[-1][1], "apex_error_voxels": apex_err, "worst_ray_angle_deg": ang}
+        reg["note"] = ("start 3.0 voxels and 5 degrees (roll + pitch) away from the pose that rendered the target; 400 Adam steps; "
+                       "wall time per iteration; before csrc/pose.hip the eager iteration was 1.56 ms (profiles/r05_registration_host.txt)")
+        out["registration_6dof"] = reg
+    except Exception as e:
+        out["registration_6dof"] = {"failed": repr(e)}
     # (f) a SHARED learnable volume on N ranks: what the gradient's collective moves per step (SURVEY §8e "Collective").  A
     #     one-rank RCCL group on this GPU (the N = 8 job cannot be run here): the dense all_reduce of d/dvolume against
     #     allreduce_box (the one slice the reference's training loop learns) and allreduce_touched (the bricks a step touched)

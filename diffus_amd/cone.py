@@ -213,7 +213,10 @@ class FanPose(torch.nn.Module):
             med = torch.tensor([median_angle_of(d) for d in direction], dtype=torch.float32)
         self.median_angle = torch.nn.Parameter(med)
         op = torch.tensor(float(opening_angle), dtype=torch.float32)
-        self.opening_angle = torch.nn.Parameter(op) if learn_opening else op
+        if learn_opening:
+            self.opening_angle = torch.nn.Parameter(op)
+        else:
+            self.register_buffer("opening_angle", op)      # a buffer: it moves with .cuda() (no upload per call, graph-capturable)
         # Six degrees of freedom: `rotvec` (axis x angle, radians; None = the reference's in-plane fan: apex + one angle)
         # turns the whole fan about its apex -- directions = R(rotvec) . fan(median angle).  Its first two components tilt the
         # fan's plane out of the slice (roll / pitch: what src/cone.py:242-258 cannot express, z = 0 there); the third is an

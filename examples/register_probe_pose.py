@@ -6,7 +6,10 @@ rendered frame matches an observed one -- and cannot: `plot_beam_frame` (src/ren
 (:754-756), so no gradient reaches the pose.  Here the trilinear sampler carries d loss / d source and
 d loss / d directions out of the HIP backward, and `FanPose` carries them on to apex, median angle and rotation vector.
 
-    python examples/register_probe_pose.py [iterations]
+    python examples/register_probe_pose.py [iterations] [--graph]
+
+--graph: the whole iteration (FanPose -> render -> loss -> backward -> Adam) captured once as a HIP graph and replayed; every
+launch of it is capturable (nothing allocates behind torch's back or synchronises), and the loop is launch-bound otherwise.
 
 The observed frame is rendered from a "true" pose; the start pose is 3 voxels and 5 degrees (roll + pitch, out of the slice)
 away.  Prints the loss, the apex error and the worst ray angle as the descent goes, and the time per iteration.
@@ -41,7 +44,8 @@ def worst_ray_angle(pose, true):
     return float(torch.rad2deg(torch.acos(cosang.clamp(-1, 1))).max())
 
 
-def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50):
+def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50, graph=False, quiet=False, stats=None):
+    say = (lambda *a: None) if quiet else print
     vol = torch.from_numpy(smooth_head(n)).cuda()
     look = np.array([0.8, 0.6, 0.0])
     side = np.array([-0.6, 0.8, 0.0])
@@ -51,28 +55,55 @@ def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50):
         target = da.render_poses(vol, *true(), S, alpha, sampler="trilinear")
     tilt = np.radians(4.0) * look + np.radians(3.0) * side                        # 5 degrees in all, out of the slice both ways
     pose = da.FanPose(apex_true + np.array([1.8, -1.9, 1.5]), look[:2], math.radians(60.0), R, rotvec=tilt).cuda()
-    opt = torch.optim.Adam([{"params": [pose.apex], "lr": 0.05}, {"params": [pose.median_angle, pose.rotvec], "lr": 0.002}], fused=True)
+    opt = torch.optim.Adam([{"params": [pose.apex], "lr": 0.05}, {"params": [pose.median_angle, pose.rotvec], "lr": 0.002}],
+                           fused=True, capturable=graph)
     err0 = float(torch.linalg.norm(pose.apex.detach() - true.apex.detach()))
-    print("start: apex error %.2f voxels, worst ray angle %.2f deg" % (err0, worst_ray_angle(pose, true)))
-    history = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(iters):
+    say("start: apex error %.2f voxels, worst ray angle %.2f deg" % (err0, worst_ray_angle(pose, true)))
+    loss_out = torch.zeros((), device="cuda")
+
+    def iteration():
         opt.zero_grad(set_to_none=True)
         src, dirs = pose()
         frame = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
         loss = ((frame - target) ** 2).sum()
         loss.backward()
         opt.step()
+        loss_out.copy_(loss.detach())
+
+    done = 0
+    replay = iteration
+    if graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # torch's recipe: a few eager iterations on a side stream first
+            for _ in range(3):
+                iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        done = 3
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            iteration()
+        done += 1
+        replay = g.replay
+    history = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(done, iters):
+        replay()
         if it % report == 0 or it == iters - 1:
-            history.append((it, float(loss.detach())))
-            print("iter %4d  loss %.4g  apex error %.3f voxels  worst ray angle %.3f deg" % (
+            history.append((it, float(loss_out)))
+            say("iter %4d  loss %.4g  apex error %.3f voxels  worst ray angle %.3f deg" % (
                 it, history[-1][1], float(torch.linalg.norm(pose.apex.detach() - true.apex.detach())), worst_ray_angle(pose, true)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("%d iterations, %.3f ms each (render fwd + bwd + Adam, the reports included)" % (iters, 1e3 * dt / iters))
+    say("%d iterations, %.3f ms each (render fwd + bwd + Adam%s, the reports included)" % (
+        iters - done, 1e3 * dt / max(iters - done, 1), ", one graph replay" if graph else ""))
+    if stats is not None:
+        stats["ms_per_iteration"] = 1e3 * dt / max(iters - done, 1)
     return history, float(torch.linalg.norm(pose.apex.detach() - true.apex.detach())), worst_ray_angle(pose, true)
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 400)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    run(int(args[0]) if args else 400, graph="--graph" in sys.argv)

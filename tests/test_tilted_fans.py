@@ -295,3 +295,6 @@ def test_full_size_registration_example_descends(da):
     history, apex_err, ang = mod.run(iters=150, report=149)
     assert history[-1][1] < 0.2 * history[0][1], history
     assert apex_err < 2.8 and ang < 2.5, (apex_err, ang)          # from 3.02 voxels and 4.6 degrees; 400 iterations: 1.1 and 0.36
+    # the same loop as ONE captured graph per iteration: every launch of it is capturable, and the descent is the same
+    hist_g, apex_g, ang_g = mod.run(iters=150, report=149, graph=True)
+    assert abs(hist_g[-1][1] - history[-1][1]) < 0.05 * history[-1][1] and abs(apex_g - apex_err) < 0.05, (hist_g, history)
