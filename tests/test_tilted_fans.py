@@ -298,3 +298,110 @@ def test_full_size_registration_example_descends(da):
     # the same loop as ONE captured graph per iteration: every launch of it is capturable, and the descent is the same
     hist_g, apex_g, ang_g = mod.run(iters=150, report=149, graph=True)
     assert abs(hist_g[-1][1] - history[-1][1]) < 0.05 * history[-1][1] and abs(apex_g - apex_err) < 0.05, (hist_g, history)
+
+
+def _coplanar_case(seed):
+    """A fan that is a RIGID MOTION of a planar one (every patch coplanar: the slab path), at random: odd volume shapes,
+    any orientation (uniform over SO(3); every third seed close to a coordinate plane, where the minor axis flips between
+    patches), source inside / on the border / outside, short and long steps, crops, f32 / f64 poses."""
+    rng = np.random.default_rng(7000 + seed)
+    dims = tuple(int(v) for v in rng.integers(5, 72, size=3))
+    if seed % 5 == 1:
+        dims = (int(rng.integers(2, 6)), int(rng.integers(30, 90)), int(rng.integers(5, 40)))
+    vol = (1.5e6 + 2e5 * rng.standard_normal(dims)).astype(np.float32)
+    R = int(rng.choice([1, 2, 5, 31, 32, 33, 40, 64, 70]))
+    S = int(rng.choice([3, 17, 33, 64, 65, 96, 130, 200]))
+    start = int(rng.integers(1, max(2, S // 3))) if seed % 4 == 3 and S > 4 else 0
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    if seed % 3 == 0:      # nearly axis-aligned planes: a coordinate permutation times a small rotation
+        perm = np.eye(3)[list(rng.permutation(3))]
+        e = 0.02 * rng.standard_normal(3)
+        K = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
+        Rm = perm @ (np.eye(3) + K + 0.5 * K @ K)
+    opening = np.radians(rng.uniform(5, 140))
+    ang = rng.uniform(0, 2 * np.pi) + np.linspace(-opening / 2, opening / 2, R)
+    fan = np.stack([np.cos(ang), np.sin(ang), np.zeros(R)], 1) @ Rm.T
+    step = float(rng.choice([0.15, 0.5, 1.0, 1.0, 1.7, 3.0]))
+    dirs = fan * step
+    centre = np.array(dims) / 2.0
+    where = seed % 4
+    src = centre + rng.normal(0, 0.25, 3) * np.array(dims) if where < 2 else (
+        centre + rng.normal(0, 1.2, 3) * np.array(dims) if where == 2 else np.array([0.3, rng.uniform(0, dims[1] - 1), dims[2] - 1.4]))   # beside two faces (exactly ON one, the d/dpoint convention
+    # at p == 0 decides the answer: grid_sample's zero there is pinned by G9, float64 autograd through clamp says one)
+    f64 = seed % 6 == 4
+    return vol, src.astype(np.float64 if f64 else np.float32), dirs.astype(np.float32), S, start, float(10 ** rng.uniform(-4, -2))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_coplanar_fans_vs_float64_autograd(da, seed):
+    """Seeded sweep of the slab path (and of its hand-over to the general path where a patch is too thick): d/dvolume in every
+    gradient layout, d/dsource, d/ddirections against float64 autograd at the float32 sample points, <= 1e-3."""
+    from oracle import autograd_ref as ar
+    vol, src, dirs, S, start, alpha = _coplanar_case(seed)
+    vol = np.abs(vol) + 1e5                             # well-conditioned reflection coefficients (the float32-vs-float64 question is not this test's)
+    for sampler in ("trilinear", "nearest"):
+        v64 = torch.from_numpy(vol).double().requires_grad_(True)
+        s64 = torch.from_numpy(src).double().requires_grad_(True)
+        d64 = torch.from_numpy(dirs).double().requires_grad_(True)
+        f64 = ar.render(v64, s64, d64, S, alpha, start, sampler)
+        up = torch.randn(f64.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+        (f64 * up).sum().backward()
+        ref = v64.grad.numpy()
+        for layout in ("bricked", "paired", "canonical"):
+            v = torch.from_numpy(vol).cuda().requires_grad_(True)
+            s = torch.from_numpy(src).cuda().requires_grad_(True)
+            d = torch.from_numpy(dirs).cuda().requires_grad_(True)
+            f = da.render_poses(v, s, d, S, alpha, start=start, sampler=sampler, layout=layout)[0]
+            (f * up.float().cuda()).sum().backward()
+            gv = v.grad.cpu().numpy()
+            assert np.all(np.isfinite(gv))
+            if np.max(np.abs(ref)) < 1e-14:
+                assert np.max(np.abs(gv)) < 1e-9, (seed, sampler, layout)
+                continue
+            assert maxnorm_rel(gv, ref) < 1e-3, (seed, sampler, layout, maxnorm_rel(gv, ref))
+            if sampler == "trilinear":
+                assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 1e-3, (seed, layout)
+                assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 1e-3, (seed, layout)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_coplanar_fans_medium_size(da, seed):
+    """The same sweep at sizes where patches fill their tiles, need several passes (faces + inside) and row chunks: volumes of
+    100-200 voxels a side, 96 rays x 400 steps of 1-2.5 voxels, any orientation; trilinear, bricked gradient."""
+    from oracle import autograd_ref as ar
+    rng = np.random.default_rng(9100 + seed)
+    dims = tuple(int(v) for v in rng.integers(100, 201, size=3))
+    u = [np.arange(d, dtype=np.float64) / (d - 1) for d in dims]
+    vol = (1.5e6 + 2e5 * np.sin(9 * u[0])[:, None, None] * np.cos(7 * u[1])[None, :, None] * np.sin(5 * u[2] + 1)[None, None, :]
+           + 3e4 * rng.standard_normal(dims)).astype(np.float32)
+    R, S, alpha = 96, 400, 1e-4
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    opening = np.radians(rng.uniform(30, 100))
+    ang = rng.uniform(0, 2 * np.pi) + np.linspace(-opening / 2, opening / 2, R)
+    dirs = (np.stack([np.cos(ang), np.sin(ang), np.zeros(R)], 1) @ Rm.T * float(rng.choice([1.0, 1.0, 2.5]))).astype(np.float32)
+    src = (np.array(dims) / 2.0 + rng.normal(0, 0.2, 3) * np.array(dims)).astype(np.float32)
+    v64 = torch.from_numpy(vol).double().requires_grad_(True)
+    s64 = torch.from_numpy(src).double().requires_grad_(True)
+    d64 = torch.from_numpy(dirs).double().requires_grad_(True)
+    f64 = ar.render(v64, s64, d64, S, alpha, 0, "trilinear")
+    (f64 ** 2).sum().backward()
+    v = torch.from_numpy(vol).cuda().requires_grad_(True)
+    s = torch.from_numpy(src).cuda().requires_grad_(True)
+    d = torch.from_numpy(dirs).cuda().requires_grad_(True)
+    f = da.render_poses(v, s, d, S, alpha, sampler="trilinear", layout="bricked")[0]
+    (f ** 2).sum().backward()
+    fo = f64.detach().numpy()
+    assert maxnorm_rel(f.detach().cpu().numpy(), fo) < 1e-4, seed
+    assert maxnorm_rel(v.grad.cpu().numpy(), v64.grad.numpy()) < 1e-3, seed
+    assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 1e-3, seed
+    assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 1e-3, seed
