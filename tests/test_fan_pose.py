@@ -136,3 +136,22 @@ def test_batched_fan_pose_on_host_equals_per_pose():
         np.testing.assert_allclose(dirs[p].detach().numpy(), one()[1].detach().numpy(), atol=1e-7)
     dirs[..., 0].sum().backward()
     assert batch.rotvec.grad.shape == (P, 3) and batch.median_angle.grad.shape == (P,)
+
+
+@pytest.mark.gpu
+def test_fan_pose_kernel_against_the_reference_fans_of_g8():
+    """Golden G8 = `generate_cone_directions` of the REFERENCE (src/cone.py:242-258) run on seven (direction, opening, n)
+    triples: the device kernel, given the median ANGLE of each direction (the angle is rounded to float32 on its way in:
+    <= 1.9e-7 rad), reproduces every fan to 3e-7 -- and to one float32 rounding of the float64 evaluation at that angle."""
+    import os
+    import diffus_amd as da
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_cone_directions.npz"))
+    for c in range(int(g["ncases"])):
+        d = np.asarray(g[f"c{c}_direction"], dtype=np.float64)
+        m = math.atan2(d[1], d[0])
+        op, n = float(g[f"c{c}_opening"]), int(g[f"c{c}_n"])
+        got = da.fan_directions(torch.tensor(m, dtype=torch.float32).cuda(), op, n).cpu().numpy()
+        want = g[f"c{c}_out"]
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, atol=3e-7, rtol=0, err_msg=f"case {c}")
+        assert np.all(got[:, 2] == 0)
