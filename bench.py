@@ -590,14 +590,16 @@ def callers_legs(args, vol, dev):
         sys.path.insert(0, os.path.join(ROOT, "examples"))
         from register_probe_pose import run as register_run
         reg = {}
-        for name, graph in (("eager", False), ("graph", True)):
+        for name, graph, one_pass in (("eager", False, False), ("graph", True, False), ("one_pass_eager", False, True),
+                                      ("one_pass_graph", True, True)):
             stats = {}
             hist, apex_err, ang = register_run(iters=400, n=n, R=args.rays, S=args.samples, alpha=args.alpha, report=399, graph=graph,
-                                               quiet=True, stats=stats)
+                                               quiet=True, stats=stats, one_pass=one_pass)
             reg[name + "_ms_per_iteration"] = stats["ms_per_iteration"]
             reg[name + "_final"] = {"loss": hist[-1][1], "apex_error_voxels": apex_err, "worst_ray_angle_deg": ang}
         reg["note"] = ("start 3.0 voxels and 5 degrees (roll + pitch) away from the pose that rendered the target; 400 Adam steps; "
-                       "wall time per iteration; before csrc/pose.hip the eager iteration was 1.56 ms (profiles/r05_registration_host.txt)")
+                       "wall time per iteration; one_pass: render + loss + backward as CapturedStep.mse_loss (diffus_render_step_mse, no volume "
+                       "gradient); before csrc/pose.hip the eager iteration was 1.56 ms (profiles/r05_registration_host.txt)")
         out["registration_6dof"] = reg
     except Exception as e:
         out["registration_6dof"] = {"failed": repr(e)}

@@ -6,10 +6,12 @@ rendered frame matches an observed one -- and cannot: `plot_beam_frame` (src/ren
 (:754-756), so no gradient reaches the pose.  Here the trilinear sampler carries d loss / d source and
 d loss / d directions out of the HIP backward, and `FanPose` carries them on to apex, median angle and rotation vector.
 
-    python examples/register_probe_pose.py [iterations] [--graph]
+    python examples/register_probe_pose.py [iterations] [--graph] [--one-pass]
 
 --graph: the whole iteration (FanPose -> render -> loss -> backward -> Adam) captured once as a HIP graph and replayed; every
 launch of it is capturable (nothing allocates behind torch's back or synchronises), and the loop is launch-bound otherwise.
+--one-pass: render + loss + backward as `CapturedStep.mse_loss` -- frame, loss and the pose gradients out of ONE pass over the
+samples (diffus_render_step_mse) instead of a forward launch, three loss kernels and a backward that recomputes the forward.
 
 The observed frame is rendered from a "true" pose; the start pose is 3 voxels and 5 degrees (roll + pitch, out of the slice)
 away.  Prints the loss, the apex error and the worst ray angle as the descent goes, and the time per iteration.
@@ -44,7 +46,7 @@ def worst_ray_angle(pose, true):
     return float(torch.rad2deg(torch.acos(cosang.clamp(-1, 1))).max())
 
 
-def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50, graph=False, quiet=False, stats=None):
+def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50, graph=False, quiet=False, stats=None, one_pass=False):
     say = (lambda *a: None) if quiet else print
     vol = torch.from_numpy(smooth_head(n)).cuda()
     look = np.array([0.8, 0.6, 0.0])
@@ -61,12 +63,23 @@ def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50, graph=False, quie
     say("start: apex error %.2f voxels, worst ray angle %.2f deg" % (err0, worst_ray_angle(pose, true)))
     loss_out = torch.zeros((), device="cuda")
 
+    step = None
+    if one_pass:   # persistent buffers, no volume gradient (the volume is not what is being learnt), the launch for any fan
+        with torch.no_grad():
+            s0, d0 = pose()
+        step = da.CapturedStep(vol, s0.detach().reshape(1, 3).clone(), d0.detach().reshape(1, R, 3).clone(), S, alpha, "trilinear",
+                               want_gvol=False, fans="oblique", target=target, loss_scale=1.0)
+
     def iteration():
         opt.zero_grad(set_to_none=True)
         src, dirs = pose()
-        frame = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
-        loss = ((frame - target) ** 2).sum()
-        loss.backward()
+        if step is not None:
+            loss = step.mse_loss(sources=src, directions=dirs)
+            loss.backward(step.unit)       # (the step's resident 1.0: the gradients are handed over as they are)
+        else:
+            frame = da.render_poses(vol, src, dirs, S, alpha, sampler="trilinear")
+            loss = ((frame - target) ** 2).sum()
+            loss.backward()
         opt.step()
         loss_out.copy_(loss.detach())
 
@@ -106,4 +119,4 @@ def run(iters=400, n=256, R=256, S=512, alpha=1e-4, report=50, graph=False, quie
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    run(int(args[0]) if args else 400, graph="--graph" in sys.argv)
+    run(int(args[0]) if args else 400, graph="--graph" in sys.argv, one_pass="--one-pass" in sys.argv)

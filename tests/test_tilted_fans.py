@@ -298,6 +298,9 @@ def test_full_size_registration_example_descends(da):
     # the same loop as ONE captured graph per iteration: every launch of it is capturable, and the descent is the same
     hist_g, apex_g, ang_g = mod.run(iters=150, report=149, graph=True)
     assert abs(hist_g[-1][1] - history[-1][1]) < 0.05 * history[-1][1] and abs(apex_g - apex_err) < 0.05, (hist_g, history)
+    # ... and with render + loss + backward as the one-pass step (CapturedStep.mse_loss): the same numbers again
+    hist_o, apex_o, ang_o = mod.run(iters=150, report=149, graph=True, one_pass=True)
+    assert abs(hist_o[-1][1] - hist_g[-1][1]) < 0.02 * hist_g[-1][1] and abs(apex_o - apex_g) < 0.02, (hist_o, hist_g)
 
 
 def _coplanar_case(seed):
