@@ -60,6 +60,7 @@ class _CapturedRender(torch.autograd.Function):
         step._run("forward")
         ctx.step = step
         ctx.stamp = step._stamp = step._stamp + 1
+        ctx.shapes = (sources.shape, directions.shape)   # (3,) / (R,3) for one pose: gradients go back in the callers' shapes
         return step.frame.detach()          # a new tensor object on the step's frame buffer (no copy)
 
     @staticmethod
@@ -84,7 +85,7 @@ class _CapturedRender(torch.autograd.Function):
         need_v, need_s, need_d = ctx.needs_input_grad[1:4]
         keep = (lambda t: t) if step.alias_grads else (lambda t: t.clone())
         return (None, keep(step.gvol) if (need_v and step.gvol is not None) else None,
-                keep(step.gsrc).reshape(step._src_shape) if need_s else None, keep(step.gdirs) if need_d else None)
+                keep(step.gsrc).reshape(ctx.shapes[0]) if need_s else None, keep(step.gdirs).reshape(ctx.shapes[1]) if need_d else None)
 
 
 class _CapturedMSE(torch.autograd.Function):
@@ -103,6 +104,7 @@ class _CapturedMSE(torch.autograd.Function):
         ctx.step = step
         ctx.where = None if slice_values is None else (dim, index)
         ctx.stamp = step._stamp = step._stamp + 1
+        ctx.shapes = (sources.shape, directions.shape)   # as handed in (autograd would otherwise sum (1,R,3) down to (R,3): a launch)
         # (one pose: the loss IS the buffer's only element -- a view, valid until the next step, instead of a reduction)
         return step.loss.sum() if step.P > 1 else step.loss.detach().view(())
 
@@ -117,11 +119,11 @@ class _CapturedMSE(torch.autograd.Function):
         if g.data_ptr() == step.unit.data_ptr():
             # `loss.backward(step.unit)`: the upstream gradient IS the step's resident 1.0 -- the gradients are handed over as
             # they are (views of the step's buffers; the slice a strided one) instead of through four multiply launches
-            return (None, step.gvol if (need_v and have_v) else None, step.gsrc.reshape(step._src_shape) if need_s else None,
-                    step.gdirs if need_d else None,
+            return (None, step.gvol if (need_v and have_v) else None, step.gsrc.reshape(ctx.shapes[0]) if need_s else None,
+                    step.gdirs.reshape(ctx.shapes[1]) if need_d else None,
                     step.gvol.select(*ctx.where) if (need_sl and have_v and ctx.where is not None) else None, None, None)
         return (None, step.gvol * g if (need_v and have_v) else None,
-                (step.gsrc * g).reshape(step._src_shape) if need_s else None, step.gdirs * g if need_d else None,
+                (step.gsrc * g).reshape(ctx.shapes[0]) if need_s else None, (step.gdirs * g).reshape(ctx.shapes[1]) if need_d else None,
                 step.gvol.select(*ctx.where) * g if (need_sl and have_v and ctx.where is not None) else None, None, None)
 
 

@@ -125,7 +125,7 @@ class _FanDirsFn(torch.autograd.Function):
     (diffus_fan_pose_fwd / _bwd, csrc/pose.hip).  Batched: median (P,), opening () or (P,), rotvec (P,3) or None."""
 
     @staticmethod
-    def forward(ctx, median, opening, rotvec, n_rays):
+    def forward(ctx, median, opening, rotvec, n_rays, single=False):
         from . import _lib
         from .renderer import _Scope, _ptr, _stream
         lib = _lib.load()
@@ -143,9 +143,10 @@ class _FanDirsFn(torch.autograd.Function):
                        "diffus_fan_pose_fwd")
         ctx.save_for_backward(m, op, rv)
         ctx.meta = (P, int(n_rays), stride, median.shape, opening.shape, opening.device, None if rotvec is None else rotvec.shape)
-        return dirs
+        return dirs.view(int(n_rays), 3) if single else dirs      # (one pose: (R,3) straight away -- a select afterwards is two launches in its backward)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, gdirs):
         from . import _lib
         from .renderer import _Scope, _ptr, _stream
@@ -164,7 +165,7 @@ class _FanDirsFn(torch.autograd.Function):
                                                _stream(dev)), "diffus_fan_pose_bwd")
         if need_o:
             g_o = (g_o.sum() if stride == 0 else g_o).reshape(oshape).to(odev)
-        return (g_m.reshape(mshape) if need_m else None, g_o, g_r.reshape(rshape) if need_r else None, None)
+        return (g_m.reshape(mshape) if need_m else None, g_o, g_r.reshape(rshape) if need_r else None, None, None)
 
 
 def fan_directions(median_angle: torch.Tensor, opening_angle, n_rays: int, rotvec=None) -> torch.Tensor:
@@ -186,8 +187,7 @@ def fan_directions(median_angle: torch.Tensor, opening_angle, n_rays: int, rotve
     if rv is not None:
         rv = torch.as_tensor(rv).to(median_angle.device)
         rv = rv.reshape(1, 3) if single else rv
-    d = _FanDirsFn.apply(median_angle.reshape(-1), opening_angle, rv, n_rays)
-    return d[0] if single else d
+    return _FanDirsFn.apply(median_angle.reshape(-1), opening_angle, rv, n_rays, single)
 
 
 class FanPose(torch.nn.Module):
