@@ -646,6 +646,21 @@ int launch_bwd_p(const Args &A, hipStream_t st)
 #endif
         constexpr int W8 = DIFFUS_BWD_WPB8; // waves (= rays) per block of the C = 8 kernel
         const dim3 grid((unsigned)((waves + W8 - 1) / W8));
+#ifndef DIFFUS_SPLIT_SMALL_WAVES
+#define DIFFUS_SPLIT_SMALL_WAVES 0
+#endif
+        // A launch of a few hundred rays (one or two frames) leaves most SIMDs empty and is as long as ONE wave's dependent chain:
+        // two waves of 4 samples per lane per ray then halve that chain (the default layout and float32 poses only: each
+        // instantiation is compile time for every build)
+        if constexpr (SM == DIFFUS_TRILINEAR && LY == DIFFUS_PAIRED && PM == 0 && DIFFUS_SPLIT_SMALL_WAVES > 0) {
+            if (waves <= DIFFUS_SPLIT_SMALL_WAVES && A.N1 > 4 * kWave) {
+                if (A.N1 == 8 * kWave)
+                    hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, 2, PM, false, 2, true>), dim3((unsigned)waves), dim3(2 * kWave), 0, st, A);
+                else
+                    hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, 2, PM, false, 2>), dim3((unsigned)waves), dim3(2 * kWave), 0, st, A);
+                break;
+            }
+        }
         if (A.N1 == 8 * kWave) // full rows: the instantiation without the end-of-row tests
             hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, W8, PM, false, 1, true>), grid, dim3(kWave * W8), 0, st, A);
         else
