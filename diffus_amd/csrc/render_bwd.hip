@@ -639,28 +639,14 @@ int launch_bwd_p(const Args &A, hipStream_t st)
     case 2: hipLaunchKernelGGL((render_bwd_kernel<2, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
     case 4: hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, kWavesPerBlock, PM>), dim3(nblk), dim3(kBlock), 0, st, A); break;
     // (256 < N1 <= 512 as two waves of 4 samples per lane was measured too: 46.5 against 37 us at config 3 -- the split
-    // pays only where it lifts the single wave out of the 2-waves-per-SIMD register regime)
+    // pays only where it lifts the single wave out of the 2-waves-per-SIMD register regime; for launches of ONE to four frames,
+    // where most SIMDs are empty, it changes nothing either: 8.3 us with or without, the event-timed floor of a launch is 6.5)
     case 8: {
 #ifndef DIFFUS_BWD_WPB8
 #define DIFFUS_BWD_WPB8 kWavesPerBlock
 #endif
         constexpr int W8 = DIFFUS_BWD_WPB8; // waves (= rays) per block of the C = 8 kernel
         const dim3 grid((unsigned)((waves + W8 - 1) / W8));
-#ifndef DIFFUS_SPLIT_SMALL_WAVES
-#define DIFFUS_SPLIT_SMALL_WAVES 0
-#endif
-        // A launch of a few hundred rays (one or two frames) leaves most SIMDs empty and is as long as ONE wave's dependent chain:
-        // two waves of 4 samples per lane per ray then halve that chain (the default layout and float32 poses only: each
-        // instantiation is compile time for every build)
-        if constexpr (SM == DIFFUS_TRILINEAR && LY == DIFFUS_PAIRED && PM == 0 && DIFFUS_SPLIT_SMALL_WAVES > 0) {
-            if (waves <= DIFFUS_SPLIT_SMALL_WAVES && A.N1 > 4 * kWave) {
-                if (A.N1 == 8 * kWave)
-                    hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, 2, PM, false, 2, true>), dim3((unsigned)waves), dim3(2 * kWave), 0, st, A);
-                else
-                    hipLaunchKernelGGL((render_bwd_kernel<4, SM, LY, GPOSE, 2, PM, false, 2>), dim3((unsigned)waves), dim3(2 * kWave), 0, st, A);
-                break;
-            }
-        }
         if (A.N1 == 8 * kWave) // full rows: the instantiation without the end-of-row tests
             hipLaunchKernelGGL((render_bwd_kernel<8, SM, LY, GPOSE, W8, PM, false, 1, true>), grid, dim3(kWave * W8), 0, st, A);
         else
