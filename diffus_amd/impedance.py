@@ -88,6 +88,9 @@ class _MlpFn(torch.autograd.Function):
         ctx.consts = (shift, div, out_scale, x.device, x.dtype, [t.shape for t in (w1, b1, w2, b2, w3, b3)],
                       [t.device for t in (w1, b1, w2, b2, w3, b3)])
         if out is not None:
+            # the kernel wrote through a raw pointer: tell torch (the version counter is shared with out's base, e.g. the volume
+            # this slice belongs to -- what the renderer's cache of converted volume copies and autograd's saved-tensor checks key on)
+            torch.autograd.graph.increment_version(y)
             return y                    # a fresh tensor object on out's memory (detach(): no view bookkeeping)
         return y.to(x.device)
 

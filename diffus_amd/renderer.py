@@ -331,21 +331,37 @@ def resolve_start(start, num_samples: int) -> int:
 # ever READ by the kernels; an in-place edit of a host tensor bumps its version and misses.
 _host_poses: list = []
 
+try:
+    from xxhash import xxh3_64_intdigest as _digest          # ~10 GB/s: 3 KB of directions in well under a microsecond
+except Exception:                                            # pragma: no cover
+    from zlib import adler32 as _digest
+
+
+def _fingerprint(t: torch.Tensor) -> int:
+    """A checksum of a host tensor's bytes.  The version counter does not see every edit: a tensor made by torch.from_numpy
+    shares its memory with an array that NumPy code may rewrite in place -- the cached device copy would then be stale
+    without any sign of it.  So a hit needs identity, version AND content."""
+    return _digest(t.numpy() if t.is_contiguous() else t.contiguous().numpy())      # (callers: host tensors that do not require grad)
+
 
 def _host_pose_lookup(dev, sources, directions):
     if sources.requires_grad or directions.requires_grad:
         return None
     for e in _host_poses:
         if e[0]() is sources and e[2]() is directions and e[1] == sources._version and e[3] == directions._version and e[4] == dev:
-            return e[5], e[6], e[7]
+            if e[8] == (_fingerprint(sources), _fingerprint(directions)):
+                return e[5], e[6], e[7]
+            return None
     return None
 
 
 def _host_pose_store(dev, sources, directions, dsrc, ddirs, planar):
     if sources.requires_grad or directions.requires_grad:
         return
-    _host_poses[:] = [e for e in _host_poses if e[0]() is not None and e[2]() is not None][-7:]
-    _host_poses.append((weakref.ref(sources), sources._version, weakref.ref(directions), directions._version, dev, dsrc, ddirs, planar))
+    _host_poses[:] = [e for e in _host_poses if e[0]() is not None and e[2]() is not None
+                      and not (e[0]() is sources and e[2]() is directions and e[4] == dev)][-7:]
+    _host_poses.append((weakref.ref(sources), sources._version, weakref.ref(directions), directions._version, dev, dsrc, ddirs, planar,
+                        (_fingerprint(sources), _fingerprint(directions))))
 
 
 _planar_seen: list = []          # (weakref to a device `directions` tensor, version, planar): one readback per tensor version

@@ -156,3 +156,24 @@ def test_layout_fits_follows_the_abi_limits():
     assert layout_fits("bricked", (8, 1024, 512)) and not layout_fits("bricked", (8, 2048, 1024))
     assert layout_fits("canonical", (8, 2048, 1024))
     assert not layout_fits("canonical", (1024, 1024, 1024))                                       # 2^30 floats: 32-bit offsets
+
+
+def test_host_pose_cache_sees_numpy_side_edits():
+    """The upload cache of host poses is keyed by identity + version + CONTENT: a tensor made by torch.from_numpy can be
+    rewritten through its array without its version counter moving."""
+    from diffus_amd import renderer as R
+    arr = np.linspace(0, 1, 12, dtype=np.float32).reshape(4, 3)
+    dirs = torch.from_numpy(arr)
+    src = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+    dev = torch.device("cpu")
+    R._host_pose_store(dev, src, dirs, "dsrc", "ddirs", True)
+    assert R._host_pose_lookup(dev, src, dirs) == ("dsrc", "ddirs", True)
+    v = dirs._version
+    arr[2, 1] += 0.5                                   # NumPy-side edit: same tensor object, same version
+    assert dirs._version == v
+    assert R._host_pose_lookup(dev, src, dirs) is None
+    R._host_pose_store(dev, src, dirs, "dsrc2", "ddirs2", False)
+    assert R._host_pose_lookup(dev, src, dirs) == ("dsrc2", "ddirs2", False)
+    dirs.add_(1.0)                                     # torch-side edit: the version moves
+    assert R._host_pose_lookup(dev, src, dirs) is None
+    assert R._fingerprint(torch.empty(0)) == R._fingerprint(torch.empty(0))
