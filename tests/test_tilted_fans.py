@@ -303,7 +303,7 @@ def test_full_size_registration_example_descends(da):
     assert abs(hist_o[-1][1] - hist_g[-1][1]) < 0.02 * hist_g[-1][1] and abs(apex_o - apex_g) < 0.02, (hist_o, hist_g)
 
 
-def _coplanar_case(seed):
+def _coplanar_case(seed, planar=False):
     """A fan that is a RIGID MOTION of a planar one (every patch coplanar: the slab path), at random: odd volume shapes,
     any orientation (uniform over SO(3); every third seed close to a coordinate plane, where the minor axis flips between
     patches), source inside / on the border / outside, short and long steps, crops, f32 / f64 poses."""
@@ -326,6 +326,8 @@ def _coplanar_case(seed):
         e = 0.02 * rng.standard_normal(3)
         K = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
         Rm = perm @ (np.eye(3) + K + 0.5 * K @ K)
+    if planar:             # (tools/fuzz_slab.py: the same cases with the fan left in the slice, as a control)
+        Rm = np.eye(3)
     opening = np.radians(rng.uniform(5, 140))
     ang = rng.uniform(0, 2 * np.pi) + np.linspace(-opening / 2, opening / 2, R)
     fan = np.stack([np.cos(ang), np.sin(ang), np.zeros(R)], 1) @ Rm.T

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Fuzz the scatter's slab path (fans that are rigid motions of planar ones, any orientation) against float64 autograd:
+tests/test_tilted_fans.py's `_coplanar_case` generator over many seeds, d/dvolume (bricked gradient), d/dsource, d/ddirections
+of a random upstream gradient, both samplers, at the sample points the reference's own arithmetic produces.  A gradient fails at
+>= 1e-3 max-norm-relative UNLESS the same algorithm run in float32 by torch is as far off there (within 3x: sources far outside the
+volume put every sample on the border and the reflection coefficients become differences of nearly equal numbers); exact ties at
+the start-crop median are skipped.  Prints one line per failing seed and a progress line every 100 seeds.
+
+    python tools/fuzz_slab.py [first_seed] [count]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+if not os.environ.get("FUZZ_DRY"):
+    import diffus_amd as da  # noqa: E402
+from oracle import autograd_ref as ar  # noqa: E402
+from test_tilted_fans import _coplanar_case  # noqa: E402
+
+
+def maxnorm_rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+PLANAR = bool(os.environ.get("FUZZ_PLANAR"))      # control: the same cases with the fans left in the slice
+SEEDS = [int(x) for x in os.environ.get("FUZZ_SEEDS", "").split(",") if x]
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad, worst, skipped, conditioned = [], 0.0, 0, 0
+t0 = time.time()
+for k, seed in enumerate(SEEDS or range(first, first + count)):
+    vol, src, dirs, S, start, alpha = _coplanar_case(seed, planar=PLANAR)
+    vol = np.abs(vol) + 1e5
+    # where the reference's own arithmetic puts the sample points: float32 multiply + add for float32 poses, float64 (then a
+    # cast) when the source is float64 (torch's promotion, src/renderer.py:119-124)
+    pts = "f32" if src.dtype == np.float32 else "exact"
+    for sampler in ("trilinear", "nearest"):
+        def reference(dt):
+            v_ = torch.from_numpy(vol).to(dt).requires_grad_(True)
+            s_ = torch.from_numpy(src).double().requires_grad_(True)
+            d_ = torch.from_numpy(dirs).double().requires_grad_(True)
+            # (the body of ar.render, with everything after the sample points in `dt`)
+            if pts == "f32":
+                p64 = ar.ray_points_f32(s_, d_, S)
+            else:   # float64 source, float32 directions: k * direction is a float32 product, the sum is float64, the sampler casts
+                # the point to float32 (src/renderer.py:119-124, :751; csrc ray_point_f, pmode 1) -- straight-through derivatives
+                exact = ar.ray_points(s_, d_, S)
+                t32 = torch.arange(S, dtype=torch.float32).view(1, S, 1) * torch.from_numpy(dirs).float().unsqueeze(1)
+                p64 = (torch.from_numpy(src).double().view(1, 1, 3) + t32.double()).float().double() + (exact - exact.detach())
+            p64.retain_grad()
+            p_ = p64.to(dt)
+            imp_ = ar.sample_nearest(v_, p_)[0] if sampler == "nearest" else ar.sample_trilinear(v_, p_)
+            e_ = ar.echo_scan(ar.start_crop(ar.reflection(imp_), start))
+            f_ = e_ * torch.exp(-alpha * torch.arange(e_.shape[1], dtype=dt))[None, :]
+            up_ = torch.randn(f_.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+            (f_ * up_.to(dt)).sum().backward()
+            gz = lambda t_: (t_.grad if t_.grad is not None else torch.zeros_like(t_)).double().numpy()     # (nearest: no pose gradient)
+            gp_ = p64.grad.abs() if p64.grad is not None else torch.zeros_like(p64)     # |dL/dp| per sample: what the pose sums are made of
+            terms = (float(gp_.sum()), float((gp_ * torch.arange(S, dtype=torch.float64).view(1, S, 1)).sum(1).max()))
+            return f_.detach(), gz(v_), gz(s_), gz(d_), up_, terms
+        f64, ref, rs, rd, up, terms = reference(torch.float64)
+        if start > 0:      # an exact tie at the per-pose median (rays clamped onto the same border voxels): which ray the
+            # median's gradient goes to is torch's choice among equals, and a different one is as good a subgradient
+            with torch.no_grad():
+                imp = (ar.sample_trilinear if sampler == "trilinear" else (lambda v_, p_: ar.sample_nearest(v_, p_)[0]))(
+                    torch.from_numpy(vol).double(), ar.ray_points_f32(torch.from_numpy(src).double(), torch.from_numpy(dirs).double(), S)
+                    if pts == "f32" else ar.ray_points(torch.from_numpy(src).double(), torch.from_numpy(dirs).double(), S))
+                first_kept = ar.reflection(imp)[:, start]
+                med = first_kept.median()
+                if int((first_kept == med).sum()) > 1:
+                    skipped += 1
+                    continue
+        _, n32, ns32, nd32, _, _ = reference(torch.float32)     # the same algorithm in float32: the noise a float32 evaluation carries here
+        if os.environ.get("FUZZ_DRY"):      # the reference side alone (runs without a GPU: a check of this script)
+            continue
+        v = torch.from_numpy(vol).cuda().requires_grad_(True)
+        s = torch.from_numpy(src).cuda().requires_grad_(True)
+        d = torch.from_numpy(dirs).cuda().requires_grad_(True)
+        f = da.render_poses(v, s, d, S, alpha, start=start, sampler=sampler, layout="bricked")[0]
+        (f * up.float().cuda()).sum().backward()
+        gv = v.grad.cpu().numpy()
+        errs, noise = {}, {}
+        if not np.all(np.isfinite(gv)):
+            errs["nonfinite"] = 1.0
+        elif np.max(np.abs(ref)) < 1e-14:
+            if np.max(np.abs(gv)) >= 1e-9:
+                errs["gvol_should_vanish"] = float(np.max(np.abs(gv)))
+        else:
+            errs["gvol"], noise["gvol"] = maxnorm_rel(gv, ref), maxnorm_rel(n32, ref)
+            if sampler == "trilinear":
+                errs["gsrc"], noise["gsrc"] = maxnorm_rel(s.grad.cpu().numpy(), rs), maxnorm_rel(ns32, rs)
+                errs["gdirs"], noise["gdirs"] = maxnorm_rel(d.grad.cpu().numpy(), rd), maxnorm_rel(nd32, rd)
+        # a pose gradient is a SUM over samples (d/dsource: of dL/dp_k, d/ddirection: of k dL/dp_k) that may cancel to far less than
+        # its terms: float32 accumulation is then held to 2e-6 of the sum of their magnitudes, beside 1e-3 of the result
+        slack = {"gsrc": 2e-6 * terms[0] / max(np.abs(rs).max(), 1e-30), "gdirs": 2e-6 * terms[1] / max(np.abs(rd).max(), 1e-30)}
+        failing = {k_: e for k_, e in errs.items() if e >= max(1e-3 + slack.get(k_, 0.0), 3.0 * noise.get(k_, 0.0))}
+        for k_, e in errs.items():
+            if k_ not in failing and e >= 1e-3:
+                conditioned += 1
+            elif k_ not in failing:
+                worst = max(worst, e)
+        if failing:
+            bad.append((seed, sampler, errs))
+            print("FAIL seed %d %s dims %s R %d S %d start %d: %s (float32 torch: %s)" % (seed, sampler, vol.shape, dirs.shape[0], S, start, errs, noise), flush=True)
+    if (k + 1) % 100 == 0:
+        print("%d seeds, %d failures, %d median ties skipped, %d above 1e-3 but within 3x float32 torch's own error, worst below 1e-3: %.2e, %.0f s"
+              % (k + 1, len(bad), skipped, conditioned, worst, time.time() - t0), flush=True)
+print("done: %d seeds from %d, %d failures, %d median ties skipped, %d ill-conditioned (within 3x float32 torch)" % (count, first, len(bad), skipped, conditioned))
+sys.exit(1 if bad else 0)
