@@ -410,3 +410,44 @@ def test_random_coplanar_fans_medium_size(da, seed):
     assert maxnorm_rel(v.grad.cpu().numpy(), v64.grad.numpy()) < 1e-3, seed
     assert maxnorm_rel(s.grad.cpu().numpy(), s64.grad.numpy()) < 1e-3, seed
     assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 1e-3, seed
+
+
+@pytest.mark.parametrize("sampler", ["trilinear", "nearest"])
+def test_mixed_batch_is_the_sum_of_its_poses(da, sampler):
+    """One launch with every kind of fan side by side -- in the slice, rolled, pitched, lying in another coordinate plane, and
+    one whose rays are NOT coplanar (the general 3-D tile) -- gives, pose by pose, the frames and pose gradients of the single-pose
+    launches, and d/dvolume is the sum of theirs (each block picks its path from its own rays: csrc/scatter.hip)."""
+    n, R, S, alpha = 96, 64, 160, 1e-3
+    vol_np = phantom(n)
+    kinds = [dict(), dict(roll_deg=20.0), dict(pitch_deg=15.0), dict(plane=(0, 2)), dict(roll_deg=45.0, pitch_deg=5.0), dict(plane=(1, 2))]
+    srcs, dirss = [], []
+    for i, kw in enumerate(kinds):
+        s_, d_ = pose_ring(n, 8, R, **kw)
+        srcs.append(s_[i]); dirss.append(d_[i].copy())
+    rng = np.random.default_rng(3)
+    warped = dirss[1].copy()
+    warped += 0.05 * rng.standard_normal(warped.shape).astype(np.float32)     # no plane holds these rays
+    srcs.append(srcs[1]); dirss.append(warped)
+    src, dirs = np.stack(srcs), np.stack(dirss)
+    P = len(srcs)
+    up = torch.randn(P, R, S, generator=torch.Generator().manual_seed(11)).cuda()
+
+    def run(sel):
+        v = torch.from_numpy(vol_np).cuda().requires_grad_(True)
+        s = torch.from_numpy(src[sel]).cuda().requires_grad_(True)
+        d = torch.from_numpy(dirs[sel]).cuda().requires_grad_(True)
+        f = da.render_poses(v, s, d, S, alpha, sampler=sampler, layout="paired")
+        (f * up[sel]).sum().backward()
+        return f.detach(), v.grad, s.grad, d.grad
+
+    f_all, gv_all, gs_all, gd_all = run(list(range(P)))
+    gv_sum = torch.zeros_like(gv_all, dtype=torch.float64)
+    for p in range(P):
+        f1, gv1, gs1, gd1 = run([p])
+        assert torch.equal(f1[0], f_all[p]), p
+        if sampler == "trilinear":
+            assert torch.equal(gs1[0], gs_all[p]) and torch.equal(gd1[0], gd_all[p]), p
+        gv_sum += gv1.double()
+    den = float(gv_sum.abs().max())
+    assert den > 0
+    assert float((gv_all.double() - gv_sum).abs().max()) <= 3e-6 * den       # float32 accumulation order, and the 3-D tile's fixed point
