@@ -61,7 +61,17 @@ for k, seed in enumerate(SEEDS or range(first, first + count)):
             up_ = torch.randn(f_.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
             (f_ * up_.to(dt)).sum().backward()
             gz = lambda t_: (t_.grad if t_.grad is not None else torch.zeros_like(t_)).double().numpy()     # (nearest: no pose gradient)
-            gp_ = p64.grad.abs() if p64.grad is not None else torch.zeros_like(p64)     # |dL/dp| per sample: what the pose sums are made of
+            # d/dsource = sum_k dL/dp_k, d/ddirection = sum_k k dL/dp_k, from the per-sample gradients with grid_sample's border rule
+            # applied (zero where p <= 0 or p >= dim - 1: the convention golden G9 pins; torch.clamp passes the gradient AT the bound,
+            # and a float32 march does land on 0.0 exactly now and then)
+            gp_ = p64.grad.clone() if p64.grad is not None else torch.zeros_like(p64)
+            hi_ = torch.tensor([d - 1.0 for d in vol.shape], dtype=torch.float64).view(1, 1, 3)
+            gp_[(p64.detach() <= 0) | (p64.detach() >= hi_)] = 0.0
+            kk_ = torch.arange(S, dtype=torch.float64).view(1, S, 1)
+            if s_.grad is not None:
+                s_.grad = gp_.sum((0, 1)).to(s_.grad.dtype)
+                d_.grad = (gp_ * kk_).sum(1).to(d_.grad.dtype)
+            gp_ = gp_.abs()                                                                # what the pose sums are made of
             terms = (float(gp_.sum()), float((gp_ * torch.arange(S, dtype=torch.float64).view(1, S, 1)).sum(1).max()))
             return f_.detach(), gz(v_), gz(s_), gz(d_), up_, terms
         f64, ref, rs, rd, up, terms = reference(torch.float64)
