@@ -29,13 +29,18 @@ def maxnorm_rel(a, b):
 
 
 PLANAR = bool(os.environ.get("FUZZ_PLANAR"))      # control: the same cases with the fans left in the slice
+CROPPED = bool(os.environ.get("FUZZ_CROPPED"))    # only the start > 0 cases, decoupled from the source's place
 SEEDS = [int(x) for x in os.environ.get("FUZZ_SEEDS", "").split(",") if x]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad, worst, skipped, conditioned = [], 0.0, 0, 0
 t0 = time.time()
 for k, seed in enumerate(SEEDS or range(first, first + count)):
-    vol, src, dirs, S, start, alpha = _coplanar_case(seed, planar=PLANAR)
+    if CROPPED and seed % 4 != 3:
+        continue
+    # (the generator crops exactly the cases whose source sits beside two faces, where most rays are clamped at once and the
+    # start-crop median ties; FUZZ_CROPPED=1 runs only the cropped cases, with the source anywhere)
+    vol, src, dirs, S, start, alpha = _coplanar_case(seed, planar=PLANAR, where=((seed // 4) % 3) if CROPPED else None)
     vol = np.abs(vol) + 1e5
     # where the reference's own arithmetic puts the sample points: float32 multiply + add for float32 poses, float64 (then a
     # cast) when the source is float64 (torch's promotion, src/renderer.py:119-124)
@@ -83,7 +88,12 @@ for k, seed in enumerate(SEEDS or range(first, first + count)):
                     if pts == "f32" else ar.ray_points(torch.from_numpy(src).double(), torch.from_numpy(dirs).double(), S))
                 first_kept = ar.reflection(imp)[:, start]
                 med = first_kept.median()
-                if int((first_kept == med).sum()) > 1:
+                srt = torch.sort(first_kept)[0]
+                mid = (len(srt) - 1) // 2
+                gaps = [float(srt[j + 1] - srt[j]) for j in (mid - 1, mid) if 0 <= j < len(srt) - 1]
+                # ... or a NEAR tie: a coefficient is dZ / sum Z with |dZ| of a few hundred on Z ~ 1.6e6, good to ~1e-4 in float32 --
+                # two rays closer than that at the median are ordered by rounding, here and in torch's own float32 run alike
+                if int((first_kept == med).sum()) > 1 or (gaps and min(gaps) < 1e-3 * max(abs(float(med)), 1e-30)):
                     skipped += 1
                     continue
         _, n32, ns32, nd32, _, _ = reference(torch.float32)     # the same algorithm in float32: the noise a float32 evaluation carries here
