@@ -597,9 +597,15 @@ def callers_legs(args, vol, dev):
                                                quiet=True, stats=stats, one_pass=one_pass)
             reg[name + "_ms_per_iteration"] = stats["ms_per_iteration"]
             reg[name + "_final"] = {"loss": hist[-1][1], "apex_error_voxels": apex_err, "worst_ray_angle_deg": ang}
+        stats = {}
+        register_run(iters=300, n=n, R=args.rays, S=args.samples, alpha=args.alpha, report=10 ** 9, graph=True, quiet=True, stats=stats,
+                     one_pass=True, poses=args.poses)
+        reg["sweep_one_pass_graph_ms_per_iteration"] = stats["ms_per_iteration"]
+        reg["sweep_poses"] = args.poses
         reg["note"] = ("start 3.0 voxels and 5 degrees (roll + pitch) away from the pose that rendered the target; 400 Adam steps; "
                        "wall time per iteration; one_pass: render + loss + backward as CapturedStep.mse_loss (diffus_render_step_mse, no volume "
-                       "gradient); before csrc/pose.hip the eager iteration was 1.56 ms (profiles/r05_registration_host.txt)")
+                       "gradient); sweep: that many frames (probe positions on a ring) registered together, one FanPose module and one render "
+                       "launch per iteration for all; before csrc/pose.hip the eager iteration was 1.56 ms (profiles/r05_registration_host.txt)")
         out["registration_6dof"] = reg
     except Exception as e:
         out["registration_6dof"] = {"failed": repr(e)}

@@ -301,6 +301,9 @@ def test_full_size_registration_example_descends(da):
     # ... and with render + loss + backward as the one-pass step (CapturedStep.mse_loss): the same numbers again
     hist_o, apex_o, ang_o = mod.run(iters=150, report=149, graph=True, one_pass=True)
     assert abs(hist_o[-1][1] - hist_g[-1][1]) < 0.02 * hist_g[-1][1] and abs(apex_o - apex_g) < 0.02, (hist_o, hist_g)
+    # a sweep of four frames registered together (one FanPose module, one render launch per iteration for all)
+    hist_s, apex_s, ang_s = mod.run(iters=120, report=119, graph=True, one_pass=True, poses=4)
+    assert hist_s[-1][1] < 0.1 * 4 * history[0][1] and ang_s < 4.0 and apex_s < 2.9, (hist_s, apex_s, ang_s)   # (every frame starts like the single one)
 
 
 def _coplanar_case(seed, planar=False, where=None):
