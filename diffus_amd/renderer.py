@@ -527,8 +527,17 @@ class _RenderFn(torch.autograd.Function):
             g = _as(gframe, pb.dev, torch.float32)
             gvol = touched = None
             sparse = False
+            common = pb.common_bwd()
             if need_v:      # gradient buffer in the layout that goes with the volume's
-                if pb.layout == _lib.CANONICAL:
+                if pb.layout == _lib.CANONICAL and layout_fits("bricked", pb.shape):
+                    # a canonical volume's gradient goes through the BRICKED scratch too (DIFFUS_GRAD_BRICKED): its scatter
+                    # accumulates planar and tilted fans in doubles, where the canonical tile is 32-bit fixed point with one scale
+                    # per patch -- 7e-3 off on 0.04-voxel steps whose contributions cancel (tools/fuzz_one_pass.py, seed 55) --
+                    # and the dense hand-back below costs what zeroing a canonical gradient would
+                    gvol, touched = _gradbuf(pb.dev, pb.shape)
+                    sparse = True
+                    common = common[:4] + (common[4] | _lib.GRAD_BRICKED,) + common[5:]
+                elif pb.layout == _lib.CANONICAL:
                     gvol = torch.zeros_like(pb.vol)
                 elif pb._layout_req == "prebricked":
                     gvol = torch.zeros(lib.diffus_bricked_floats(*pb.shape), dtype=torch.float32, device=pb.dev)
@@ -538,7 +547,7 @@ class _RenderFn(torch.autograd.Function):
             gsrc = torch.empty((pb.P, 3), dtype=torch.float32, device=pb.dev) if need_s else None
             gdirs = torch.empty((pb.P, pb.R, 3), dtype=torch.float32, device=pb.dev) if need_d else None
             ws = pb.workspace()
-            rc = lib.diffus_render_bwd(*pb.common_bwd(), _ptr(g), _ptr(gvol), _ptr(touched), _ptr(gsrc), _ptr(gdirs),
+            rc = lib.diffus_render_bwd(*common, _ptr(g), _ptr(gvol), _ptr(touched), _ptr(gsrc), _ptr(gdirs),
                                        _lib.BWD_ALL, _ptr(ws), ws.numel(), _stream(pb.dev))
             _lib.check(rc, "diffus_render_bwd")
             if sparse:      # a fresh dense (d0,d1,d2) gradient in ONE launch: touched bricks' values, zeros elsewhere
