@@ -73,7 +73,7 @@ extern "C" {
                               scratch tiles accumulate planar and tilted fans in doubles (per-voxel bound 4e-6 of the voxel's mass),
                               a canonical `gvol` without this flag goes through a 3-D tile in 32-bit fixed point with one scale per
                               patch of 32 rays x 32 steps (<= 2^-20 of the patch's sum of |contributions| per add: seen 7e-3 of
-                              max |gvol| on 0.04-voxel steps whose contributions cancel).  The Python mirror always sets it. */
+                              max |gvol| on 0.04-voxel steps whose contributions cancel).  The Python mirror sets it by default. */
 
 #define DIFFUS_FANS_PLANAR 0x20 /* backward entry points only, OR'ed into `layout`: a HINT that no ray of the call moves along
                               dim 2 (every fan of the reference: src/cone.py:258 writes a zero dim-2 component).  The volume
