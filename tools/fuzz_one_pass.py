@@ -9,6 +9,7 @@ import diffus_amd as da
 cases = int(sys.argv[1]) if (__name__ == "__main__" and len(sys.argv) > 1) else 100
 rng = np.random.default_rng(int(sys.argv[2]) if (__name__ == "__main__" and len(sys.argv) > 2) else 0)
 worst = {"frame": 0.0, "loss": 0.0, "gvol": 0.0, "gsrc": 0.0, "gdirs": 0.0}
+ill = 0
 def gen_case(rng):
     dims = tuple(int(x) for x in rng.integers(5, 70, 3))
     if rng.random() < 0.15:
@@ -74,6 +75,20 @@ for c in range(cases):
     if c % 500 == 499:
         print("progress", c + 1, {k: "%.1e" % x for k, x in worst.items()}, flush=True)
     if bad:
-        print("MISMATCH case", c, dims, P, R, S, start, sampler, layout, alpha, "f64" if f64 else "f32", e, flush=True)
+        # An echo is the ratio (P_n)01 / (P_n)11 of a running matrix product; where the denominator nearly cancels (|echo| > 8: rays
+        # through white noise like this tool's volumes) float32 loses digits.  The two-call path's FORWARD kernel evaluates such a ray
+        # again in float64, the one-pass step only on request (CapturedStep(repair_frames=True)): there the two are expected to
+        # differ, and the case is re-run with the repair on before it counts as a mismatch.
+        emax = float((f.detach() * torch.exp(alpha * torch.arange(f.shape[-1], device=f.device, dtype=torch.float32))).abs().max())
+        kind = "MISMATCH"
+        if emax > 8.0:
+            rep = da.CapturedStep(v, s, d, S, alpha, sampler, start=start, layout=layout, target=t, loss_scale=scale, repair_frames=True)
+            rep.step()
+            torch.cuda.synchronize()
+            e["frame_repaired"] = rel(rep.frame, f.detach())
+            e["loss_repaired"] = rel(rep.loss, loss.detach())
+            kind = "ILL-CONDITIONED" if (e["frame_repaired"] <= 5e-5 and e["loss_repaired"] <= 1e-4) else "MISMATCH"
+            ill += kind == "ILL-CONDITIONED"
+        print(kind, "case", c, dims, P, R, S, start, sampler, layout, alpha, "f64" if f64 else "f32", "max |echo| %.1f" % emax, e, flush=True)
 if cases:
-    print("cases", cases, "worst relative differences", {k: "%.1e" % x for k, x in worst.items()})
+    print("cases", cases, "worst relative differences", {k: "%.1e" % x for k, x in worst.items()}, "ill-conditioned (equal once repaired):", ill)
