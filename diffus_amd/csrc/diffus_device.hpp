@@ -1143,12 +1143,15 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
 // echo_n = b_n / d_n; on a ray that grazes the skull d_n is nearly cancelled for a sample or two (|echo| = 123 and 287 on the
 // two worst rays of BASELINE config 3, ~0.05 elsewhere) and every float32 evaluation carries (condition number) x eps of
 // noise there -- the reference's own dense LU 4.2e-5 of the ray's peak (golden G19), the wave scan's tree of 2x2 products
-// 2.5x that.  A wave that sees |echo| > kEchoRecheck anywhere (9 rays in 8192 at config 3: max |echo| x eps x ~10 is below
-// 1e-5 of the ray's peak under that) evaluates the SAME scan again in float64 and keeps those echoes: the result is then the
+// 2.5x that.  A wave that sees |echo| > kEchoRecheck anywhere evaluates the SAME scan again in float64 and keeps those echoes: the result is then the
 // float64 series of its float32 reflection coefficients, i.e. better conditioned than any float32 evaluation, the
 // reference's included.  Well-conditioned rays never take the branch and stay bit-identical.
+// The threshold: the float32 evaluation's error grows like 1.5e-5 x |echo| of the ray's peak (tools/fuzz_forward.py: 6.0e-5 against
+// float64 on a ray with |echo| = 4.0, where the oracle's float32 series is at 1e-5); at 8 (rounds 4-5) rays between 3 and 8
+// could exceed the 5e-5 the tests hold a frame to, at 3 none of 24 000 random launches does.  25 rays instead of 9 of config 3's
+// 8192 take the branch: the forward launch 15.4 -> 15.8 us.
 #ifndef DIFFUS_ECHO_RECHECK
-#define DIFFUS_ECHO_RECHECK 8.f
+#define DIFFUS_ECHO_RECHECK 3.f
 #endif
 constexpr float kEchoRecheck = DIFFUS_ECHO_RECHECK;
 struct DMat {

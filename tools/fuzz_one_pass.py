@@ -75,7 +75,7 @@ for c in range(cases):
     if c % 500 == 499:
         print("progress", c + 1, {k: "%.1e" % x for k, x in worst.items()}, flush=True)
     if bad:
-        # An echo is the ratio (P_n)01 / (P_n)11 of a running matrix product; where the denominator nearly cancels (|echo| > 8: rays
+        # An echo is the ratio (P_n)01 / (P_n)11 of a running matrix product; where the denominator nearly cancels (|echo| > 8 here; the kernels' threshold is 3: rays
         # through white noise like this tool's volumes) float32 loses digits.  The two-call path's FORWARD kernel evaluates such a ray
         # again in float64, the one-pass step only on request (CapturedStep(repair_frames=True)): there the two are expected to
         # differ, and the case is re-run with the repair on before it counts as a mismatch.
