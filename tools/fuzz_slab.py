@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz the scatter's slab path (fans that are rigid motions of planar ones, any orientation) against float64 autograd:
 tests/test_tilted_fans.py's `_coplanar_case` generator over many seeds, d/dvolume (bricked gradient), d/dsource, d/ddirections
-of a random upstream gradient, both samplers, at the sample points the reference's own arithmetic produces.  A gradient fails at
+of a random upstream gradient, both samplers, the volume layout by seed, at the sample points the reference's own arithmetic produces.  A gradient fails at
 >= 1e-3 max-norm-relative UNLESS the same algorithm run in float32 by torch is as far off there (within 3x: sources far outside the
 volume put every sample on the border and the reflection coefficients become differences of nearly equal numbers); exact ties at
 the start-crop median are skipped.  Prints one line per failing seed and a progress line every 100 seeds.
@@ -22,6 +22,7 @@ if not os.environ.get("FUZZ_DRY"):
     import diffus_amd as da  # noqa: E402
 from oracle import autograd_ref as ar  # noqa: E402
 from test_tilted_fans import _coplanar_case  # noqa: E402
+from test_hip_random import _case as _random_case  # noqa: E402
 
 
 def maxnorm_rel(a, b):
@@ -29,6 +30,7 @@ def maxnorm_rel(a, b):
 
 
 PLANAR = bool(os.environ.get("FUZZ_PLANAR"))      # control: the same cases with the fans left in the slice
+RANDOM = bool(os.environ.get("FUZZ_RANDOM"))        # tests/test_hip_random.py's generator instead: every ray its own direction (the 3-D tile)
 CROPPED = bool(os.environ.get("FUZZ_CROPPED"))    # only the start > 0 cases, decoupled from the source's place
 SEEDS = [int(x) for x in os.environ.get("FUZZ_SEEDS", "").split(",") if x]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
@@ -36,15 +38,20 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad, worst, skipped, conditioned = [], 0.0, 0, 0
 t0 = time.time()
 for k, seed in enumerate(SEEDS or range(first, first + count)):
-    if CROPPED and seed % 4 != 3:
+    if CROPPED and not RANDOM and seed % 4 != 3:
         continue
     # (the generator crops exactly the cases whose source sits beside two faces, where most rays are clamped at once and the
     # start-crop median ties; FUZZ_CROPPED=1 runs only the cropped cases, with the source anywhere)
-    vol, src, dirs, S, start, alpha = _coplanar_case(seed, planar=PLANAR, where=((seed // 4) % 3) if CROPPED else None)
+    if RANDOM:
+        vol, src, dirs, S, start, alpha = _random_case(seed)
+        S = min(S, 300)
+        start = min(start, S - 2)
+    else:
+        vol, src, dirs, S, start, alpha = _coplanar_case(seed, planar=PLANAR, where=((seed // 4) % 3) if CROPPED else None)
     vol = np.abs(vol) + 1e5
     # where the reference's own arithmetic puts the sample points: float32 multiply + add for float32 poses, float64 (then a
     # cast) when the source is float64 (torch's promotion, src/renderer.py:119-124)
-    pts = "f32" if src.dtype == np.float32 else "exact"
+    pts = "f32" if (src.dtype == np.float32 and dirs.dtype == np.float32) else "exact"
     for sampler in ("trilinear", "nearest"):
         def reference(dt):
             v_ = torch.from_numpy(vol).to(dt).requires_grad_(True)
@@ -53,11 +60,14 @@ for k, seed in enumerate(SEEDS or range(first, first + count)):
             # (the body of ar.render, with everything after the sample points in `dt`)
             if pts == "f32":
                 p64 = ar.ray_points_f32(s_, d_, S)
+            elif dirs.dtype == np.float64:      # float64 directions: the whole march in float64, the sampler's cast at the end (pmode 2)
+                exact = ar.ray_points(s_, d_, S)
+                p64 = exact.detach().float().double() + (exact - exact.detach())
             else:   # float64 source, float32 directions: k * direction is a float32 product, the sum is float64, the sampler casts
                 # the point to float32 (src/renderer.py:119-124, :751; csrc ray_point_f, pmode 1) -- straight-through derivatives
                 exact = ar.ray_points(s_, d_, S)
                 t32 = torch.arange(S, dtype=torch.float32).view(1, S, 1) * torch.from_numpy(dirs).float().unsqueeze(1)
-                p64 = (torch.from_numpy(src).double().view(1, 1, 3) + t32.double()).float().double() + (exact - exact.detach())
+                p64 = (torch.from_numpy(src).double().view(1, 1, 3) + t32.double()).float().double() + (exact - exact.detach())   # (a float32 source is promoted: exact)
             p64.retain_grad()
             p_ = p64.to(dt)
             imp_ = ar.sample_nearest(v_, p_)[0] if sampler == "nearest" else ar.sample_trilinear(v_, p_)
@@ -102,7 +112,7 @@ for k, seed in enumerate(SEEDS or range(first, first + count)):
         v = torch.from_numpy(vol).cuda().requires_grad_(True)
         s = torch.from_numpy(src).cuda().requires_grad_(True)
         d = torch.from_numpy(dirs).cuda().requires_grad_(True)
-        f = da.render_poses(v, s, d, S, alpha, start=start, sampler=sampler, layout="bricked")[0]
+        f = da.render_poses(v, s, d, S, alpha, start=start, sampler=sampler, layout=("bricked", "paired", "canonical")[seed % 3])[0]
         (f * up.float().cuda()).sum().backward()
         gv = v.grad.cpu().numpy()
         errs, noise = {}, {}
