@@ -1,0 +1,53 @@
+"""Cases the round-5 fuzzing campaigns found (tools/fuzz_forward.py, tools/fuzz_one_pass.py; DESIGN facts 44-45), kept as tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxnorm_rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_forward_ray_with_moderate_echo_is_reevaluated(oracle):
+    """tools/fuzz_forward.py seed 1641: a ray with |echo| = 4.0 was 6.0e-5 from float64 (the oracle's float32 series: 1e-5) while
+    the float64 re-evaluation started at |echo| > 8; it starts at 3 now and the frame is inside the usual 5e-5."""
+    import diffus_amd
+    from test_hip_random import _case
+    vol, src, dirs, S, start, alpha = _case(1641)
+    x, y, z, fo = oracle.plot_beam_frame(vol, src, dirs, S, alpha, start, sampler="trilinear")
+    assert 3.0 < float(np.max(np.abs(fo) * np.exp(alpha * np.arange(fo.shape[-1]))[None, :])) < 8.0     # the band the old threshold missed
+    for layout in ("canonical", "bricked", "paired"):
+        f, idx = diffus_amd.render_poses(torch.from_numpy(vol).cuda(), torch.from_numpy(src), torch.from_numpy(dirs), S, alpha,
+                                         start=start, sampler="trilinear", return_indices=True, layout=layout)
+        np.testing.assert_array_equal(idx[0, 0].cpu().numpy(), x)
+        assert maxnorm_rel(f[0].cpu().numpy(), fo) < 5e-5, layout
+
+
+@pytest.mark.parametrize("case,bar", [(1719, 1.5e-3), (9860, 1e-3)])
+def test_canonical_volume_gradient_on_tiny_steps(case, bar):
+    """tools/fuzz_one_pass.py seed 55, cases 1719 and 9860: canonical volumes marched in 0.03-0.04-voxel steps (thousands of
+    contributions per voxel that cancel).  Through the 3-D tile of the canonical gradient (32-bit fixed point, one scale per patch)
+    `render_poses -> backward` was 7.5e-3 / 2.7e-3 from float64; through the bricked scratch (doubles) it is where the other
+    layouts are."""
+    import diffus_amd as da
+    from oracle import autograd_ref as ar
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_one_pass as fz
+    rng = np.random.default_rng(55)
+    for _ in range(case + 1):
+        k = fz.gen_case(rng)
+    dims, P, R, S, start, sampler, alpha, vol, tgt, scale, f64 = (k[x] for x in ("dims", "P", "R", "S", "start", "sampler", "alpha", "vol", "tgt", "scale", "f64"))
+    assert k["layout"] == "canonical" and P == 1
+    src, dirs = k["src"], k["dirs"]
+    v = torch.from_numpy(vol).cuda().requires_grad_(True)
+    f = da.render_poses(v, torch.from_numpy(src).cuda(), torch.from_numpy(dirs).cuda(), S, alpha, start=start, sampler=sampler, layout="canonical")
+    (scale * ((f - torch.from_numpy(tgt).cuda()) ** 2).sum()).backward()
+    v64 = torch.from_numpy(vol).double().requires_grad_(True)
+    f64_ = ar.render(v64, torch.from_numpy(src[0]).double(), torch.from_numpy(dirs[0]).double(), S, alpha, start, sampler,
+                     points="exact" if f64 else "f32")
+    (scale * ((f64_ - torch.from_numpy(tgt[0]).double()) ** 2).sum()).backward()
+    assert maxnorm_rel(v.grad.cpu().numpy(), v64.grad.numpy()) < bar
