@@ -1188,8 +1188,10 @@ __device__ __forceinline__ DMat dmat_dpp_ident(const DMat &m) // the identity wh
 }
 // r[j]: the reflection coefficient entering sample n = lane * C + j (0 where there is none); e[j] gets echo_n (NaN -> 0,
 // reference :408).  carry: a product that precedes the whole wave (nullable).
+// last (nullable): gets the product up to and including the wave's last sample, every lane the same value (the carry of the next
+// piece of a row that is walked in several).
 template <int C, typename T>
-__device__ __forceinline__ void echo_chunk_f64(const T (&r)[C], int lane, float (&e)[C], const DMat *carry = nullptr)
+__device__ __forceinline__ void echo_chunk_f64(const T (&r)[C], int lane, float (&e)[C], const DMat *carry = nullptr, DMat *last = nullptr)
 {
     DMat L{1.0, 0.0, 0.0, 1.0};
 #pragma unroll
@@ -1215,6 +1217,15 @@ __device__ __forceinline__ void echo_chunk_f64(const T (&r)[C], int lane, float 
         if ((j & 3) == 3) dmat_renorm(Pm);
         const double v = Pm.b / Pm.d;
         e[j] = (v == v) ? (float)v : 0.f;
+    }
+    if (last) {
+        dmat_renorm(Pm);
+        auto bc = [](double x) {
+            const long long b = __double_as_longlong(x);
+            const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), kWave - 1), hi = __builtin_amdgcn_readlane((int)(b >> 32), kWave - 1);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
+        *last = DMat{bc(Pm.a), bc(Pm.b), bc(Pm.c), bc(Pm.d)};
     }
 }
 // The float64 series of such a ray from its float32 impedance samples -- the samples taken AGAIN, with the stage-wise sampler

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
     const int lane = threadIdx.x & 63;
     // rows longer than 64*C samples: the wave walks them in pieces, the running product stays in registers
     Mat K = mat_identity();
+    bool again = false; // a row of several pieces with an ill-conditioned echo somewhere: walked a second time in float64 below
     for (int base = 0; base <= N; base += kWave * C) {
         const int n0 = base + lane * C;
         float r[C], e[C];
@@ -204,11 +205,35 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
         Mat Kl = K;
         echo_chunk<C>(r, lane, e, base ? &K : nullptr, kWave * C - 1, &Kl);
         K = mat_lane_bcast(Kl, kWave - 1);
-        if (N < kWave * C && __builtin_expect(echo_needs_f64<C>(e), 0)) echo_chunk_f64<C>(r, lane, e); // rows of one piece; diffus_device.hpp (a stage-wise kernel: inlined)
+        if (__builtin_expect(echo_needs_f64<C>(e), 0)) {
+            if (N < kWave * C) echo_chunk_f64<C>(r, lane, e); // rows of one piece: in place; diffus_device.hpp (a stage-wise kernel: inlined)
+            else again = true;
+        }
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = n0 + j;
             if (n <= N) echo[w * (N + 1) + n] = e[j];
+        }
+    }
+    if (__builtin_expect(again, 0)) { // (wave-uniform) the whole row again, the running product carried from piece to piece in float64
+        DMat Kd{1.0, 0.0, 0.0, 1.0};
+#pragma unroll 1
+        for (int base = 0; base <= N; base += kWave * C) {
+            const int n0 = base + lane * C;
+            float r[C], e[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                int n = n0 + j;
+                r[j] = (n >= 1 && n <= N) ? rin[w * N + n - 1] : 0.f;
+            }
+            DMat nextK;
+            echo_chunk_f64<C>(r, lane, e, base ? &Kd : nullptr, &nextK);
+            Kd = nextK;
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                int n = n0 + j;
+                if (n <= N) echo[w * (N + 1) + n] = e[j];
+            }
         }
     }
 }

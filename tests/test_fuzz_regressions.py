@@ -51,3 +51,23 @@ def test_canonical_volume_gradient_on_tiny_steps(case, bar):
                      points="exact" if f64 else "f32")
     (scale * ((f64_ - torch.from_numpy(tgt[0]).double()) ** 2).sum()).backward()
     assert maxnorm_rel(v.grad.cpu().numpy(), v64.grad.numpy()) < bar
+
+
+@pytest.mark.parametrize("seed", [344, 485, 1575, 2207, 2573, 2650])
+def test_long_rows_with_ill_conditioned_echoes(oracle, seed):
+    """tools/fuzz_echo.py: rows of 1024 ... 3000 samples (walked in 1024-sample pieces) with |echo| of 25 ... 656 somewhere were
+    2e-4 ... 2e-2 from float64 -- the float64 re-evaluation existed for rows of one piece only.  Such a row is now walked a second time
+    with its running product carried from piece to piece in float64."""
+    import diffus_amd as da
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_echo
+    r, _ = fuzz_echo.gen(seed)
+    assert r.shape[1] >= 1024
+    e = da.compute_echo_traces(torch.from_numpy(r).cuda())[0].cpu().numpy()
+    with np.errstate(all="ignore"):
+        ref = oracle.echo_scan(r.astype(np.float64), np.float64)
+        o32 = oracle.echo_scan(r, np.float32)
+    assert float(np.max(np.abs(ref))) > 20.0
+    for i in range(r.shape[0]):
+        tol = max(2e-5, 30 * maxnorm_rel(o32[i], ref[i]))
+        assert maxnorm_rel(e[i], ref[i]) < tol, (seed, i)
