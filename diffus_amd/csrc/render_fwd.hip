@@ -194,18 +194,28 @@ __global__ __launch_bounds__(kBlock) void echo_traces_kernel(const float *__rest
     // rows longer than 64*C samples: the wave walks them in pieces, the running product stays in registers
     Mat K = mat_identity();
     bool again = false; // a row of several pieces with an ill-conditioned echo somewhere: walked a second time in float64 below
+    // Strong reflectors at MANY samples (coefficients nothing like tissue's: white noise of |r| ~ 0.3 and more) make the running
+    // product numerically rank one -- det P = prod (1 - r^2) against entries of order one --, and the wave scan multiplies PARTIAL
+    // products of that kind with each other: up to 200x the error of a sequential float32 evaluation (tools/fuzz_echo.py), with
+    // |echo| itself unremarkable.  bits = -log2 det P so far; a skull crossed twice and an air interface are ~15, 512 samples of
+    // |r| <= 0.3 are ~33: beyond kCondBits the row takes the float64 path like an ill-conditioned echo does.
+    constexpr float kCondBits = 20.f;
+    float bits = 0.f;
     for (int base = 0; base <= N; base += kWave * C) {
         const int n0 = base + lane * C;
         float r[C], e[C];
+        float lb = 0.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             int n = n0 + j;
             r[j] = (n >= 1 && n <= N) ? rin[w * N + n - 1] : 0.f;
+            lb -= __builtin_amdgcn_logf(fmaxf(fabsf(1.f - r[j] * r[j]), 0x1p-24f)); // (v_log_f32: log2; a NaN coefficient counts 24 bits)
         }
+        bits += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63(lb)), kWave - 1));
         Mat Kl = K;
         echo_chunk<C>(r, lane, e, base ? &K : nullptr, kWave * C - 1, &Kl);
         K = mat_lane_bcast(Kl, kWave - 1);
-        if (__builtin_expect(echo_needs_f64<C>(e), 0)) {
+        if (__builtin_expect(echo_needs_f64<C>(e) || bits > kCondBits, 0)) {
             if (N < kWave * C) echo_chunk_f64<C>(r, lane, e); // rows of one piece: in place; diffus_device.hpp (a stage-wise kernel: inlined)
             else again = true;
         }
