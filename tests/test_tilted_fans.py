@@ -356,7 +356,9 @@ def test_random_coplanar_fans_vs_float64_autograd(da, seed):
         v64 = torch.from_numpy(vol).double().requires_grad_(True)
         s64 = torch.from_numpy(src).double().requires_grad_(True)
         d64 = torch.from_numpy(dirs).double().requires_grad_(True)
-        f64 = ar.render(v64, s64, d64, S, alpha, start, sampler)
+        # (float32 poses: the reference's float32 march decides where the samples are -- one ulp elsewhere can put a sample on the
+        # other side of a cell boundary, where the trilinear gradient jumps, or flip a nearest index: tools/fuzz_slab.py)
+        f64 = ar.render(v64, s64, d64, S, alpha, start, sampler, points="f32" if src.dtype == np.float32 else "exact")
         up = torch.randn(f64.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
         (f64 * up).sum().backward()
         ref = v64.grad.numpy()
@@ -377,7 +379,7 @@ def test_random_coplanar_fans_vs_float64_autograd(da, seed):
                 assert maxnorm_rel(d.grad.cpu().numpy(), d64.grad.numpy()) < 1e-3, (seed, layout)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", list(range(8)) + list(range(100, 108)))
 def test_random_coplanar_fans_medium_size(da, seed):
     """The same sweep at sizes where patches fill their tiles, need several passes (faces + inside) and row chunks: volumes of
     100-200 voxels a side, 96 rays x 400 steps of 1-2.5 voxels, any orientation; trilinear, bricked gradient."""
@@ -401,7 +403,7 @@ def test_random_coplanar_fans_medium_size(da, seed):
     v64 = torch.from_numpy(vol).double().requires_grad_(True)
     s64 = torch.from_numpy(src).double().requires_grad_(True)
     d64 = torch.from_numpy(dirs).double().requires_grad_(True)
-    f64 = ar.render(v64, s64, d64, S, alpha, 0, "trilinear")
+    f64 = ar.render(v64, s64, d64, S, alpha, 0, "trilinear", points="f32")       # at the float32 march's sample points (see above)
     (f64 ** 2).sum().backward()
     v = torch.from_numpy(vol).cuda().requires_grad_(True)
     s = torch.from_numpy(src).cuda().requires_grad_(True)
