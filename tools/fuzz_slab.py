@@ -22,7 +22,7 @@ if not os.environ.get("FUZZ_DRY"):
     import diffus_amd as da  # noqa: E402
 from oracle import autograd_ref as ar  # noqa: E402
 from test_tilted_fans import _coplanar_case  # noqa: E402
-from test_hip_random import _case as _random_case  # noqa: E402
+from test_hip_random import _case as _random_case, _long_case  # noqa: E402
 
 
 def maxnorm_rel(a, b):
@@ -30,7 +30,8 @@ def maxnorm_rel(a, b):
 
 
 PLANAR = bool(os.environ.get("FUZZ_PLANAR"))      # control: the same cases with the fans left in the slice
-RANDOM = bool(os.environ.get("FUZZ_RANDOM"))        # tests/test_hip_random.py's generator instead: every ray its own direction (the 3-D tile)
+LONG = bool(os.environ.get("FUZZ_LONG"))            # tests/test_hip_random.py's long rays: 1025 ... 2600 samples, chained launches
+RANDOM = bool(os.environ.get("FUZZ_RANDOM")) or LONG        # tests/test_hip_random.py's generator instead: every ray its own direction (the 3-D tile)
 CROPPED = bool(os.environ.get("FUZZ_CROPPED"))    # only the start > 0 cases, decoupled from the source's place
 SEEDS = [int(x) for x in os.environ.get("FUZZ_SEEDS", "").split(",") if x]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
@@ -43,9 +44,10 @@ for k, seed in enumerate(SEEDS or range(first, first + count)):
     # (the generator crops exactly the cases whose source sits beside two faces, where most rays are clamped at once and the
     # start-crop median ties; FUZZ_CROPPED=1 runs only the cropped cases, with the source anywhere)
     if RANDOM:
-        vol, src, dirs, S, start, alpha = _random_case(seed)
-        S = min(S, 300)
-        start = min(start, S - 2)
+        vol, src, dirs, S, start, alpha = _long_case(seed) if LONG else _random_case(seed)
+        if not LONG:
+            S = min(S, 300)
+            start = min(start, S - 2)
     else:
         vol, src, dirs, S, start, alpha = _coplanar_case(seed, planar=PLANAR, where=((seed // 4) % 3) if CROPPED else None)
     vol = np.abs(vol) + 1e5
