@@ -1238,8 +1238,12 @@ __device__ __forceinline__ void echo_chunk_f64(const T (&r)[C], int lane, float 
 // sample requested before the first is used, no IEEE division.  (As a called function the kernels inherit its 178 VGPRs; with
 // rolled loops that sample one point at a time the nine such waves of config 3 held the scan kernel for 25 us.)
 // CHUNKED mapping: lane owns samples n0 .. n0 + C - 1 of the segment; e[j] gets echo_n (NaN -> 0).
+// A ray walked in several pieces (render_fwd_long_repair_kernel): carry = the float64 product of the earlier pieces, zcarry = their
+// last impedance sample; last / zlast receive this piece's (all lanes the same values).
 template <int C, int SAMPLER, int LAYOUT, int PM>
-__device__ __forceinline__ void echo_f64_rare(const Args &A, const Pose &ps, int seg0, int segN, int n0, float medv, float (&e)[C])
+__device__ __forceinline__ void echo_f64_rare(const Args &A, const Pose &ps, int seg0, int segN, int n0, float medv, float (&e)[C],
+                                              const DMat *carry = nullptr, DMat *last = nullptr, const float *zcarry = nullptr,
+                                              float *zlast = nullptr)
 {
     const int lane = n0 / C;
     // all samples first (one memory round trip: a wave that takes this path is the kernel's tail), then the coefficients
@@ -1253,7 +1257,15 @@ __device__ __forceinline__ void echo_f64_rare(const Args &A, const Pose &ps, int
         else
             z[j] = tri_sample<LAYOUT, false>(A.vol, A.G, p0, p1, p2).v;
     }
-    const float zprev = lane_prev(z[C - 1], z[C - 1]);
+    float zprev = lane_prev(z[C - 1], z[C - 1]);
+    if (zcarry && lane == 0) zprev = *zcarry;
+    if (zlast) { // the sample at segN - 1 (lane and slot wave-uniform)
+        const int ll = (segN - 1) / C, lj = (segN - 1) % C;
+        float zl = z[0];
+#pragma unroll
+        for (int j = 1; j < C; ++j) zl = (j == lj) ? z[j] : zl;
+        *zlast = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zl), ll));
+    }
     double r[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) {
@@ -1283,6 +1295,10 @@ __device__ __forceinline__ void echo_f64_rare(const Args &A, const Pose &ps, int
 #undef DIFFUS_ROUND
     DMat Pm{dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.a), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.b), dpp_mov_d<kDppWaveShr1, 0xf>(0.0, L.c),
             dpp_mov_d<kDppWaveShr1, 0xf>(1.0, L.d)}; // exclusive prefix; lane 0: identity
+    if (carry) {
+        Pm = dmat_mul(*carry, Pm);
+        dmat_renorm(Pm);
+    }
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         Pm = dmat_step(Pm, r[j]);
@@ -1290,6 +1306,15 @@ __device__ __forceinline__ void echo_f64_rare(const Args &A, const Pose &ps, int
         // b and d are accurate now; their quotient needs no more than float32 (entries are within 2^4 of 1 in magnitude range)
         const float v = fast_div((float)Pm.b, (float)Pm.d);
         e[j] = (v == v) ? v : 0.f;
+    }
+    if (last) { // (coefficients past segN are 0: identity steps -- lane 63 ends on the product up to the piece's last sample)
+        dmat_renorm(Pm);
+        auto bc = [](double x) {
+            const long long b = __double_as_longlong(x);
+            const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), kWave - 1), hi = __builtin_amdgcn_readlane((int)(b >> 32), kWave - 1);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
+        *last = DMat{bc(Pm.a), bc(Pm.b), bc(Pm.c), bc(Pm.d)};
     }
 }
 // wave-uniform: does any lane hold an echo that asks for the float64 evaluation?

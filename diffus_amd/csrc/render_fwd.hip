@@ -93,9 +93,13 @@ __global__ __launch_bounds__(kWave *WPB, (C <= 8 ? DIFFUS_FWD_MIN_WAVES : 1)) vo
         echo_chunk<C, true>(r, lane, e, nullptr, -1, nullptr, exchange);
     } else {
         echo_chunk<C, true>(r, lane, e, cin ? &K : nullptr, segN - 1, cout ? &Klast : nullptr);
-        // an ill-conditioned ray (wave-uniform, rare): the same scan in float64 (diffus_device.hpp).  Rays of one launch only
-        // (SEG / SPLIT rays would need their carries in float64 as well: they keep the float32 series)
-        if (!SEG && __builtin_expect(echo_needs_f64<C>(e), 0)) echo_f64_rare<C, SAMPLER, LAYOUT, PM>(A, ps, seg0, segN, n0, medv, e);
+        // an ill-conditioned ray (wave-uniform, rare): the same scan in float64 (diffus_device.hpp).  A ray of one launch: in place; a
+        // ray of several (SEG) is flagged and walked again from its first sample by render_fwd_long_repair_kernel, its running
+        // product carried in float64 (a float32 carry would bring its own rounding times the ray's condition number along)
+        if (__builtin_expect(echo_needs_f64<C>(e), 0)) {
+            if (!SEG) echo_f64_rare<C, SAMPLER, LAYOUT, PM>(A, ps, seg0, segN, n0, medv, e);
+            else if (A.rflag && lane == 0) A.rflag[w * 2] = 1; // a ray of several launches: render_fwd_long_repair_kernel walks it again
+        }
     }
 #endif
     if (cout) { // hand the running product and the last impedance sample to the next segment
@@ -405,6 +409,48 @@ __global__ __launch_bounds__(kBlock) void sample_points_kernel(const float *__re
     }
 }
 
+// Rays of more than DIFFUS_MAX_SAMPLES samples go through render_fwd_kernel in chained launches whose carries are float32.  Those a
+// launch flagged (|echo| > kEchoRecheck somewhere) are walked again here, one wave per ray, piece after piece from the first sample,
+// the running product carried in float64 and the samples re-taken with the stage-wise sampler (echo_f64_rare): the frame row is
+// rewritten whole.
+template <int SAMPLER, int LAYOUT, int PM>
+__global__ __launch_bounds__(kBlock) void render_fwd_long_repair_kernel(Args A)
+{
+    constexpr int C = 16;
+    const long w = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (w >= (long)A.P * A.R) return;
+    if (__builtin_amdgcn_readfirstlane(A.rflag[w * 2]) == 0) return; // (wave-uniform)
+    const int lane = threadIdx.x & 63, n0 = lane * C;
+    const long pose = w / A.R;
+    Pose ps;
+    load_pose<PM>(ps, A.src, A.src_f64, A.dirs, A.dir_f64, pose, w);
+    const float medv = (A.start > 0) ? A.med[pose] : 0.f;
+    DMat K{1.0, 0.0, 0.0, 1.0};
+    float zc = 0.f;
+#pragma unroll 1
+    for (int seg0 = 0; seg0 < A.N1; seg0 += kWave * C) {
+        const int segN = min(A.N1 - seg0, kWave * C);
+        float e[C], znext;
+        DMat Knext;
+        echo_f64_rare<C, SAMPLER, LAYOUT, PM>(A, ps, seg0, segN, n0, medv, e, seg0 ? &K : nullptr, &Knext, seg0 ? &zc : nullptr, &znext);
+        K = Knext;
+        zc = znext;
+        float att[C];
+        chunk_attenuation<C>(A, seg0 + n0, att);
+#pragma unroll
+        for (int j = 0; j < C; ++j) e[j] = __fmul_rn(e[j], att[j]);
+        store_chunk<C, true>(A.frame + w * A.N1 + seg0, n0, segN, e);
+    }
+}
+
+template <int SM, int LY, int PM>
+int launch_fwd_long_repair_t(const Args &A, hipStream_t st)
+{
+    const long waves = (long)A.P * A.R;
+    hipLaunchKernelGGL((render_fwd_long_repair_kernel<SM, LY, PM>), dim3((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, st, A);
+    return last_launch();
+}
+
 template <int SM, int LY, int PM>
 int launch_fwd_t(const Args &A, hipStream_t st)
 {
@@ -448,6 +494,17 @@ int diffus::launch_fwd(const Args &A, int sampler, int layout, hipStream_t st)
         return f32 ? launch_fwd_t<SM, LY, 0>(A, st) : launch_fwd_t<SM, LY, 1>(A, st);
     });
 }
+
+namespace {
+int launch_fwd_long_repair(const Args &A, int sampler, int layout, hipStream_t st)
+{
+    const bool f32 = !A.src_f64 && !A.dir_f64;
+    return dispatch_sl(sampler, layout, [&](auto S_, auto L_) {
+        constexpr int SM = decltype(S_)::value, LY = decltype(L_)::value;
+        return f32 ? launch_fwd_long_repair_t<SM, LY, 0>(A, st) : launch_fwd_long_repair_t<SM, LY, 1>(A, st);
+    });
+}
+} // namespace
 
 extern "C" {
 
@@ -497,12 +554,22 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout, cons
     }
     // rays longer than one launch covers: segments of DIFFUS_MAX_SAMPLES chained through the running product
     const size_t wr = (size_t)P * R;
+    if (ws.nseg > 1) { // ... whose launches flag the rays with an ill-conditioned echo for the float64 walk below
+        if (hipMemsetAsync(ws.rflag, 0, sizeof(int) * wr * 2, st) != hipSuccess) return DIFFUS_ELAUNCH;
+        A.rflag = ws.rflag;
+    }
     for (int s = 0; s < ws.nseg; ++s) {
         A.seg0 = s * DIFFUS_MAX_SAMPLES;
         A.segN = (s == ws.nseg - 1) ? A.N1 - A.seg0 : DIFFUS_MAX_SAMPLES;
         A.cin = s ? ws.carry + (size_t)(s - 1) * wr * 5 : nullptr;
         A.cout = (s + 1 < ws.nseg) ? ws.carry + (size_t)s * wr * 5 : nullptr;
         rc = diffus::launch_fwd(A, sampler, layout, st);
+        if (rc) return rc;
+    }
+    if (ws.nseg > 1) {
+        A.seg0 = 0;
+        A.segN = A.N1;
+        rc = launch_fwd_long_repair(A, sampler, layout, st);
         if (rc) return rc;
     }
     return DIFFUS_OK;

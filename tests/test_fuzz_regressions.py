@@ -71,3 +71,41 @@ def test_long_rows_with_ill_conditioned_echoes(oracle, seed):
     for i in range(r.shape[0]):
         tol = max(2e-5, 30 * maxnorm_rel(o32[i], ref[i]))
         assert maxnorm_rel(e[i], ref[i]) < tol, (seed, i)
+
+
+@pytest.mark.parametrize("seed,row", [(2207, 2), (344, 1), (2573, 0)])
+def test_long_ill_conditioned_rays_are_walked_again_in_float64(oracle, seed, row):
+    """Rays of more than 1024 samples go through the forward kernel in chained launches with float32 carries; those with an
+    ill-conditioned echo somewhere (here |echo| of 345 ... 656: an impedance profile built from the coefficient rows tools/fuzz_echo.py
+    found) are flagged and walked again from the first sample with the running product carried in float64
+    (render_fwd_long_repair_kernel).  The sequential float32 oracle is 2e-3 ... 4e-3 from float64 on these rays; the kernels 5e-5."""
+    import diffus_amd as da
+    from oracle import autograd_ref as ar
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_echo
+    rr = fuzz_echo.gen(seed)[0][row].astype(np.float64)
+    Z = np.empty(len(rr) + 1)
+    Z[0] = 1.5e6
+    for n in range(len(rr)):
+        Z[n + 1] = Z[n] * (1 + rr[n]) / (1 - rr[n])
+    vol = Z.astype(np.float32).reshape(1, 1, -1)
+    S = vol.shape[2]
+    assert S > 1024
+    src = np.zeros(3, np.float32)
+    dirs = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0]], np.float32)
+    for sampler in ("nearest", "trilinear"):
+        f64 = ar.render(torch.from_numpy(vol).double(), torch.from_numpy(src).double(), torch.from_numpy(dirs).double(), S, 1e-4, 0,
+                        sampler, points="f32").numpy()
+        assert float(np.max(np.abs(f64) * np.exp(1e-4 * np.arange(S))[None, :])) > 100.0
+        x, y, z, fo = oracle.plot_beam_frame(vol, src, dirs, S, 1e-4, 0, sampler=sampler)
+        assert maxnorm_rel(fo, f64) > 1e-3                                   # what float32 carries cost on such a ray
+        for layout in ("canonical", "bricked", "paired"):
+            f = da.render_poses(torch.from_numpy(vol).cuda(), torch.from_numpy(src), torch.from_numpy(dirs), S, 1e-4, sampler=sampler,
+                                layout=layout)[0].cpu().numpy()
+            assert maxnorm_rel(f, f64) < 5e-5, (sampler, layout, maxnorm_rel(f, f64))
+    # ... with a start crop (the per-pose median replaces the first kept coefficient, reference :237-244) and a float64 source
+    src64 = np.zeros(3, np.float64)
+    f64 = ar.render(torch.from_numpy(vol).double(), torch.from_numpy(src64), torch.from_numpy(dirs).double(), S, 1e-4, 3, "trilinear").numpy()
+    f = da.render_poses(torch.from_numpy(vol).cuda(), torch.from_numpy(src64), torch.from_numpy(dirs), S, 1e-4, start=3, sampler="trilinear",
+                        layout="paired")[0].cpu().numpy()
+    assert maxnorm_rel(f, f64) < 5e-5

@@ -19,7 +19,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import diffus_amd as da  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from oracle import autograd_ref as ar  # noqa: E402
-from test_hip_random import _case  # noqa: E402
+from test_hip_random import _case, _long_case  # noqa: E402
+
+LONG = bool(os.environ.get("FUZZ_LONG"))      # rays of 1025 ... 2600 samples (chained launches + the float64 walk of flagged rays)
 
 orc.build()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -28,7 +30,7 @@ bad = ill = checked = cond = 0
 worst = 0.0
 t0 = time.time()
 for k, seed in enumerate(range(first, first + count)):
-    vol, src, dirs, S, start, alpha = _case(seed)
+    vol, src, dirs, S, start, alpha = _long_case(seed) if LONG else _case(seed)
     for sampler in ("nearest", "trilinear"):
         x, y, z, fo = orc.plot_beam_frame(vol, src, dirs, S, alpha, start, sampler=sampler)
         finite = bool(np.all(np.isfinite(fo)))
