@@ -1051,7 +1051,7 @@ def verify_step(args, vol_of_pose, src_all, dirs_all, local_lo, hp, losses_all, 
         frames.append({"pose": int(local_lo + q), "rel_err": err, "tol": tol})
         ok &= err <= tol
     # the same poses through the FORWARD kernel (diffus_render_fwd: what plot_beam_frame / render_poses return).  It evaluates
-    # ill-conditioned rays (|echo| > 2: fans that graze the skull) again in float64 inside the kernel; the one-pass training step
+    # ill-conditioned rays (|echo| > 1: fans that graze the skull) again in float64 inside the kernel; the one-pass training step
     # timed above does not unless asked to (DIFFUS_BWD_REPAIR_FRAME, ~10 us per step) -- its frame is a by-product.  Tolerance:
     # 5e-5 (the reference's own float32 result is 4.2e-5 from this on pose 18, golden G19).
     fwd_frames = []

@@ -176,7 +176,7 @@ class CapturedStep:
         # correctness); "oblique" -- the launch that also carries the slab path for fans that leave the slice; "auto" -- look
         # at the directions now (one readback) and again never: set_poses() with new directions makes the answer unknown,
         # and unknown means the slab-capable launch.
-        # repair_frames: the one-pass step evaluates the frame rows of ILL-CONDITIONED rays (a ray grazing the skull: |echo| > 2)
+        # repair_frames: the one-pass step evaluates the frame rows of ILL-CONDITIONED rays (a ray grazing the skull: |echo| > 1)
         # again in float64 (DIFFUS_BWD_REPAIR_FRAME) -- what the forward kernel does by itself; here it costs ~10 us per step
         self.repair_frames = bool(repair_frames)
         if fans not in ("auto", "planar", "oblique"):

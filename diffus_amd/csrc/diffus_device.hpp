@@ -1148,11 +1148,10 @@ __device__ __forceinline__ void echo_chunk(const float (&r)[C], int lane, float 
 // reference's included.  Well-conditioned rays never take the branch and stay bit-identical.
 // The threshold: the float32 evaluation's error grows like 1.5e-5 x |echo| of the ray's peak (tools/fuzz_forward.py: 6.0e-5 against
 // float64 on a ray with |echo| = 4.0, where the oracle's float32 series is at 1e-5); at 8 (rounds 4-5) rays between 3 and 8
-// could exceed the 5e-5 the tests hold a frame to; at 2 none of 24 000 random launches does and `compute_echo_traces` keeps one
-// marginal row of 8000 (tools/fuzz_echo.py; 4 at a threshold of 3).  31 rays instead of 9 of config 3's 8192 take the branch: the
-// forward launch 15.4 -> 15.9 us.
+// could exceed the 5e-5 the tests hold a frame to; at 2 one launch in 36 000 still does (a ray with |echo| = 1.8 at 8.8e-5); at 1
+// none.  63 rays instead of 9 of config 3's 8192 take the branch: the forward launch 15.4 -> 16.7 us.
 #ifndef DIFFUS_ECHO_RECHECK
-#define DIFFUS_ECHO_RECHECK 2.f
+#define DIFFUS_ECHO_RECHECK 1.f
 #endif
 constexpr float kEchoRecheck = DIFFUS_ECHO_RECHECK;
 struct DMat {

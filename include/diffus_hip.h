@@ -214,7 +214,7 @@ int diffus_render_fwd(const float *vol, int d0, int d1, int d2, int layout,
 #define DIFFUS_BWD_ALL     3
 #define DIFFUS_BWD_KEEP_MEDIAN 4
 #define DIFFUS_BWD_REPAIR_FRAME 8 /* diffus_render_step_mse only, OR'ed into `stages`: rays whose echo series is ILL-CONDITIONED
-                                     (|echo| > 2 somewhere: a ray grazing the skull, echo = b/d with d nearly cancelled -- 31 rays of
+                                     (|echo| > 1 somewhere: a ray grazing the skull, echo = b/d with d nearly cancelled -- 63 rays of
                                      8192 at BASELINE config 3) get their frame row and loss term evaluated again in float64, from
                                      float32 samples taken with the reference's own lerp sequence (reference src/renderer.py:33,
                                      :407-457; golden G19).  Every float32 evaluation -- the reference's dense LU included -- carries

@@ -378,7 +378,16 @@ def test_start_crop_backward_reuses_the_forwards_median(Step, sampler):
     f = da.render_poses(v, sa, dd, S, alpha, start=start, sampler=sampler, layout="paired")
     (f ** 2).sum().backward()
     torch.cuda.synchronize()
-    assert torch.equal(f.detach(), hp.frame)
+    # the same frame bit for bit -- except on rays with |echo| > 1 somewhere, which the FORWARD kernel evaluates again in float64 and
+    # the one-pass step only on request (DESIGN fact 45): those agree to the float32 scan's noise there
+    fd = f.detach()
+    echo = fd.abs() * torch.exp(alpha * torch.arange(fd.shape[-1], device=fd.device, dtype=torch.float32))
+    well = echo.amax(dim=-1) <= 1.0
+    assert int(well.sum()) >= well.numel() - 8
+    assert torch.equal(fd[well], hp.frame[well])
+    if not bool(well.all()):
+        peak = fd[~well].abs().amax(dim=-1, keepdim=True)
+        assert float(((fd[~well] - hp.frame[~well]).abs() / peak).max()) <= 3e-4
     assert float(hp.gvol.abs().max()) > 0
     assert float((hp.gvol - v.grad).abs().max()) <= 2e-5 * float(v.grad.abs().max())
     if sampler == "trilinear":

@@ -2,7 +2,7 @@
 """Fuzz the FORWARD path (diffus_render_fwd through render_poses) against the C oracle: tests/test_hip_random.py's `_case`
 generator over many seeds -- odd volume shapes, any directions (non-unit, zero), sources far outside, crops, f32 / f64 poses,
 air pockets -- both samplers, all three volume layouts: index planes bit-exact, frames <= 5e-5 of the frame's peak (rays whose
-echo series is ill-conditioned, |echo| > 8 (well above the kernels' float64 re-evaluation threshold of 2), are counted separately and held to 3e-4: the pinned tolerance of golden G19).
+echo series is ill-conditioned, |echo| > 8 (well above the kernels' float64 re-evaluation threshold of 1), are counted separately and held to 3e-4: the pinned tolerance of golden G19).
 
     python tools/fuzz_forward.py [first_seed] [count]
 """

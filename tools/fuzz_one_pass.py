@@ -75,13 +75,13 @@ for c in range(cases):
     if c % 500 == 499:
         print("progress", c + 1, {k: "%.1e" % x for k, x in worst.items()}, flush=True)
     if bad:
-        # An echo is the ratio (P_n)01 / (P_n)11 of a running matrix product; where the denominator nearly cancels (|echo| > 2: rays
+        # An echo is the ratio (P_n)01 / (P_n)11 of a running matrix product; where the denominator nearly cancels (|echo| > 1: rays
         # through white noise like this tool's volumes) float32 loses digits.  The two-call path's FORWARD kernel evaluates such a ray
         # again in float64, the one-pass step only on request (CapturedStep(repair_frames=True)): there the two are expected to
         # differ, and the case is re-run with the repair on before it counts as a mismatch.
         emax = float((f.detach().double() * torch.exp(alpha * torch.arange(f.shape[-1], device=f.device, dtype=torch.float64))).abs().max())   # (float64: exp(0.5 * 1023) is beyond float32)
         kind = "MISMATCH"
-        if emax > 2.0:
+        if emax > 1.0:
             rep = da.CapturedStep(v, s, d, S, alpha, sampler, start=start, layout=layout, target=t, loss_scale=scale, repair_frames=True)
             rep.step()
             torch.cuda.synchronize()

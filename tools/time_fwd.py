@@ -23,5 +23,5 @@ with torch.no_grad():
     e1.record(); torch.cuda.synchronize()
 echo = f * torch.exp(1e-4 * torch.arange(512, device="cuda"))
 em = echo.abs().amax(dim=2)
-print(os.path.basename(os.environ.get("DIFFUS_LIB", "in-tree")), "forward 32 poses: %.2f us per launch; rays with |echo| > 8: %d, > 4: %d, > 3: %d, > 2: %d of %d" % (
-    e0.elapsed_time(e1) / 300 * 1e3, int((em > 8).sum()), int((em > 4).sum()), int((em > 3).sum()), int((em > 2).sum()), em.numel()))
+print(os.path.basename(os.environ.get("DIFFUS_LIB", "in-tree")), "forward 32 poses: %.2f us per launch; rays with |echo| > 8: %d, > 4: %d, > 3: %d, > 2: %d, > 1.5: %d, > 1: %d of %d" % (
+    e0.elapsed_time(e1) / 300 * 1e3, int((em > 8).sum()), int((em > 4).sum()), int((em > 3).sum()), int((em > 2).sum()), int((em > 1.5).sum()), int((em > 1).sum()), em.numel()))
