@@ -72,7 +72,7 @@ def test_config3_one_pass_step_values(oracle, vol256):
     d2 = torch.from_numpy(dirs).cuda().requires_grad_(True)
     f2 = da.render_poses(v2, s2, d2, S, ALPHA, sampler="trilinear", layout="paired")
     (f2 ** 2).sum().backward()
-    # frames: the forward kernel evaluates ILL-CONDITIONED rays (|echo| > 8 somewhere: nine rays of this workload) again in
+    # frames: the forward kernel evaluates ILL-CONDITIONED rays (|echo| > 1 somewhere; nine rays of this workload are beyond 8) again in
     # float64, the one-pass step does not (DIFFUS_BWD_REPAIR_FRAME is opt-in): those rays differ by the float32 scan's noise
     # there -- (condition number) x eps, 2.7e-4 of the batch's peak on pose 30 --, every other ray agrees to 2e-5
     fmax = float(f2.detach().abs().max())
